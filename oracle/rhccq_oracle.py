@@ -1,0 +1,731 @@
+"""CPU oracle for the RHCCQ encoder hot path  --  TEST INFRASTRUCTURE ONLY.
+
+This module is a numpy restatement of the reference's palette-hierarchy encoder
+(Riccardoalfieri2003/ROIBasedImageCompression, snapshot 2026-01-16).  It exists so
+that the HIP path can be checked against it; it is *never* imported by the product
+package.  Only tests/, __graft_entry__.smoke() and bench.py's cpu_baseline leg may
+import it.
+
+Parity pins (see DESIGN.md "Oracle"):
+  * every function below is checked against golden vectors that were produced by
+    importing and running the reference itself in the build container
+    (tests/golden/make_golden.py; versions in tests/golden/versions.json);
+  * integer / index work (unique colours, parameters, eps-components, floor-means,
+    merge, remap, dtype choice, container bytes) is bit-exact against those vectors
+    (Tier A);
+  * the two k-means branches reach into scikit-learn 1.7.2 (unpinned by the
+    reference, requirements.txt:6).  Their *algorithm* is restated here with a
+    canonical, order-independent arithmetic ("KM64", below) that the HIP kernels
+    reproduce bit-for-bit.  Against scikit-learn itself the KMeans split reproduces
+    the same partition on most golden cases (Tier A when it does, Tier B = same
+    palette size / equivalent PSNR otherwise); MiniBatchKMeans is Tier B only,
+    because scikit-learn's own result depends on an unstable argsort over tied
+    counts and on a data-dependent position in the MT19937 stream.
+
+Canonical k-means arithmetic "KM64" (shared with csrc/):
+  * points are integer colours p in [0,255]^3;
+  * k-means++ works on EXACT integer squared distances between data points
+    (sklearn: the same quantities in float64, |err| ~ 1e-11), so cumulative sums,
+    potentials and argmins are order-independent;
+  * random draws follow numpy's legacy MT19937 RandomState(42) stream exactly as
+    sklearn consumes it (choice(p=uniform) for the first centre, uniform(size=T)
+    per further centre, T = 2 + int(ln k));
+  * Lloyd (KMeans): x = p - m with m = sum(p)/n (exact integer sum, one IEEE
+    division); dist(i,j) = csq_j + (-2 * ((x0*c0 + x1*c1) + x2*c2)) with
+    csq_j = (c0*c0 + c1*c1) + c2*c2, every operation individually rounded (no FMA);
+    label = first arg-min; new centre = (exact integer sum of member p)/count - m;
+    convergence exactly as sklearn._kmeans_single_lloyd (labels unchanged, or
+    sum_j |dc_j|^2 <= tol with tol = 1e-4 * mean(var)), max_iter = 300.
+  * MiniBatch: see minibatch_kmeans_labels().
+
+Each function cites the reference lines it restates (paths relative to the reference
+root).
+"""
+from __future__ import annotations
+
+import io
+import math
+import pickle
+import struct
+import zlib
+
+import numpy as np
+
+__all__ = [
+    "pack_rgb", "unpack_rgb", "unique_colors", "clustering_params", "eps_threshold",
+    "eps_components", "kmeanspp_int", "kmeans_labels", "split_large_cluster",
+    "minibatch_kmeans_labels", "cluster_palette", "merge_components", "segment_crop",
+    "level1_region", "region_quantization", "quantize_image", "optimal_index_dtype",
+    "encode_frame", "pack_container", "container_bytes", "load_container", "decode_container",
+    "dct_quant_blocks", "counter_hash",
+]
+
+MINIBATCH_THRESHOLD = 10000  # clustering.py:205
+
+
+# --------------------------------------------------------------------------------------
+# K1: unique colours  (encoder/compression/clustering.py:21-48)
+# --------------------------------------------------------------------------------------
+def pack_rgb(rgb):
+    rgb = np.asarray(rgb, dtype=np.uint8).reshape(-1, 3).astype(np.uint32)
+    return (rgb[:, 0] << 16) | (rgb[:, 1] << 8) | rgb[:, 2]
+
+
+def unpack_rgb(keys):
+    keys = np.asarray(keys, dtype=np.uint32)
+    return np.stack([(keys >> 16) & 255, (keys >> 8) & 255, keys & 255], axis=1).astype(np.uint8)
+
+
+def unique_colors(image):
+    """palette = rows of np.unique(pixels, axis=0) (ascending lexicographic R,G,B);
+    indices[p] = rank of pixel p's colour (clustering.py:21-48).  Returns
+    (uint8[P,3], int32[h*w]); None for an empty image (clustering.py:9-10)."""
+    image = np.asarray(image)
+    if image.size == 0:
+        return None
+    keys = pack_rgb(image)
+    u, inv = np.unique(keys, return_inverse=True)
+    return unpack_rgb(u), inv.astype(np.int32).reshape(-1)
+
+
+# --------------------------------------------------------------------------------------
+# parameters  (clustering.py:108-135)
+# --------------------------------------------------------------------------------------
+def clustering_params(n_colors, quality):
+    """eps = 128 - 1.28 q ; mc = ceil((-(q/100) n + n)/q); zeros -> 1; min_samples = 1.
+    quality 0 raises ZeroDivisionError like the reference (clustering.py:129)."""
+    eps = 128 - 1.28 * quality
+    mc = math.ceil((-(quality / 100) * n_colors + n_colors) / quality)
+    if eps == 0:
+        eps = 1
+    if mc == 0:
+        mc = 1
+    return eps, 1, mc
+
+
+# --------------------------------------------------------------------------------------
+# K3/K4: DBSCAN(min_samples=1) == connected components of the eps graph
+# (clustering.py:204-205,233-235)
+# --------------------------------------------------------------------------------------
+def eps_threshold(eps):
+    """Integer form of sklearn's float64 test sum((a/255-b/255)^2) <= (eps/255)^2.
+
+    Returns (thr, boundary): pairs with integer d2 <= thr are neighbours; when
+    `boundary` >= 0, pairs with d2 == boundary sit exactly on the radius and must be
+    decided by the float64 expression (boundary_pair_is_neighbor)."""
+    from fractions import Fraction
+    exact = Fraction(float(eps)) ** 2                    # eps^2 in exact rational arithmetic
+    if exact.denominator == 1:                          # integral: d2 == eps^2 sits on the radius
+        b = int(exact)
+        return b - 1, b
+    return int(math.floor(exact)), -1
+
+
+def boundary_pair_is_neighbor(a, b, eps):
+    """The KD-tree leaf test of sklearn.neighbors (rdist <= r*r, sequential float64 sum)
+    on the values the reference feeds it: c/255.0 and eps/255.0 (clustering.py:205,233)."""
+    r = np.float64(eps) / np.float64(255.0)
+    d = np.float64(0.0)
+    for k in range(3):
+        t = np.float64(a[k]) / np.float64(255.0) - np.float64(b[k]) / np.float64(255.0)
+        d = d + t * t
+    return bool(d <= r * r)
+
+
+def eps_components(colors, eps):
+    """Labels of sklearn DBSCAN(eps/255, min_samples=1) on colors/255: connected
+    components of {d2 <= eps^2}; a component's label is the rank of its smallest member
+    index (dbscan_inner visits points in index order).  int32[N]."""
+    colors = np.asarray(colors, dtype=np.int64).reshape(-1, 3)
+    n = len(colors)
+    if n == 0:
+        return np.zeros(0, np.int32)
+    thr, boundary = eps_threshold(eps)
+    f = colors.astype(np.float64) / np.float64(255.0)
+    r = np.float64(eps) / np.float64(255.0)
+    r2 = r * r
+    lab = np.arange(n)
+    B = 1024
+    while True:                                           # min-label propagation + pointer jumping
+        new = lab.copy()
+        for s in range(0, n, B):
+            a = colors[s:s + B]
+            d2 = ((a[:, None, :] - colors[None, :, :]) ** 2).sum(-1)
+            adj = d2 <= thr
+            if boundary >= 0:
+                bi, bj = np.nonzero(d2 == boundary)
+                if len(bi):
+                    t = f[s + bi] - f[bj]
+                    d = (t[:, 0] * t[:, 0] + t[:, 1] * t[:, 1]) + t[:, 2] * t[:, 2]
+                    adj[bi, bj] = d <= r2
+            new[s:s + B] = np.where(adj, lab[None, :], n).min(1)
+        while True:
+            nn = new[new]
+            if np.array_equal(nn, new):
+                break
+            new = nn
+        if np.array_equal(new, lab):
+            break
+        lab = new
+    # lab[i] = smallest member index of i's component; dense rank in order of that index
+    roots, inv = np.unique(lab, return_inverse=True)
+    return inv.astype(np.int32)
+
+
+# --------------------------------------------------------------------------------------
+# K7: KMeans(n_clusters=k, random_state=42, n_init='auto')  (clustering.py:751-752)
+# --------------------------------------------------------------------------------------
+def _choice_uniform(rs, n):
+    """numpy legacy RandomState.choice(n, p=ones/n): cdf = cumsum(p); cdf /= cdf[-1];
+    searchsorted(cdf, random_sample(), 'right')."""
+    p = np.full(n, 1.0) / np.float64(n)
+    cdf = np.cumsum(p)
+    cdf /= cdf[-1]
+    return int(np.searchsorted(cdf, rs.random_sample(), side="right"))
+
+
+def kmeanspp_int(points, k, rs):
+    """Greedy k-means++ (sklearn.cluster._kmeans._kmeans_plusplus) on integer points with
+    exact integer squared distances.  Returns the chosen point indices int64[k]."""
+    P = np.asarray(points, dtype=np.int64).reshape(-1, 3)
+    n = len(P)
+    T = 2 + int(np.log(k))
+    idx = np.empty(k, np.int64)
+    first = min(_choice_uniform(rs, n), n - 1)
+    idx[0] = first
+    closest = ((P - P[first]) ** 2).sum(1)            # exact ints
+    pot = int(closest.sum())
+    for c in range(1, k):
+        rand_vals = rs.uniform(size=T) * np.float64(pot)
+        cum = np.cumsum(closest).astype(np.float64)   # exact (< 2^53)
+        cand = np.searchsorted(cum, rand_vals)         # side='left'
+        np.clip(cand, None, n - 1, out=cand)
+        d = ((P[cand][:, None, :] - P[None, :, :]) ** 2).sum(-1)
+        np.minimum(d, closest[None, :], out=d)
+        pots = d.sum(1)
+        b = int(np.argmin(pots))
+        pot = int(pots[b])
+        closest = d[b]
+        idx[c] = cand[b]
+    return idx
+
+
+def _km64_dist(X, C):
+    """dist(i,j) = csq_j + (-2*((x0*c0 + x1*c1) + x2*c2)), each op rounded once."""
+    csq = (C[:, 0] * C[:, 0] + C[:, 1] * C[:, 1]) + C[:, 2] * C[:, 2]
+    dot = (X[:, None, 0] * C[None, :, 0] + X[:, None, 1] * C[None, :, 1]) + X[:, None, 2] * C[None, :, 2]
+    return csq[None, :] + (-2.0 * dot)
+
+
+def _argmin_first(D):
+    return np.argmin(D, axis=1).astype(np.int32)      # numpy argmin returns the first minimum
+
+
+def kmeans_labels(points, k, seed=42, max_iter=300, return_info=False):
+    """Restatement of KMeans(k, random_state=seed, n_init=1, algorithm='lloyd',
+    tol=1e-4).fit_predict(points.astype(float)) in KM64 arithmetic.  int32[n]."""
+    P = np.asarray(points, dtype=np.int64).reshape(-1, 3)
+    n = len(P)
+    assert 1 <= k <= n
+    rs = np.random.RandomState(seed)
+    S = P.sum(0)
+    m = S.astype(np.float64) / np.float64(n)
+    X = P.astype(np.float64) - m
+    # tol = mean(var(X, axis=0)) * 1e-4 ; var from exact integers: (n*sum(p^2) - sum(p)^2) / n^2
+    num = n * (P * P).sum(0) - S * S
+    var = num.astype(np.float64) / (np.float64(n) * np.float64(n))
+    tol = ((var[0] + var[1]) + var[2]) / 3.0 * 1e-4
+    init_idx = kmeanspp_int(P, k, rs)
+    C = X[init_idx].copy()
+    labels_old = np.full(n, -1, np.int32)
+    strict = False
+    n_iter = 0
+    relocated = 0
+    for it in range(max_iter):
+        n_iter = it + 1
+        D = _km64_dist(X, C)
+        labels = _argmin_first(D)
+        cnt = np.bincount(labels, minlength=k).astype(np.int64)
+        Sj = np.zeros((k, 3), np.int64)
+        np.add.at(Sj, labels, P)
+        empty = np.nonzero(cnt == 0)[0]
+        if len(empty):
+            # sklearn _relocate_empty_clusters_dense: the n_empty points farthest from their
+            # own centre are moved; canonical order = (distance desc, index asc).
+            diff = X - C[labels]
+            dist = (diff[:, 0] * diff[:, 0] + diff[:, 1] * diff[:, 1]) + diff[:, 2] * diff[:, 2]
+            if dist.max() > 0:
+                far = np.lexsort((np.arange(n), -dist))[:len(empty)]
+                for e, f in zip(empty, far):
+                    old = labels[f]
+                    Sj[old] -= P[f]; cnt[old] -= 1
+                    Sj[e] = P[f]; cnt[e] = 1
+                    relocated += 1
+        Cn = C.copy()
+        nz = cnt > 0
+        Cn[nz] = Sj[nz].astype(np.float64) / cnt[nz, None].astype(np.float64) - m
+        if (~nz).any():                                # _average_centers: copy the heaviest centre
+            Cn[~nz] = Cn[int(np.argmax(cnt))]
+        dC = Cn - C
+        shift = (dC[:, 0] * dC[:, 0] + dC[:, 1] * dC[:, 1]) + dC[:, 2] * dC[:, 2]
+        C = Cn
+        if np.array_equal(labels, labels_old):
+            strict = True
+            break
+        tot = np.float64(0.0)
+        for s in shift:                                # sequential sum over j
+            tot = tot + s
+        if tot <= tol:
+            break
+        labels_old = labels
+    if not strict:
+        labels = _argmin_first(_km64_dist(X, C))
+    if return_info:
+        return labels, {"n_iter": n_iter, "strict": strict, "relocated": relocated, "init_idx": init_idx}
+    return labels
+
+
+def split_large_cluster(colors, mc, kmeans=kmeans_labels):
+    """clustering.py:720-775 -> list of index arrays (into `colors`), depth-first, child
+    label order, each child <= mc unless it cannot be split (n <= 2)."""
+    colors = np.asarray(colors).reshape(-1, 3)
+    n = len(colors)
+    me = np.arange(n)
+    if n <= mc:
+        return [me]
+    n_splits = max(2, (n + mc - 1) // mc)
+    n_splits = min(n_splits, n)
+    if n <= 2 or n_splits < 2:
+        return [me]
+    labels = kmeans(colors, n_splits)
+    out = []
+    for i in range(n_splits):
+        sub = me[labels == i]
+        if len(sub) == 0:
+            continue
+        if len(sub) > mc:
+            out.extend(sub[s] for s in split_large_cluster(colors[sub], mc, kmeans))
+        else:
+            out.append(sub)
+    return out
+
+
+# --------------------------------------------------------------------------------------
+# K8: MiniBatchKMeans(k, batch_size=1000, random_state=42, n_init='auto')
+# (clustering.py:207-230)  --  Tier B
+# --------------------------------------------------------------------------------------
+_M64 = (1 << 64) - 1
+
+
+def counter_hash(seed, stream, counter):
+    """splitmix64-style counter hash shared with csrc/ (vectorised over `counter`)."""
+    counter = np.asarray(counter, dtype=np.uint64)
+    with np.errstate(over="ignore"):
+        z = (np.uint64((seed * 0x9E3779B97F4A7C15) & _M64) + np.uint64((stream * 0xD1B54A32D192ED03) & _M64)
+             + counter * np.uint64(0x2545F4914F6CDD1D))
+        z = (z ^ (z >> np.uint64(30))) * np.uint64(0xBF58476D1CE4E5B9)
+        z = (z ^ (z >> np.uint64(27))) * np.uint64(0x94D049BB133111EB)
+        z = z ^ (z >> np.uint64(31))
+    return z
+
+
+def _bounded(z, n):
+    """(high 32 bits of z * n) >> 32  -> [0, n)."""
+    return ((z >> np.uint64(32)) * np.uint64(n)) >> np.uint64(32)
+
+
+def tree_sum_1024(v):
+    """sum of <= 1024 float64 values by the fixed tree v[i] += v[i+s], s = 512,256,...,1."""
+    buf = np.zeros(1024, np.float64)
+    buf[:len(v)] = v
+    s = 512
+    while s >= 1:
+        buf[:s] = buf[:s] + buf[s:2 * s]
+        s //= 2
+    return buf[0]
+
+
+def _mb_dist(Xb, C):
+    """MiniBatch E-step distance on RAW coordinates (sklearn does not centre here)."""
+    return _km64_dist(Xb, C)
+
+
+def minibatch_kmeans_labels(points, k, seed=42, batch_size=1000, max_iter=100,
+                            max_no_improvement=10, reassignment_ratio=0.01, return_info=False,
+                            assign=None):
+    """Restatement of sklearn 1.7.2 MiniBatchKMeans.fit (cluster/_kmeans.py) with the
+    canonical choices that make it reproducible on a GPU:
+
+      * init: validation_indices and init_indices are drawn from the MT19937 stream exactly as
+        sklearn does (randint(0,n,init_size) twice); the init sample is then SORTED ascending
+        (deviation: sklearn keeps draw order) and greedy k-means++ runs on it in exact integers;
+      * step s draws its batch as idx_b = bounded(counter_hash(seed, 2*s, b), n), b < batch;
+      * E-step distance dist = csq_j + (-2 * dot) on raw 0..255 coordinates, first arg-min;
+      * centre update c = (c*w + S_int) * (1/(w+cnt)) with S_int the exact integer sum of the
+        batch members (order independent);
+      * reassignment (sklearn _mini_batch_step): candidates w < ratio*max(w); if more than
+        batch/2, keep the batch/2 smallest by (w, index) [sklearn: unstable argsort]; the i-th
+        candidate (ascending index) takes batch row perm[i], perm = batch positions ordered by
+        (counter_hash(seed, 2*s+1, b), b) [sklearn: RandomState.choice(replace=False)];
+      * batch inertia = sum_i ((x0-c0)^2 + (x1-c1)^2) + (x2-c2)^2 over the batch, added with the
+        fixed 1024-leaf binary tree of tree_sum_1024(); early stopping: sklearn's EWA rule verbatim.
+    Returns labels int32[n] from a full E-step over all points (first arg-min)."""
+    P = np.asarray(points, dtype=np.int64).reshape(-1, 3)
+    n = len(P)
+    X = P.astype(np.float64)
+    rs = np.random.RandomState(seed)
+    bs = min(batch_size, n)
+    init_size = 3 * bs
+    if init_size < k:
+        init_size = 3 * k
+    init_size = min(init_size, n)
+    rs.randint(0, n, init_size)                        # validation_indices (stream position only)
+    if init_size < n:
+        init_indices = np.sort(rs.randint(0, n, init_size))
+    else:
+        init_indices = np.arange(n)
+    cidx = kmeanspp_int(P[init_indices], k, rs)
+    C = X[init_indices[cidx]].copy()
+    W = np.zeros(k, np.float64)
+    ewa = None
+    ewa_min = None
+    no_impr = 0
+    since = 0
+    n_steps = (max_iter * n) // bs
+    steps_done = 0
+    for s in range(n_steps):
+        steps_done = s + 1
+        bidx = _bounded(counter_hash(seed, 2 * s, np.arange(bs)), n).astype(np.int64)
+        Xb = X[bidx]
+        Pb = P[bidx]
+        since += bs
+        do_reassign = bool((W == 0).any() or since >= 10 * k)
+        if do_reassign:
+            since = 0
+        D = _mb_dist(Xb, C)
+        lab = _argmin_first(D)
+        dd = Xb - C[lab]
+        per = (dd[:, 0] * dd[:, 0] + dd[:, 1] * dd[:, 1]) + dd[:, 2] * dd[:, 2]
+        inertia = tree_sum_1024(per)                    # fixed binary tree, GPU-reproducible
+        cnt = np.bincount(lab, minlength=k).astype(np.int64)
+        Sb = np.zeros((k, 3), np.int64)
+        np.add.at(Sb, lab, Pb)
+        Cn = C.copy()
+        t = cnt > 0
+        Wn = W.copy()
+        Wn[t] = W[t] + cnt[t].astype(np.float64)
+        alpha = 1.0 / Wn[t]
+        Cn[t] = (C[t] * W[t, None] + Sb[t].astype(np.float64)) * alpha[:, None]
+        W = Wn
+        if do_reassign and reassignment_ratio > 0:
+            to_re = W < reassignment_ratio * W.max()
+            if to_re.sum() > 0.5 * bs:
+                order = np.lexsort((np.arange(k), W))            # (w asc, index asc)
+                to_re[order[int(0.5 * bs):]] = False
+            nre = int(to_re.sum())
+            if nre:
+                keys = counter_hash(seed, 2 * s + 1, np.arange(bs))
+                perm = np.lexsort((np.arange(bs), keys))
+                Cn[to_re] = Xb[perm[:nre]]
+            W[to_re] = np.min(W[~to_re])
+        C = Cn
+        # _mini_batch_convergence
+        binert = inertia / np.float64(bs)
+        if s + 1 == 1:
+            continue
+        if ewa is None:
+            ewa = binert
+        else:
+            a = bs * 2.0 / (n + 1)
+            a = min(a, 1)
+            ewa = ewa * (1 - a) + binert * a
+        if ewa_min is None or ewa < ewa_min:
+            no_impr = 0
+            ewa_min = ewa
+        else:
+            no_impr += 1
+        if no_impr >= max_no_improvement:
+            break
+    if assign is None:
+        labels = np.empty(n, np.int32)
+        for s0 in range(0, n, 4096):
+            labels[s0:s0 + 4096] = _argmin_first(_mb_dist(X[s0:s0 + 4096], C))
+    else:
+        labels = assign(X, C)
+    if return_info:
+        return labels, {"n_steps": steps_done, "centers": C, "weights": W}
+    return labels
+
+
+# --------------------------------------------------------------------------------------
+# cluster_palette_colors_parallel  (clustering.py:160-437)
+# --------------------------------------------------------------------------------------
+def cluster_palette(quality, palette, indices, eps, mc, kmeans=kmeans_labels,
+                    minibatch=minibatch_kmeans_labels, return_info=False):
+    """Returns (new_palette uint8[K,3], new_indices int64[h*w]).
+
+    Order of the new palette: black rows; clusters with size <= mc in
+    ascending label order (floor-mean colour); then oversize clusters in ascending label order
+    (reference: as_completed order, nondeterministic), each contributing its k-means children
+    depth-first.  Old->new mapping for split children goes through the reference's
+    find_color_index (first equal row, clustering.py:352-355,803-808), so a duplicated colour's
+    later row is left unmapped (-> 0); mapping is stored in uint16 (clustering.py:373)."""
+    palette = np.asarray(palette, dtype=np.uint8).reshape(-1, 3)
+    indices = np.asarray(indices, dtype=np.int64).reshape(-1)
+    P = len(palette)
+    isblack = np.all(palette == 0, axis=1)
+    black_idx = np.nonzero(isblack)[0]
+    nb_idx = np.nonzero(~isblack)[0]
+    info = {"branch": "none"}
+    if len(nb_idx) == 0:                                   # clustering.py:197-199
+        return (palette, indices, info) if return_info else (palette, indices)
+    nb = palette[nb_idx]
+    if len(nb) >= MINIBATCH_THRESHOLD:
+        k = math.ceil(len(nb) * (quality / 100) / 10)
+        labels = minibatch(nb, k)
+        info["branch"] = "minibatch"
+    else:
+        labels = eps_components(nb, eps)
+        info["branch"] = "dbscan"
+    new_pal = []
+    mapping = np.zeros(P, np.uint16)                        # unmapped -> 0
+    for b in black_idx:
+        mapping[b] = len(new_pal) & 0xFFFF
+        new_pal.append(palette[b])
+    present = np.unique(labels)
+    keys = pack_rgb(palette)
+    order = np.argsort(keys, kind="stable")
+    sorted_keys = keys[order]
+
+    def first_index_of(cols):
+        """find_color_index: first palette row equal to the colour."""
+        ck = pack_rgb(cols)
+        # first occurrence in original order = smallest original index among equal keys
+        pos = np.searchsorted(sorted_keys, ck, side="left")
+        return order[pos]                                   # stable sort => smallest index first
+
+    small, large = [], []
+    for lab in present:
+        rel = np.nonzero(labels == lab)[0]
+        (large if len(rel) > mc else small).append(rel)
+    info["n_clusters"] = len(present)
+    info["n_large"] = len(large)
+    for rel in small:
+        cols = nb[rel].astype(np.int64)
+        avg = (cols.sum(0) // len(rel)).astype(np.uint8)
+        mapping[nb_idx[rel]] = len(new_pal) & 0xFFFF
+        new_pal.append(avg)
+    for rel in large:
+        cols = nb[rel]
+        for sub in split_large_cluster(cols, mc, kmeans):
+            sc = cols[sub].astype(np.int64)
+            avg = (sc.sum(0) // len(sub)).astype(np.uint8)
+            mapping[first_index_of(cols[sub])] = len(new_pal) & 0xFFFF
+            new_pal.append(avg)
+    new_pal = np.array(new_pal, dtype=np.uint8).reshape(-1, 3)
+    new_idx = mapping[indices].astype(np.int64)
+    return (new_pal, new_idx, info) if return_info else (new_pal, new_idx)
+
+
+# --------------------------------------------------------------------------------------
+# K5: merge_region_components_simple  (merging.py:8-120)
+# --------------------------------------------------------------------------------------
+def merge_components(comps, bbox):
+    """comps: list of dicts {top_left:(r,c), shape:(h,w), palette:uint8[K,3], indices:int[h*w]}.
+    Returns None for an empty list, the single component (as-is, merging.py:16-21) for one, else
+    {top_left, shape, palette, indices(int64 flat)} with black = index 0, colours in first-seen
+    order scanning components last->first, each in raster order, earlier components winning."""
+    if not comps:
+        return None
+    if len(comps) == 1:
+        c = dict(comps[0])
+        c["single"] = True
+        return c
+    minr, minc, maxr, maxc = (int(v) for v in bbox)
+    H, W = maxr - minr, maxc - minc
+    canvas = np.zeros((H, W), np.int64)
+    colors = [0]                                           # packed keys, black first
+    lut = {0: 0}
+    for seg in reversed(comps):
+        h, w = seg["shape"]
+        pal = np.asarray(seg["palette"], dtype=np.uint8).reshape(-1, 3)
+        idx = np.asarray(seg["indices"], dtype=np.int64).reshape(h, w)
+        r0, c0 = seg["top_left"][0] - minr, seg["top_left"][1] - minc
+        rr, cc = np.mgrid[0:h, 0:w]
+        ok = (rr + r0 >= 0) & (rr + r0 < H) & (cc + c0 >= 0) & (cc + c0 < W) & (idx < len(pal)) & (idx >= 0)
+        if len(pal) == 0:
+            continue
+        pk = pack_rgb(pal)[np.clip(idx, 0, len(pal) - 1)]
+        ok &= pk != 0
+        pkv = pk[ok]
+        if pkv.size == 0:
+            continue
+        u, first = np.unique(pkv, return_index=True)
+        for key in u[np.argsort(first)]:
+            if int(key) not in lut:
+                lut[int(key)] = len(colors)
+                colors.append(int(key))
+        gidx = np.array([lut[int(kk)] for kk in u])[np.searchsorted(u, pkv)]
+        canvas[(rr + r0)[ok], (cc + c0)[ok]] = gidx
+    return {"top_left": (minr, minc), "shape": (H, W), "palette": unpack_rgb(np.array(colors, dtype=np.uint32)),
+            "indices": canvas.reshape(-1), "single": False}
+
+
+# --------------------------------------------------------------------------------------
+# K0/K0b + level-1 driver  (subregions.py:315-449,634-679)
+# --------------------------------------------------------------------------------------
+def segment_crop(region_image, segment_mask):
+    """Tight bbox of the mask +-2 px clamped to the region, zero outside the mask, black pixels
+    inside the mask replaced by the segment's non-black pixel of smallest R^2+G^2+B^2 (first in
+    mask raster order) (subregions.py:338-421).  Returns (crop uint8[ch,cw,3], (r0,c0)) or None."""
+    rows, cols = np.where(segment_mask)
+    if len(rows) == 0:
+        return None
+    h, w = region_image.shape[:2]
+    r0, r1 = max(0, rows.min() - 2), min(h - 1, rows.max() + 2)
+    c0, c1 = max(0, cols.min() - 2), min(w - 1, cols.max() + 2)
+    crop = region_image[r0:r1 + 1, c0:c1 + 1]
+    m = segment_mask[r0:r1 + 1, c0:c1 + 1]
+    out = np.zeros_like(crop)
+    px = crop[m].copy()
+    isb = np.all(px == 0, axis=1)
+    if isb.any() and (~isb).any():
+        nb = px[~isb].astype(np.int64)
+        n2 = (nb * nb).sum(1)
+        px[isb] = nb[int(np.argmin(n2))].astype(np.uint8)
+    out[m] = px
+    return out, (int(r0), int(c0))
+
+
+def level1_region(image, bbox, bbox_mask, seglabels, quality, kmeans=kmeans_labels,
+                  minibatch=minibatch_kmeans_labels):
+    """One region of subregion_quantization (subregions.py:98-679) given its SLIC label map
+    (0 = background, ids ascending as in extract_slic_segment_boundaries, slic.py:158-160).
+    Returns the list the reference appends to subregions_components: [merged] or [components]."""
+    minr, minc, maxr, maxc = bbox
+    region_image = image[minr:maxr, minc:maxc]
+    comps = []
+    ids = np.unique(seglabels)
+    for sid in ids[ids != 0]:
+        segmask = (seglabels == sid) & bbox_mask
+        res = segment_crop(region_image, segmask)
+        if res is None:
+            continue
+        crop, (r0, c0) = res
+        pal, idx = unique_colors(crop)
+        eps, _, mc = clustering_params(len(pal), quality)
+        npal, nidx = cluster_palette(quality, pal, idx, eps, mc, kmeans, minibatch)
+        comps.append({"top_left": (r0 + minr, c0 + minc), "shape": crop.shape[:2], "palette": npal, "indices": nidx})
+    if len(comps) > 1:
+        return [merge_components(comps, (minr, minc, maxr, maxc))]
+    return comps
+
+
+def region_quantization(components, H, W, quality, kmeans=kmeans_labels, minibatch=minibatch_kmeans_labels):
+    """regions.py:9-70: merge all components of one class on the full-image canvas, cluster."""
+    merged = merge_components(components, (0, 0, H, W))
+    if merged is None:
+        raise IndexError("no components")                 # regions.py:43 regions_image[0]
+    pal = np.asarray(merged["palette"], dtype=np.uint8).reshape(-1, 3)
+    eps, _, mc = clustering_params(len(pal), quality)
+    npal, nidx = cluster_palette(quality, pal, merged["indices"], eps, mc, kmeans, minibatch)
+    return {"top_left": merged["top_left"], "shape": merged["shape"], "palette": npal, "indices": nidx}
+
+
+def optimal_index_dtype(indices):
+    """compression.py:360-372: by max index."""
+    mx = int(np.max(indices)) if len(indices) else 0
+    return "uint8" if mx < 256 else ("uint16" if mx < 65536 else "uint32")
+
+
+def quantize_image(components, H, W, quality, kmeans=kmeans_labels, minibatch=minibatch_kmeans_labels):
+    """image.py:243-286."""
+    out = region_quantization(components, H, W, quality, kmeans, minibatch)
+    out["indices_dtype"] = optimal_index_dtype(out["indices"])
+    return out
+
+
+def encode_frame(image, classes, qualities, kmeans=kmeans_labels, minibatch=minibatch_kmeans_labels):
+    """Three-level chain of rhccq.ipynb:978-1039.
+
+    classes: list (ROI first, then non-ROI) of lists of regions, each region a dict
+    {bbox:(minr,minc,maxr,maxc), bbox_mask: bool[h,w], seglabels: int32[h,w] (0 = background)}.
+    qualities: per-class level-1 quality.  Returns dict with per-level results."""
+    H, W = image.shape[:2]
+    lvl2 = []
+    l1_all = []
+    q2s = []
+    for regions, q in zip(classes, qualities):
+        l1 = []
+        for reg in regions:
+            l1.extend(level1_region(image, reg["bbox"], reg["bbox_mask"], reg["seglabels"], q, kmeans, minibatch))
+        l1_all.append(l1)
+        q2 = min(q * 2, 100)
+        q2s.append(q2)
+        try:
+            lvl2.append(region_quantization(l1, H, W, q2, kmeans, minibatch))
+        except IndexError:                                  # rhccq.ipynb:1009-1013 swallows
+            pass
+    q3 = min(sum(q2s), 100)
+    fin = quantize_image(lvl2, H, W, q3, kmeans, minibatch)
+    return {"level1": l1_all, "level2": lvl2, "final": fin}
+
+
+# --------------------------------------------------------------------------------------
+# container  (compression.py:10-22,119-142,151-220 ; uncompression.py:58-150)
+# --------------------------------------------------------------------------------------
+def pack_container(palette, indices, shape):
+    """lossless_compress_optimized: dict {s,l,p,i,d}."""
+    palette = np.asarray(palette, dtype=np.uint8).reshape(-1, 3)
+    indices = np.asarray(indices).reshape(-1)
+    d = optimal_index_dtype(indices)
+    return {"s": tuple(int(v) for v in shape), "l": len(palette),
+            "p": zlib.compress(palette.tobytes(), 9),
+            "i": zlib.compress(indices.astype(d).tobytes(), 9), "d": d}
+
+
+def container_bytes(pkg):
+    """save_compressed: b'RHCCQ' + <I len + zlib9(pickle5(pkg))."""
+    body = zlib.compress(pickle.dumps(pkg, protocol=5), 9)
+    return b"RHCCQ" + struct.pack("<I", len(body)) + body
+
+
+class _SafeUnpickler(pickle.Unpickler):
+    _OK = {("numpy._core.multiarray", "scalar"), ("numpy.core.multiarray", "scalar"), ("numpy", "dtype")}
+
+    def find_class(self, module, name):
+        if (module, name) in self._OK:
+            return super().find_class(module, name)
+        raise pickle.UnpicklingError(f"forbidden global {module}.{name}")
+
+
+def load_container(raw):
+    if raw[:5] != b"RHCCQ":
+        raise ValueError("Invalid file format")
+    n = struct.unpack("<I", raw[5:9])[0]
+    return _SafeUnpickler(io.BytesIO(zlib.decompress(raw[9:9 + n]))).load()
+
+
+def decode_container(pkg):
+    h, w = int(pkg["s"][0]), int(pkg["s"][1])
+    pal = np.frombuffer(zlib.decompress(pkg["p"]), np.uint8).reshape(-1, 3)
+    idx = np.frombuffer(zlib.decompress(pkg["i"]), np.dtype(pkg.get("d", "uint16")))
+    return pal, idx, (h, w)
+
+
+# --------------------------------------------------------------------------------------
+# EXTENSION (no reference counterpart): block DCT-II + per-region quantisation
+# --------------------------------------------------------------------------------------
+def dct_quant_blocks(plane, block, qstep_map):
+    """Orthonormal 2-D DCT-II on non-overlapping block x block tiles of a float32 plane
+    (scipy.fft.dctn(type=2, norm='ortho') semantics), then q = rint(coef / qstep) where
+    qstep_map holds one step per tile.  Returns (coef float32[H,W], q int16[H,W])."""
+    from scipy.fft import dctn
+    H, W = plane.shape
+    assert H % block == 0 and W % block == 0
+    t = plane.astype(np.float32).reshape(H // block, block, W // block, block).transpose(0, 2, 1, 3)
+    c = dctn(t.astype(np.float64), type=2, norm="ortho", axes=(2, 3))
+    q = np.rint(c / qstep_map[:, :, None, None]).astype(np.int16)
+    c = c.transpose(0, 2, 1, 3).reshape(H, W).astype(np.float32)
+    q = q.transpose(0, 2, 1, 3).reshape(H, W)
+    return c, q
