@@ -1,0 +1,178 @@
+/* rhccq.h -- C ABI of the MI355X-native RHCCQ encoder hot path (librhccq_hip.so).
+ *
+ * Boundary: the reference has no FFI; its "interface" for this path is the Python
+ * import surface encoder.compression.{clustering,merging,subregions,regions,image}.  The host side
+ * stays in Python (roibasedimagecompression_amd/, mirrored under encoder/ and decoder/) and calls
+ * the entry points below through ctypes.  Each entry point is a thin launcher of hand-written
+ * gfx950 kernels; the reference function it replaces is cited next to it (paths relative to the
+ * reference root).
+ *
+ * Conventions
+ *   - every pointer is a DEVICE pointer (HIP, same device as the context) unless the parameter
+ *     name ends in _host; buffers are caller-allocated (the Python side uses torch tensors);
+ *   - every call is asynchronous on the context's HIP stream unless documented "synchronises";
+ *   - return value: 0 on success, negative on error (RHCCQ_E_*); rhccq_last_error() gives text;
+ *   - no exceptions cross the boundary; a context is not thread-safe, use one per thread;
+ *   - colours travel as "keys": uint32 = R<<16 | G<<8 | B  (lexicographic order == numeric order).
+ */
+#ifndef RHCCQ_H
+#define RHCCQ_H
+
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define RHCCQ_OK 0
+#define RHCCQ_E_ARG (-1)     /* bad argument / shape */
+#define RHCCQ_E_HIP (-2)     /* HIP runtime error */
+#define RHCCQ_E_LIMIT (-3)   /* size beyond what the kernel supports */
+
+#define RHCCQ_BITMAP_WORDS 524288u /* 2^24 colours / 32 bits: one unique-colour bitmap per job */
+#define RHCCQ_EPS_LDS_MAX 10240    /* eps-components: problems up to this size run from LDS */
+#define RHCCQ_KM_LDS_MAX 10240     /* k-means: problems up to this size keep their points in LDS */
+
+typedef struct rhccq_ctx rhccq_ctx;
+
+/* ---- context ------------------------------------------------------------------------------ */
+int rhccq_ctx_create(int device, void* hip_stream /* NULL = the default (null) stream */, rhccq_ctx** out);
+void rhccq_ctx_destroy(rhccq_ctx* ctx);
+const char* rhccq_last_error(const rhccq_ctx* ctx);
+int rhccq_sync(rhccq_ctx* ctx);                 /* hipStreamSynchronize on the context stream */
+void* rhccq_stream(rhccq_ctx* ctx);             /* the hipStream_t in use */
+int rhccq_abi_version(void);
+
+/* ---- parameters: compute_clustering_params (encoder/compression/clustering.py:108-135) ----- */
+int rhccq_params(int64_t n_colors, double quality, double* eps_host, int64_t* max_colors_host);
+/* integer form of the eps predicate: thr, boundary (-1 if none), r2 = (eps/255)^2 */
+int rhccq_eps_threshold(double eps, int32_t* thr_host, int32_t* boundary_host, double* r2_host);
+
+/* ---- K0/K1: per-job unique colours ----------------------------------------------------------
+ * A "job" is one set of pixels whose unique colours are wanted: a whole crop
+ * (get_all_unique_colors, clustering.py:4-103) or one SLIC segment of a region
+ * (subregion_quantization, subregions.py:315-426).  Each job owns a 2^24-bit bitmap.
+ *
+ * rhccq_job_scan: one pass over the pixels.  For class c (0..n_class-1) pixel p belongs to job
+ *   job_base[c] + labels[c][p] - 1 when labels[c][p] > 0 (labels[c] == NULL: every pixel belongs
+ *   to job job_base[c]).  Sets the colour bit of every non-black pixel, accumulates per-job
+ *   stats {min_r, max_r, min_c, max_c, count, n_black} (int32[6] each, caller-initialised to
+ *   {INT_MAX,-1,INT_MAX,-1,0,0}); black pixels set their bit only when black_is_colour != 0. */
+int rhccq_job_scan(rhccq_ctx* ctx, const uint8_t* rgb, int32_t H, int32_t W, int32_t n_class,
+                   const int32_t* const* labels_host /* host array of device ptrs */,
+                   const int32_t* job_base_host, int32_t black_is_colour, uint32_t* bitmaps,
+                   int32_t* stats);
+/* set bit 0 (black) of the bitmaps of the jobs listed (device int32 list) */
+int rhccq_job_set_black(rhccq_ctx* ctx, uint32_t* bitmaps, const int32_t* jobs, int32_t n_jobs);
+/* popcount of every job's bitmap -> counts[n_jobs] (device) and chunk sums workspace
+ * chunk_sums[n_jobs*512] */
+int rhccq_bitmap_count(rhccq_ctx* ctx, const uint32_t* bitmaps, int32_t n_jobs, uint32_t* chunk_sums,
+                       int32_t* counts);
+/* per-word exclusive prefix (word_prefix[n_jobs*BITMAP_WORDS]) and the sorted palette keys of each
+ * job written at keys_out[pal_off[j] ...) (np.unique order, clustering.py:22) */
+int rhccq_bitmap_emit(rhccq_ctx* ctx, const uint32_t* bitmaps, int32_t n_jobs, const uint32_t* chunk_sums,
+                      const int64_t* pal_off /* device int64[n_jobs] */, uint32_t* word_prefix,
+                      uint32_t* keys_out);
+/* black-in-segment fix (subregions.py:393-421): per job the in-mask non-black pixel with the
+ * smallest R^2+G^2+B^2, first in raster order; best[job] = (norm2<<40 | pixel index), init ~0 */
+int rhccq_job_blackfix(rhccq_ctx* ctx, const uint8_t* rgb, int32_t H, int32_t W, int32_t n_class,
+                       const int32_t* const* labels_host, const int32_t* job_base_host,
+                       const uint8_t* job_needs_fix /* device u8[n_jobs] */, unsigned long long* best);
+/* per-pixel palette index (rank of the pixel's colour in its job's palette) and/or first raster
+ * position of every palette entry.  fix_key[job] (device, may be NULL) = key that replaces in-mask
+ * black pixels (0 = no fix).  idx_out (int32[n_class][H*W], may be NULL): -1 where the pixel has no
+ * job.  first_pos (int32 at pal_off[job]+rank, may be NULL) must be initialised to INT_MAX. */
+int rhccq_job_index(rhccq_ctx* ctx, const uint8_t* rgb, int32_t H, int32_t W, int32_t n_class,
+                    const int32_t* const* labels_host, const int32_t* job_base_host,
+                    const uint32_t* bitmaps, const uint32_t* word_prefix, const int64_t* pal_off,
+                    const uint32_t* fix_key, int32_t* idx_out, int32_t* first_pos);
+
+/* ---- K3/K4: DBSCAN(min_samples=1) labels = eps-graph components (clustering.py:233-235) -------
+ * problems p = 0..n_prob-1: keys[off[p] .. off[p]+n[p]); labels in sklearn order (rank of the
+ * component's smallest member index).  desc: int32[n_prob][4] = {off, n, thr, boundary},
+ * r2: double[n_prob].  labels_out int32 (same offsets), ncomp_out int32[n_prob]. */
+int rhccq_eps_components(rhccq_ctx* ctx, const uint32_t* keys, const int32_t* desc, const double* r2,
+                         int32_t n_prob, int32_t max_n, int32_t* labels_out, int32_t* ncomp_out);
+
+/* ---- K2: per-cluster floor-mean colour (clustering.py:304-310,346-355) ----------------------
+ * sums[k*4] (uint64 r,g,b,count) zero-initialised by the caller; labels < 0 are skipped. */
+int rhccq_cluster_sums(rhccq_ctx* ctx, const uint32_t* keys, const int32_t* labels, int64_t n,
+                       unsigned long long* sums);
+int rhccq_cluster_means(rhccq_ctx* ctx, const unsigned long long* sums, int64_t k, uint32_t* keys_out);
+
+/* ---- K7: KMeans split of oversize clusters (clustering.py:720-775 -> sklearn KMeans) ---------
+ * desc: int32[n_prob][6] = {off, n, k, rand_off, first_index, T}; rand: the MT19937 uniforms
+ * (k-1)*T per problem at rand_off (numpy RandomState(42).uniform stream, generated on the host);
+ * work: double workspace, 8*k doubles per problem at 8*koff (koff = desc-order prefix of k, given
+ * as koff int64[n_prob]); labels_out int32 at the same offsets as keys; info int32[n_prob][4] =
+ * {n_iter, strict, relocations, reserved}. */
+int rhccq_kmeans(rhccq_ctx* ctx, const uint32_t* keys, const int32_t* desc, const int64_t* koff,
+                 const double* rand, int32_t n_prob, int32_t max_n, double* work, int32_t* labels_out,
+                 int32_t* info);
+/* ---- K8: MiniBatchKMeans branch (clustering.py:207-230), canonical spec in oracle/ ------------ */
+typedef struct rhccq_mbk_problem {
+  int64_t off;        /* first key of the problem in keys[] */
+  int64_t n;          /* number of points */
+  int64_t k;          /* n_clusters */
+  int64_t koff;       /* offset (in clusters) into centres / weights / work arrays */
+  int64_t init_off;   /* offset into init_idx (sorted sample indices, relative to off) */
+  int64_t init_n;     /* init sample size */
+  int64_t rand_off;   /* offset into rand (k-1)*T uniforms */
+  int32_t first;      /* first centre (index into the init sample) */
+  int32_t T;          /* n_local_trials */
+} rhccq_mbk_problem;
+/* greedy k-means++ on the init sample in exact integers; writes centres[(koff+j)*4 + {0,1,2}]
+ * (doubles, raw 0..255 coordinates) and chosen[koff+j] (index into the init sample) */
+int rhccq_mbk_init(rhccq_ctx* ctx, const uint32_t* keys, const rhccq_mbk_problem* probs_host,
+                   int32_t n_prob, const int32_t* init_idx, const double* rand, double* centres,
+                   int32_t* chosen);
+/* run up to n_steps mini-batch steps starting at step index step0 for every problem that has not
+ * converged; state: double[n_prob][8] = {ewa, ewa_min, no_improvement, since_reassign, done,
+ * steps_done, have_ewa, reserved}; weights double[sum k]; seed = 42 stream of counter_hash() */
+int rhccq_mbk_steps(rhccq_ctx* ctx, const uint32_t* keys, const rhccq_mbk_problem* probs_host,
+                    int32_t n_prob, int64_t step0, int32_t n_steps, uint64_t seed, double* centres,
+                    double* weights, double* state, void* work, int64_t work_bytes);
+int64_t rhccq_mbk_work_bytes(const rhccq_mbk_problem* probs_host, int32_t n_prob);
+/* final E-step over all points: labels_out int32 at the key offsets (first arg-min of
+ * csq_j + (-2 * dot), brute force order-independent; uses a centre grid for pruning) */
+int rhccq_mbk_assign(rhccq_ctx* ctx, const uint32_t* keys, const rhccq_mbk_problem* probs_host,
+                     int32_t n_prob, const double* centres, void* work, int64_t work_bytes,
+                     int32_t* labels_out);
+
+/* ---- K6: index remap gather (clustering.py:373-377) ------------------------------------------ */
+int rhccq_remap(rhccq_ctx* ctx, const int32_t* idx, int64_t n, const int32_t* lut, int64_t lut_n,
+                int32_t* out);
+/* fused final remap of a frame: class precedence = class order; lut values < 0 are transparent;
+ * out_elem_bytes in {1,2,4} */
+int rhccq_frame_remap(rhccq_ctx* ctx, const uint8_t* rgb, int32_t H, int32_t W, int32_t n_class,
+                      const int32_t* const* labels_host, const int32_t* job_base_host,
+                      const uint32_t* bitmaps, const uint32_t* word_prefix, const int64_t* pal_off,
+                      const uint32_t* fix_key, const int32_t* lut, int32_t default_index, void* out,
+                      int32_t out_elem_bytes);
+
+/* ---- K5: merge_region_components_simple (encoder/compression/merging.py:8-120) ---------------
+ * one component at a time (the host assigns first-seen global indices between the two calls):
+ * first_pos[idx] = min raster position (component raster) of in-canvas pixels showing palette
+ * entry idx (entries >= pal_n are skipped, merging.py:72); paint writes lut[idx] where >= 0. */
+int rhccq_merge_firstpos(rhccq_ctx* ctx, const int32_t* idx, int32_t h, int32_t w, int32_t top, int32_t left,
+                         int32_t canvas_h, int32_t canvas_w, int32_t pal_n, int32_t* first_pos);
+int rhccq_merge_paint(rhccq_ctx* ctx, const int32_t* idx, int32_t h, int32_t w, int32_t top, int32_t left,
+                      int32_t canvas_h, int32_t canvas_w, const int32_t* lut, int32_t pal_n, int32_t* canvas);
+
+/* ---- decode: palette[index] LUT gather (decoder/uncompression/uncompression.py:209) ---------- */
+int rhccq_decode(rhccq_ctx* ctx, const void* idx, int32_t idx_elem_bytes, int64_t n, const uint8_t* palette,
+                 int64_t pal_n, uint8_t* rgb_out);
+
+/* ---- EXTENSION (no reference counterpart): block DCT-II + region quantisation --
+ * plane: float32[H*W]; block in {8,16}; qstep: float32 per tile [(H/block)*(W/block)];
+ * coef_out float32[H*W] (may be NULL), q_out int16[H*W]. */
+int rhccq_dct_quant(rhccq_ctx* ctx, const float* plane, int32_t H, int32_t W, int32_t block,
+                    const float* qstep, float* coef_out, int16_t* q_out);
+/* RGB u8 -> luma float32 (BT.601) plus per-tile qstep from a ROI mask (u8, may be NULL) */
+int rhccq_luma_qstep(rhccq_ctx* ctx, const uint8_t* rgb, const uint8_t* roi_mask, int32_t H, int32_t W,
+                     int32_t block, float q_roi, float q_bg, float* luma_out, float* qstep_out);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* RHCCQ_H */

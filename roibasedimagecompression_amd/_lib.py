@@ -1,0 +1,86 @@
+"""ctypes binding of librhccq_hip.so (C ABI declared in include/rhccq.h).
+
+The product path has NO CPU fallback: if the library is missing or a GPU is not present the
+functions below raise.  (The CPU oracle lives in oracle/ and is test infrastructure only.)
+"""
+import ctypes as C
+import os
+
+HERE = os.path.dirname(os.path.abspath(__file__))
+LIB_PATH = os.path.join(HERE, "librhccq_hip.so")
+
+_lib = None
+
+c_void_p, c_int32, c_int64, c_double, c_float, c_uint64 = C.c_void_p, C.c_int32, C.c_int64, C.c_double, C.c_float, C.c_uint64
+
+
+class MbkProblem(C.Structure):
+    """struct rhccq_mbk_problem (include/rhccq.h)."""
+    _fields_ = [("off", c_int64), ("n", c_int64), ("k", c_int64), ("koff", c_int64), ("init_off", c_int64),
+                ("init_n", c_int64), ("rand_off", c_int64), ("first", c_int32), ("T", c_int32)]
+
+
+# name -> (restype, argtypes).  Every symbol include/rhccq.h declares is listed here; the CPU test
+# suite checks that the library exports all of them.
+PROTOTYPES = {
+    "rhccq_abi_version": (c_int32, []),
+    "rhccq_ctx_create": (c_int32, [c_int32, c_void_p, C.POINTER(c_void_p)]),
+    "rhccq_ctx_destroy": (None, [c_void_p]),
+    "rhccq_last_error": (C.c_char_p, [c_void_p]),
+    "rhccq_sync": (c_int32, [c_void_p]),
+    "rhccq_stream": (c_void_p, [c_void_p]),
+    "rhccq_params": (c_int32, [c_int64, c_double, C.POINTER(c_double), C.POINTER(c_int64)]),
+    "rhccq_eps_threshold": (c_int32, [c_double, C.POINTER(c_int32), C.POINTER(c_int32), C.POINTER(c_double)]),
+    "rhccq_job_scan": (c_int32, [c_void_p, c_void_p, c_int32, c_int32, c_int32, C.POINTER(c_void_p), C.POINTER(c_int32),
+                                 c_int32, c_void_p, c_void_p]),
+    "rhccq_job_set_black": (c_int32, [c_void_p, c_void_p, c_void_p, c_int32]),
+    "rhccq_bitmap_count": (c_int32, [c_void_p, c_void_p, c_int32, c_void_p, c_void_p]),
+    "rhccq_bitmap_emit": (c_int32, [c_void_p, c_void_p, c_int32, c_void_p, c_void_p, c_void_p, c_void_p]),
+    "rhccq_job_blackfix": (c_int32, [c_void_p, c_void_p, c_int32, c_int32, c_int32, C.POINTER(c_void_p), C.POINTER(c_int32),
+                                     c_void_p, c_void_p]),
+    "rhccq_job_index": (c_int32, [c_void_p, c_void_p, c_int32, c_int32, c_int32, C.POINTER(c_void_p), C.POINTER(c_int32),
+                                  c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p]),
+    "rhccq_eps_components": (c_int32, [c_void_p, c_void_p, c_void_p, c_void_p, c_int32, c_int32, c_void_p, c_void_p]),
+    "rhccq_cluster_sums": (c_int32, [c_void_p, c_void_p, c_void_p, c_int64, c_void_p]),
+    "rhccq_cluster_means": (c_int32, [c_void_p, c_void_p, c_int64, c_void_p]),
+    "rhccq_kmeans": (c_int32, [c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_int32, c_int32, c_void_p, c_void_p, c_void_p]),
+    "rhccq_mbk_init": (c_int32, [c_void_p, c_void_p, C.POINTER(MbkProblem), c_int32, c_void_p, c_void_p, c_void_p, c_void_p]),
+    "rhccq_mbk_steps": (c_int32, [c_void_p, c_void_p, C.POINTER(MbkProblem), c_int32, c_int64, c_int32, c_uint64, c_void_p,
+                                  c_void_p, c_void_p, c_void_p, c_int64]),
+    "rhccq_mbk_work_bytes": (c_int64, [C.POINTER(MbkProblem), c_int32]),
+    "rhccq_mbk_assign": (c_int32, [c_void_p, c_void_p, C.POINTER(MbkProblem), c_int32, c_void_p, c_void_p, c_int64, c_void_p]),
+    "rhccq_remap": (c_int32, [c_void_p, c_void_p, c_int64, c_void_p, c_int64, c_void_p]),
+    "rhccq_frame_remap": (c_int32, [c_void_p, c_void_p, c_int32, c_int32, c_int32, C.POINTER(c_void_p), C.POINTER(c_int32),
+                                    c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_int32, c_void_p, c_int32]),
+    "rhccq_merge_firstpos": (c_int32, [c_void_p, c_void_p, c_int32, c_int32, c_int32, c_int32, c_int32, c_int32, c_int32, c_void_p]),
+    "rhccq_merge_paint": (c_int32, [c_void_p, c_void_p, c_int32, c_int32, c_int32, c_int32, c_int32, c_int32, c_void_p, c_int32, c_void_p]),
+    "rhccq_decode": (c_int32, [c_void_p, c_void_p, c_int32, c_int64, c_void_p, c_int64, c_void_p]),
+    "rhccq_dct_quant": (c_int32, [c_void_p, c_void_p, c_int32, c_int32, c_int32, c_void_p, c_void_p, c_void_p]),
+    "rhccq_luma_qstep": (c_int32, [c_void_p, c_void_p, c_void_p, c_int32, c_int32, c_int32, c_float, c_float, c_void_p, c_void_p]),
+}
+
+
+class RhccqError(RuntimeError):
+    pass
+
+
+def load():
+    """Load the shared library (no GPU needed to load it) and attach prototypes."""
+    global _lib
+    if _lib is not None:
+        return _lib
+    if not os.path.exists(LIB_PATH):
+        raise RhccqError(f"{LIB_PATH} is missing: run `python -m roibasedimagecompression_amd.build` "
+                         "(or __graft_entry__.build()); there is no CPU fallback for the product path")
+    lib = C.CDLL(LIB_PATH)
+    for name, (res, args) in PROTOTYPES.items():
+        fn = getattr(lib, name)          # AttributeError if the symbol is not exported
+        fn.restype = res
+        fn.argtypes = args
+    _lib = lib
+    return lib
+
+
+def exported_symbols():
+    lib = load()
+    return [n for n in PROTOTYPES if hasattr(lib, n)]

@@ -1,0 +1,69 @@
+"""Build librhccq_hip.so (gfx950) in-tree with hipcc.  No GPU needed: hipcc cross-compiles."""
+import os
+import shutil
+import subprocess
+import sys
+
+HERE = os.path.dirname(os.path.abspath(__file__))
+CSRC = os.path.join(HERE, "csrc")
+LIB = os.path.join(HERE, "librhccq_hip.so")
+SOURCES = ["api.hip", "k1_unique.hip", "k3_epscomp.hip", "k7_kmeans.hip", "k8_minibatch.hip", "k5_merge.hip", "dct_ext.hip"]
+# -ffp-contract=off: the KM64 float64 arithmetic and the eps boundary test must round every
+# operation separately (bit-exact against the oracle / the reference's non-FMA x86 arithmetic)
+FLAGS = ["--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC", "-ffp-contract=off", "-Wall", "-Wno-unused-function"]
+
+
+def hipcc():
+    for c in (os.environ.get("HIPCC"), "/opt/rocm/bin/hipcc", shutil.which("hipcc")):
+        if c and os.path.exists(c):
+            return c
+    raise RuntimeError("hipcc not found (expected /opt/rocm/bin/hipcc)")
+
+
+def needs_build():
+    if not os.path.exists(LIB):
+        return True
+    t = os.path.getmtime(LIB)
+    deps = [os.path.join(CSRC, f) for f in os.listdir(CSRC)] + [os.path.join(HERE, "..", "include", "rhccq.h")]
+    return any(os.path.getmtime(d) > t for d in deps)
+
+
+def build(force=False, verbose=True):
+    if not force and not needs_build():
+        return LIB
+    cc = hipcc()
+    objdir = os.path.join(HERE, "build")
+    os.makedirs(objdir, exist_ok=True)
+    objs = []
+    procs = []
+    for src in SOURCES:
+        sp = os.path.join(CSRC, src)
+        if not os.path.exists(sp):
+            continue
+        obj = os.path.join(objdir, src.replace(".hip", ".o"))
+        objs.append(obj)
+        if (not force and os.path.exists(obj) and os.path.getmtime(obj) > max(
+                os.path.getmtime(sp), os.path.getmtime(os.path.join(CSRC, "rhccq_common.h")),
+                os.path.getmtime(os.path.join(HERE, "..", "include", "rhccq.h")))):
+            continue
+        cmd = [cc] + FLAGS + ["-c", sp, "-o", obj]
+        if verbose:
+            print(" ".join(cmd), flush=True)
+        procs.append((src, subprocess.Popen(cmd, stdout=subprocess.PIPE, stderr=subprocess.STDOUT)))
+    for src, pr in procs:
+        out, _ = pr.communicate()
+        if pr.returncode != 0:
+            sys.stderr.write(out.decode())
+            raise RuntimeError(f"hipcc failed on {src}")
+        if verbose and out.strip():
+            print(out.decode())
+    cmd = [cc, "--offload-arch=gfx950", "-shared", "-fPIC", "-o", LIB] + objs
+    if verbose:
+        print(" ".join(cmd), flush=True)
+    subprocess.check_call(cmd)
+    return LIB
+
+
+if __name__ == "__main__":
+    build(force="--force" in sys.argv)
+    print(LIB)

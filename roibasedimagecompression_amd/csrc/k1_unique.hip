@@ -1,0 +1,476 @@
+// K0 / K0b / K1 / K6: per-job unique colours through a 2^24-bit bitmap per job.
+//
+// Reference behaviour replaced: np.unique(pixels, axis=0) + the per-pixel dict loop of
+// get_all_unique_colors (encoder/compression/clustering.py:21-48), the per-segment mask / bbox /
+// crop of subregion_quantization (encoder/compression/subregions.py:317-383), its black-in-segment
+// fix (:393-421) and the index remap gather (clustering.py:373-377).
+//
+// MI355X design: a colour is a 24-bit key, so "sorted unique + rank" needs no sort: one streaming
+// pass sets bits (test-before-atomicOr; the bitmaps of the jobs of a frame live in L2 / Infinity
+// Cache), a popcount scan turns the bitmap into ranks (== np.unique order because the key order is
+// the lexicographic R,G,B order), and every later pass recomputes a pixel's palette index as
+//   word_prefix[key >> 5] + popc(word & lower_mask)
+// instead of storing a 4 B/pixel index map.  All per-pixel passes are HBM-streaming kernels:
+// 4 pixels per thread, 12 B of RGB as three dwords + one int4 of labels per class.
+#include "rhccq_common.h"
+
+namespace rhccq {
+
+constexpr int kMaxClass = 4;
+
+struct ClassArgs {
+  const int32_t* labels[kMaxClass];
+  int32_t job_base[kMaxClass];
+  int32_t n_class;
+};
+
+// ---- tiny per-block hash table of job statistics (LDS), flushed with global atomics ------------
+constexpr int kStatSlots = 64;
+struct StatTable {
+  int job[kStatSlots];
+  int minr[kStatSlots], maxr[kStatSlots], minc[kStatSlots], maxc[kStatSlots];
+  unsigned cnt[kStatSlots], nblack[kStatSlots];
+};
+
+__device__ __forceinline__ void stat_add(StatTable& t, int32_t* gstats, int job, int r, int c, bool black) {
+  unsigned h = ((unsigned)job * 2654435761u) >> 26;  // 6 bits
+  for (int probe = 0; probe < kStatSlots; ++probe) {
+    int s = (h + probe) & (kStatSlots - 1);
+    int cur = t.job[s];
+    if (cur == -1) {
+      int old = atomicCAS(&t.job[s], -1, job);
+      cur = (old == -1) ? job : old;
+    }
+    if (cur == job) {
+      atomicMin(&t.minr[s], r);
+      atomicMax(&t.maxr[s], r);
+      atomicMin(&t.minc[s], c);
+      atomicMax(&t.maxc[s], c);
+      atomicAdd(&t.cnt[s], 1u);
+      if (black) atomicAdd(&t.nblack[s], 1u);
+      return;
+    }
+  }
+  // table full: straight to global memory
+  int32_t* g = gstats + (size_t)job * 6;
+  atomicMin(&g[0], r);
+  atomicMax(&g[1], r);
+  atomicMin(&g[2], c);
+  atomicMax(&g[3], c);
+  atomicAdd((unsigned*)&g[4], 1u);
+  if (black) atomicAdd((unsigned*)&g[5], 1u);
+}
+
+__device__ __forceinline__ void load4px(const uint8_t* rgb, int64_t p0, int64_t n_px, uint32_t key[4]) {
+  // 4 pixels = 12 bytes starting at a 4-byte aligned address when p0 % 4 == 0 and rgb is 4-B aligned
+  if (p0 + 4 <= n_px) {
+    const uint32_t* q = reinterpret_cast<const uint32_t*>(rgb + p0 * 3);
+    uint32_t a = q[0], b = q[1], c = q[2];
+    // bytes: a = r0 g0 b0 r1 | b = g1 b1 r2 g2 | c = b2 r3 g3 b3   (little endian)
+    key[0] = ((a & 255u) << 16) | (((a >> 8) & 255u) << 8) | ((a >> 16) & 255u);
+    key[1] = ((a >> 24) << 16) | ((b & 255u) << 8) | ((b >> 8) & 255u);
+    key[2] = (((b >> 16) & 255u) << 16) | ((b >> 24) << 8) | (c & 255u);
+    key[3] = (((c >> 8) & 255u) << 16) | (((c >> 16) & 255u) << 8) | (c >> 24);
+  } else {
+    for (int i = 0; i < 4; ++i) {
+      int64_t p = p0 + i;
+      key[i] = p < n_px ? ((uint32_t)rgb[p * 3] << 16) | ((uint32_t)rgb[p * 3 + 1] << 8) | rgb[p * 3 + 2] : 0u;
+    }
+  }
+}
+
+__device__ __forceinline__ void load4lab(const int32_t* lab, int64_t p0, int64_t n_px, int32_t out[4]) {
+  if (lab == nullptr) {
+    out[0] = out[1] = out[2] = out[3] = 1;
+  } else if (p0 + 4 <= n_px) {
+    int4 v = *reinterpret_cast<const int4*>(lab + p0);
+    out[0] = v.x; out[1] = v.y; out[2] = v.z; out[3] = v.w;
+  } else {
+    for (int i = 0; i < 4; ++i) out[i] = (p0 + i < n_px) ? lab[p0 + i] : 0;
+  }
+}
+
+__global__ __launch_bounds__(256) void job_scan_kernel(const uint8_t* __restrict__ rgb, int H, int W, ClassArgs ca,
+                                                       int black_is_colour, uint32_t* bitmaps,
+                                                       int32_t* stats) {
+  __shared__ StatTable tab;
+  for (int i = threadIdx.x; i < kStatSlots; i += blockDim.x) {
+    tab.job[i] = -1;
+    tab.minr[i] = INT_MAX; tab.maxr[i] = -1; tab.minc[i] = INT_MAX; tab.maxc[i] = -1;
+    tab.cnt[i] = 0; tab.nblack[i] = 0;
+  }
+  __syncthreads();
+  const int64_t n_px = (int64_t)H * W;
+  const int64_t n_quads = (n_px + 3) >> 2;
+  // each block owns a contiguous run of quads so that its pixels touch few jobs
+  const int64_t per_block = (n_quads + gridDim.x - 1) / gridDim.x;
+  const int64_t q_begin = (int64_t)blockIdx.x * per_block;
+  const int64_t q_end = min(q_begin + per_block, n_quads);
+  for (int64_t q = q_begin + threadIdx.x; q < q_end; q += blockDim.x) {
+    const int64_t p0 = q << 2;
+    uint32_t key[4];
+    load4px(rgb, p0, n_px, key);
+    for (int c = 0; c < ca.n_class; ++c) {
+      int32_t lab[4];
+      load4lab(ca.labels[c], p0, n_px, lab);
+#pragma unroll
+      for (int i = 0; i < 4; ++i) {
+        if (lab[i] <= 0 || p0 + i >= n_px) continue;
+        const int job = ca.job_base[c] + lab[i] - 1;
+        const int r = (int)((p0 + i) / W), col = (int)((p0 + i) % W);
+        const bool black = key[i] == 0u;
+        stat_add(tab, stats, job, r, col, black);
+        if (!black || black_is_colour) {
+          uint32_t* wptr = bitmaps + (size_t)job * RHCCQ_BITMAP_WORDS + (key[i] >> 5);
+          const uint32_t bit = 1u << (key[i] & 31u);
+          if ((*wptr & bit) == 0u) atomicOr(wptr, bit);   // bits are only ever set: a stale read costs one redundant atomic
+        }
+      }
+    }
+  }
+  __syncthreads();
+  for (int s = threadIdx.x; s < kStatSlots; s += blockDim.x) {
+    if (tab.job[s] >= 0) {
+      int32_t* g = stats + (size_t)tab.job[s] * 6;
+      atomicMin(&g[0], tab.minr[s]);
+      atomicMax(&g[1], tab.maxr[s]);
+      atomicMin(&g[2], tab.minc[s]);
+      atomicMax(&g[3], tab.maxc[s]);
+      atomicAdd((unsigned*)&g[4], tab.cnt[s]);
+      if (tab.nblack[s]) atomicAdd((unsigned*)&g[5], tab.nblack[s]);
+    }
+  }
+}
+
+__global__ void job_set_black_kernel(uint32_t* bitmaps, const int32_t* jobs, int n) {
+  int i = blockIdx.x * blockDim.x + threadIdx.x;
+  if (i < n) atomicOr(bitmaps + (size_t)jobs[i] * RHCCQ_BITMAP_WORDS, 1u);
+}
+
+// ---- bitmap -> ranks ---------------------------------------------------------------------------
+constexpr int kChunkWords = 1024;                      // 4 KiB of bitmap per block
+constexpr int kChunks = RHCCQ_BITMAP_WORDS / kChunkWords;  // 512 per job
+
+__global__ __launch_bounds__(256) void bitmap_chunk_count_kernel(const uint32_t* __restrict__ bitmaps,
+                                                                 uint32_t* __restrict__ chunk_sums) {
+  __shared__ unsigned red[4];
+  const size_t job = blockIdx.y;
+  const uint4 v = reinterpret_cast<const uint4*>(bitmaps + job * RHCCQ_BITMAP_WORDS + (size_t)blockIdx.x * kChunkWords)[threadIdx.x];
+  unsigned c = __popc(v.x) + __popc(v.y) + __popc(v.z) + __popc(v.w);
+  unsigned t = block_sum<unsigned>(c, red);
+  if (threadIdx.x == 0) chunk_sums[job * kChunks + blockIdx.x] = t;
+}
+
+// in-place exclusive scan of the 512 chunk sums of each job; counts[job] = total
+__global__ __launch_bounds__(512) void bitmap_chunk_scan_kernel(uint32_t* __restrict__ chunk_sums, int32_t* __restrict__ counts) {
+  __shared__ unsigned red[9];
+  const size_t job = blockIdx.x;
+  unsigned v = chunk_sums[job * kChunks + threadIdx.x];
+  unsigned tot;
+  unsigned ex = block_exscan<unsigned>(v, red, &tot);
+  chunk_sums[job * kChunks + threadIdx.x] = ex;
+  if (threadIdx.x == 0) counts[job] = (int32_t)tot;
+}
+
+__global__ __launch_bounds__(256) void bitmap_emit_kernel(const uint32_t* __restrict__ bitmaps, const uint32_t* __restrict__ chunk_base,
+                                                          const int64_t* __restrict__ pal_off, uint32_t* __restrict__ word_prefix,
+                                                          uint32_t* __restrict__ keys_out) {
+  __shared__ unsigned red[5];
+  const size_t job = blockIdx.y;
+  const size_t w0 = (size_t)blockIdx.x * kChunkWords + (size_t)threadIdx.x * 4;
+  const uint4 v = reinterpret_cast<const uint4*>(bitmaps + job * RHCCQ_BITMAP_WORDS)[w0 >> 2];
+  const unsigned c0 = __popc(v.x), c1 = __popc(v.y), c2 = __popc(v.z), c3 = __popc(v.w);
+  unsigned tot;
+  unsigned ex = block_exscan<unsigned>(c0 + c1 + c2 + c3, red, &tot);
+  if (tot == 0) return;                                 // empty chunk: its prefixes are never read
+  const unsigned base = chunk_base[job * kChunks + blockIdx.x] + ex;
+  uint4 pre;
+  pre.x = base; pre.y = base + c0; pre.z = base + c0 + c1; pre.w = base + c0 + c1 + c2;
+  reinterpret_cast<uint4*>(word_prefix + job * RHCCQ_BITMAP_WORDS)[w0 >> 2] = pre;
+  if (keys_out) {
+    uint32_t* out = keys_out + pal_off[job];
+    uint32_t words[4] = {v.x, v.y, v.z, v.w};
+    unsigned rank = base;
+#pragma unroll
+    for (int j = 0; j < 4; ++j) {
+      uint32_t m = words[j];
+      while (m) {
+        int b = __ffs(m) - 1;
+        m &= m - 1;
+        out[rank++] = (uint32_t)((w0 + j) << 5) | (uint32_t)b;
+      }
+    }
+  }
+}
+
+// ---- K0b: black-in-segment fix -----------------------------------------------------------------
+__global__ __launch_bounds__(256) void job_blackfix_kernel(const uint8_t* __restrict__ rgb, int H, int W, ClassArgs ca,
+                                                           const uint8_t* __restrict__ needs_fix, unsigned long long* __restrict__ best) {
+  const int64_t n_px = (int64_t)H * W;
+  const int64_t n_quads = (n_px + 3) >> 2;
+  for (int64_t q = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; q < n_quads; q += (int64_t)gridDim.x * blockDim.x) {
+    const int64_t p0 = q << 2;
+    uint32_t key[4];
+    load4px(rgb, p0, n_px, key);
+    for (int c = 0; c < ca.n_class; ++c) {
+      int32_t lab[4];
+      load4lab(ca.labels[c], p0, n_px, lab);
+#pragma unroll
+      for (int i = 0; i < 4; ++i) {
+        if (lab[i] <= 0 || p0 + i >= n_px || key[i] == 0u) continue;
+        const int job = ca.job_base[c] + lab[i] - 1;
+        if (!needs_fix[job]) continue;
+        const unsigned r = key_r(key[i]), g = key_g(key[i]), b = key_b(key[i]);
+        const unsigned long long v = ((unsigned long long)(r * r + g * g + b * b) << 40) | (unsigned long long)(p0 + i);
+        if (v < best[job]) atomicMin(&best[job], v);       // monotone: a stale read costs one redundant atomic
+      }
+    }
+  }
+}
+
+// ---- rank lookup shared by K1d and K6 ----------------------------------------------------------
+__device__ __forceinline__ uint32_t rank_of(const uint32_t* __restrict__ bitmaps, const uint32_t* __restrict__ word_prefix, int job, uint32_t key) {
+  const size_t w = (size_t)job * RHCCQ_BITMAP_WORDS + (key >> 5);
+  const uint32_t word = bitmaps[w];
+  return word_prefix[w] + __popc(word & ((1u << (key & 31u)) - 1u));
+}
+
+__global__ __launch_bounds__(256) void job_index_kernel(const uint8_t* __restrict__ rgb, int H, int W, ClassArgs ca,
+                                                        const uint32_t* __restrict__ bitmaps, const uint32_t* __restrict__ word_prefix,
+                                                        const int64_t* __restrict__ pal_off, const uint32_t* __restrict__ fix_key,
+                                                        int32_t* __restrict__ idx_out, int32_t* __restrict__ first_pos) {
+  const int64_t n_px = (int64_t)H * W;
+  const int64_t n_quads = (n_px + 3) >> 2;
+  for (int64_t q = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; q < n_quads; q += (int64_t)gridDim.x * blockDim.x) {
+    const int64_t p0 = q << 2;
+    uint32_t key[4];
+    load4px(rgb, p0, n_px, key);
+    for (int c = 0; c < ca.n_class; ++c) {
+      int32_t lab[4];
+      load4lab(ca.labels[c], p0, n_px, lab);
+      int32_t res[4];
+#pragma unroll
+      for (int i = 0; i < 4; ++i) {
+        res[i] = -1;
+        if (lab[i] <= 0 || p0 + i >= n_px) continue;
+        const int job = ca.job_base[c] + lab[i] - 1;
+        uint32_t k = key[i];
+        if (k == 0u && fix_key) k = fix_key[job];      // recoloured in-mask black (0 = keep black)
+        const uint32_t rk = rank_of(bitmaps, word_prefix, job, k);
+        res[i] = (int32_t)rk;
+        if (first_pos) {
+          int32_t* fp = first_pos + pal_off[job] + rk;
+          const int32_t p = (int32_t)(p0 + i);
+          if (p < *fp) atomicMin(fp, p);
+        }
+      }
+      if (idx_out) {
+        int32_t* o = idx_out + (size_t)c * n_px + p0;
+        if (p0 + 4 <= n_px) {
+          *reinterpret_cast<int4*>(o) = make_int4(res[0], res[1], res[2], res[3]);
+        } else {
+          for (int i = 0; i < 4 && p0 + i < n_px; ++i) o[i] = res[i];
+        }
+      }
+    }
+  }
+}
+
+template <typename OutT>
+__global__ __launch_bounds__(256) void frame_remap_kernel(const uint8_t* __restrict__ rgb, int H, int W, ClassArgs ca,
+                                                          const uint32_t* __restrict__ bitmaps, const uint32_t* __restrict__ word_prefix,
+                                                          const int64_t* __restrict__ pal_off, const uint32_t* __restrict__ fix_key,
+                                                          const int32_t* __restrict__ lut, int32_t default_index, OutT* __restrict__ out) {
+  const int64_t n_px = (int64_t)H * W;
+  const int64_t n_quads = (n_px + 3) >> 2;
+  for (int64_t q = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; q < n_quads; q += (int64_t)gridDim.x * blockDim.x) {
+    const int64_t p0 = q << 2;
+    uint32_t key[4];
+    load4px(rgb, p0, n_px, key);
+    int32_t res[4] = {-1, -1, -1, -1};
+    for (int c = 0; c < ca.n_class; ++c) {
+      if (res[0] >= 0 && res[1] >= 0 && res[2] >= 0 && res[3] >= 0) break;
+      int32_t lab[4];
+      load4lab(ca.labels[c], p0, n_px, lab);
+#pragma unroll
+      for (int i = 0; i < 4; ++i) {
+        if (res[i] >= 0 || lab[i] <= 0 || p0 + i >= n_px) continue;
+        const int job = ca.job_base[c] + lab[i] - 1;
+        uint32_t k = key[i];
+        if (k == 0u && fix_key) k = fix_key[job];
+        res[i] = lut[pal_off[job] + rank_of(bitmaps, word_prefix, job, k)];
+      }
+    }
+#pragma unroll
+    for (int i = 0; i < 4; ++i)
+      if (res[i] < 0) res[i] = default_index;
+    if (p0 + 4 <= n_px) {
+      if constexpr (sizeof(OutT) == 1) {
+        *reinterpret_cast<uint32_t*>(out + p0) = (uint32_t)res[0] | ((uint32_t)res[1] << 8) | ((uint32_t)res[2] << 16) | ((uint32_t)res[3] << 24);
+      } else if constexpr (sizeof(OutT) == 2) {
+        *reinterpret_cast<uint2*>(out + p0) = make_uint2((uint32_t)res[0] | ((uint32_t)res[1] << 16), (uint32_t)res[2] | ((uint32_t)res[3] << 16));
+      } else {
+        *reinterpret_cast<int4*>(out + p0) = make_int4(res[0], res[1], res[2], res[3]);
+      }
+    } else {
+      for (int i = 0; i < 4 && p0 + i < n_px; ++i) out[p0 + i] = (OutT)res[i];
+    }
+  }
+}
+
+__global__ __launch_bounds__(256) void remap_kernel(const int32_t* __restrict__ idx, int64_t n, const int32_t* __restrict__ lut,
+                                                    int64_t lut_n, int32_t* __restrict__ out) {
+  for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (int64_t)gridDim.x * blockDim.x) {
+    const int32_t v = idx[i];
+    out[i] = (v >= 0 && v < lut_n) ? lut[v] : 0;
+  }
+}
+
+template <typename IdxT>
+__global__ __launch_bounds__(256) void decode_kernel(const IdxT* __restrict__ idx, int64_t n, const uint8_t* __restrict__ pal,
+                                                     int64_t pal_n, uint8_t* __restrict__ rgb) {
+  for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (int64_t)gridDim.x * blockDim.x) {
+    int64_t v = (int64_t)idx[i];
+    if (v >= pal_n) v = 0;
+    rgb[i * 3] = pal[v * 3]; rgb[i * 3 + 1] = pal[v * 3 + 1]; rgb[i * 3 + 2] = pal[v * 3 + 2];
+  }
+}
+
+static int make_class_args(rhccq_ctx* ctx, int n_class, const int32_t* const* labels, const int32_t* job_base, ClassArgs* ca) {
+  if (n_class < 1 || n_class > kMaxClass) return rhccq_fail(ctx, RHCCQ_E_ARG, "n_class must be 1..4");
+  ca->n_class = n_class;
+  for (int i = 0; i < kMaxClass; ++i) {
+    ca->labels[i] = i < n_class ? labels[i] : nullptr;
+    ca->job_base[i] = i < n_class ? job_base[i] : 0;
+  }
+  return 0;
+}
+
+static inline int stream_grid(int64_t items, int per_block) {
+  int64_t b = (items + per_block - 1) / per_block;
+  if (b < 1) b = 1;
+  if (b > 256 * 8) b = 256 * 8;                         // 8 blocks per CU, grid-stride beyond
+  return (int)b;
+}
+
+}  // namespace rhccq
+
+using namespace rhccq;
+
+extern "C" {
+
+int rhccq_job_scan(rhccq_ctx* ctx, const uint8_t* rgb, int32_t H, int32_t W, int32_t n_class,
+                   const int32_t* const* labels_host, const int32_t* job_base_host, int32_t black_is_colour,
+                   uint32_t* bitmaps, int32_t* stats) {
+  if (!ctx || !rgb || !bitmaps || !stats || H <= 0 || W <= 0) return rhccq_fail(ctx, RHCCQ_E_ARG, "job_scan: bad argument");
+  if (((uintptr_t)rgb & 3u) != 0) return rhccq_fail(ctx, RHCCQ_E_ARG, "job_scan: rgb must be 4-byte aligned");
+  ClassArgs ca;
+  if (int e = make_class_args(ctx, n_class, labels_host, job_base_host, &ca)) return e;
+  const int64_t quads = ((int64_t)H * W + 3) / 4;
+  // contiguous runs per block keep the per-block job hash small; cap the grid at 8 blocks per CU
+  int64_t g64 = (quads + 1023) / 1024;
+  if (g64 > 2048) g64 = 2048;
+  if (g64 < 1) g64 = 1;
+  const int grid = (int)g64;
+  hipLaunchKernelGGL(job_scan_kernel, dim3(grid), dim3(256), 0, ctx->stream, rgb, H, W, ca, black_is_colour, bitmaps, stats);
+  RHCCQ_LAUNCH_CHECK(ctx);
+  return 0;
+}
+
+int rhccq_job_set_black(rhccq_ctx* ctx, uint32_t* bitmaps, const int32_t* jobs, int32_t n_jobs) {
+  if (!ctx || !bitmaps || (n_jobs > 0 && !jobs)) return rhccq_fail(ctx, RHCCQ_E_ARG, "job_set_black: bad argument");
+  if (n_jobs <= 0) return 0;
+  hipLaunchKernelGGL(job_set_black_kernel, dim3((n_jobs + 63) / 64), dim3(64), 0, ctx->stream, bitmaps, jobs, n_jobs);
+  RHCCQ_LAUNCH_CHECK(ctx);
+  return 0;
+}
+
+int rhccq_bitmap_count(rhccq_ctx* ctx, const uint32_t* bitmaps, int32_t n_jobs, uint32_t* chunk_sums, int32_t* counts) {
+  if (!ctx || !bitmaps || !chunk_sums || !counts || n_jobs <= 0) return rhccq_fail(ctx, RHCCQ_E_ARG, "bitmap_count: bad argument");
+  if (n_jobs > 65535) return rhccq_fail(ctx, RHCCQ_E_LIMIT, "bitmap_count: more than 65535 jobs per call");
+  hipLaunchKernelGGL(bitmap_chunk_count_kernel, dim3(kChunks, n_jobs), dim3(256), 0, ctx->stream, bitmaps, chunk_sums);
+  hipLaunchKernelGGL(bitmap_chunk_scan_kernel, dim3(n_jobs), dim3(512), 0, ctx->stream, chunk_sums, counts);
+  RHCCQ_LAUNCH_CHECK(ctx);
+  return 0;
+}
+
+int rhccq_bitmap_emit(rhccq_ctx* ctx, const uint32_t* bitmaps, int32_t n_jobs, const uint32_t* chunk_sums,
+                      const int64_t* pal_off, uint32_t* word_prefix, uint32_t* keys_out) {
+  if (!ctx || !bitmaps || !chunk_sums || !word_prefix || n_jobs <= 0 || (keys_out && !pal_off))
+    return rhccq_fail(ctx, RHCCQ_E_ARG, "bitmap_emit: bad argument");
+  if (n_jobs > 65535) return rhccq_fail(ctx, RHCCQ_E_LIMIT, "bitmap_emit: more than 65535 jobs per call");
+  hipLaunchKernelGGL(bitmap_emit_kernel, dim3(kChunks, n_jobs), dim3(256), 0, ctx->stream, bitmaps, chunk_sums, pal_off, word_prefix, keys_out);
+  RHCCQ_LAUNCH_CHECK(ctx);
+  return 0;
+}
+
+int rhccq_job_blackfix(rhccq_ctx* ctx, const uint8_t* rgb, int32_t H, int32_t W, int32_t n_class,
+                       const int32_t* const* labels_host, const int32_t* job_base_host, const uint8_t* job_needs_fix,
+                       unsigned long long* best) {
+  if (!ctx || !rgb || !job_needs_fix || !best || H <= 0 || W <= 0) return rhccq_fail(ctx, RHCCQ_E_ARG, "job_blackfix: bad argument");
+  ClassArgs ca;
+  if (int e = make_class_args(ctx, n_class, labels_host, job_base_host, &ca)) return e;
+  const int64_t quads = ((int64_t)H * W + 3) / 4;
+  hipLaunchKernelGGL(job_blackfix_kernel, dim3(stream_grid(quads, 256)), dim3(256), 0, ctx->stream, rgb, H, W, ca, job_needs_fix, best);
+  RHCCQ_LAUNCH_CHECK(ctx);
+  return 0;
+}
+
+int rhccq_job_index(rhccq_ctx* ctx, const uint8_t* rgb, int32_t H, int32_t W, int32_t n_class,
+                    const int32_t* const* labels_host, const int32_t* job_base_host, const uint32_t* bitmaps,
+                    const uint32_t* word_prefix, const int64_t* pal_off, const uint32_t* fix_key, int32_t* idx_out,
+                    int32_t* first_pos) {
+  if (!ctx || !rgb || !bitmaps || !word_prefix || !pal_off || H <= 0 || W <= 0 || (int64_t)H * W > INT32_MAX)
+    return rhccq_fail(ctx, RHCCQ_E_ARG, "job_index: bad argument");
+  ClassArgs ca;
+  if (int e = make_class_args(ctx, n_class, labels_host, job_base_host, &ca)) return e;
+  const int64_t quads = ((int64_t)H * W + 3) / 4;
+  hipLaunchKernelGGL(job_index_kernel, dim3(stream_grid(quads, 256)), dim3(256), 0, ctx->stream, rgb, H, W, ca, bitmaps, word_prefix,
+                     pal_off, fix_key, idx_out, first_pos);
+  RHCCQ_LAUNCH_CHECK(ctx);
+  return 0;
+}
+
+int rhccq_frame_remap(rhccq_ctx* ctx, const uint8_t* rgb, int32_t H, int32_t W, int32_t n_class,
+                      const int32_t* const* labels_host, const int32_t* job_base_host, const uint32_t* bitmaps,
+                      const uint32_t* word_prefix, const int64_t* pal_off, const uint32_t* fix_key, const int32_t* lut,
+                      int32_t default_index, void* out, int32_t out_elem_bytes) {
+  if (!ctx || !rgb || !bitmaps || !word_prefix || !pal_off || !lut || !out || H <= 0 || W <= 0)
+    return rhccq_fail(ctx, RHCCQ_E_ARG, "frame_remap: bad argument");
+  ClassArgs ca;
+  if (int e = make_class_args(ctx, n_class, labels_host, job_base_host, &ca)) return e;
+  const int64_t quads = ((int64_t)H * W + 3) / 4;
+  const dim3 grid(stream_grid(quads, 256)), block(256);
+  switch (out_elem_bytes) {
+    case 1: hipLaunchKernelGGL(frame_remap_kernel<uint8_t>, grid, block, 0, ctx->stream, rgb, H, W, ca, bitmaps, word_prefix, pal_off, fix_key, lut, default_index, (uint8_t*)out); break;
+    case 2: hipLaunchKernelGGL(frame_remap_kernel<uint16_t>, grid, block, 0, ctx->stream, rgb, H, W, ca, bitmaps, word_prefix, pal_off, fix_key, lut, default_index, (uint16_t*)out); break;
+    case 4: hipLaunchKernelGGL(frame_remap_kernel<int32_t>, grid, block, 0, ctx->stream, rgb, H, W, ca, bitmaps, word_prefix, pal_off, fix_key, lut, default_index, (int32_t*)out); break;
+    default: return rhccq_fail(ctx, RHCCQ_E_ARG, "frame_remap: out_elem_bytes must be 1, 2 or 4");
+  }
+  RHCCQ_LAUNCH_CHECK(ctx);
+  return 0;
+}
+
+int rhccq_remap(rhccq_ctx* ctx, const int32_t* idx, int64_t n, const int32_t* lut, int64_t lut_n, int32_t* out) {
+  if (!ctx || n < 0 || (n > 0 && (!idx || !lut || !out))) return rhccq_fail(ctx, RHCCQ_E_ARG, "remap: bad argument");
+  if (n == 0) return 0;
+  hipLaunchKernelGGL(remap_kernel, dim3(stream_grid(n, 1024)), dim3(256), 0, ctx->stream, idx, n, lut, lut_n, out);
+  RHCCQ_LAUNCH_CHECK(ctx);
+  return 0;
+}
+
+int rhccq_decode(rhccq_ctx* ctx, const void* idx, int32_t idx_elem_bytes, int64_t n, const uint8_t* palette, int64_t pal_n, uint8_t* rgb_out) {
+  if (!ctx || n < 0 || (n > 0 && (!idx || !palette || !rgb_out)) || pal_n <= 0) return rhccq_fail(ctx, RHCCQ_E_ARG, "decode: bad argument");
+  if (n == 0) return 0;
+  const dim3 grid(stream_grid(n, 1024)), block(256);
+  switch (idx_elem_bytes) {
+    case 1: hipLaunchKernelGGL(decode_kernel<uint8_t>, grid, block, 0, ctx->stream, (const uint8_t*)idx, n, palette, pal_n, rgb_out); break;
+    case 2: hipLaunchKernelGGL(decode_kernel<uint16_t>, grid, block, 0, ctx->stream, (const uint16_t*)idx, n, palette, pal_n, rgb_out); break;
+    case 4: hipLaunchKernelGGL(decode_kernel<uint32_t>, grid, block, 0, ctx->stream, (const uint32_t*)idx, n, palette, pal_n, rgb_out); break;
+    default: return rhccq_fail(ctx, RHCCQ_E_ARG, "decode: idx_elem_bytes must be 1, 2 or 4");
+  }
+  RHCCQ_LAUNCH_CHECK(ctx);
+  return 0;
+}
+
+}  // extern "C"

@@ -1,0 +1,284 @@
+// K3 + K4: DBSCAN(eps, min_samples = 1) labels of a palette == connected components of the graph
+// { (i,j) : |c_i - c_j|^2 <= eps^2 } numbered by smallest member index.
+//
+// Reference behaviour replaced: sklearn DBSCAN(eps/255, 1).fit_predict(palette/255) at
+// encoder/compression/clustering.py:233-235 (KD-tree radius_neighbors materialising ~N^2 neighbour
+// lists + Cython DFS).
+//
+// MI355X design (one workgroup per palette, everything staged in LDS; the palette is <= 40 KB):
+//   K3  fixed-radius neighbour pass over an LDS-staged spatial grid in RGB space.  Cells have side
+//       s with 3 (s-1)^2 <= eps^2 whenever that keeps the grid <= 16^3: then all points of a cell are
+//       mutually within eps (a clique) and only ONE witness pair per pair of nearby cells is needed;
+//       a wave searches a cell pair 64 candidate pairs at a time and stops at the first hit
+//       (wave ballot).  For small eps (cell side fixed at 16) every pair of nearby cells is tested
+//       exhaustively.
+//   K4  lock-free union-find in LDS (root = smallest index, atomicCAS linking, path halving), then a
+//       flag + block prefix-sum turns roots into sklearn's label order.
+// The eps predicate is the exact integer d2 <= thr; pairs with d2 == boundary (eps^2 integral) are
+// decided by the same float64 expression the KD-tree leaf test uses, with FMA contraction disabled.
+// Not a dense contraction: no MFMA; the work is integer VALU + LDS.
+#include "rhccq_common.h"
+
+namespace rhccq {
+
+constexpr int kEpsThreads = 512;
+constexpr int kMaxCells = 4096;  // 16^3
+
+struct EpsArrays {
+  uint32_t* keys;     // [n]
+  uint32_t* parent;   // [n]
+  uint32_t* perm;     // [n]  points ordered by cell, later reused for flags / ranks
+};
+
+__device__ __forceinline__ uint32_t uf_find(uint32_t* parent, uint32_t i) {
+  while (true) {
+    uint32_t p = parent[i];
+    if (p == i) return i;
+    uint32_t gp = parent[p];
+    if (gp != p) parent[i] = gp;  // path halving; racy writes only ever move towards an ancestor
+    i = p;
+  }
+}
+
+__device__ __forceinline__ void uf_union(uint32_t* parent, uint32_t a, uint32_t b) {
+  while (true) {
+    a = uf_find(parent, a);
+    b = uf_find(parent, b);
+    if (a == b) return;
+    if (a < b) { uint32_t t = a; a = b; b = t; }       // a = larger root goes under b
+    if (atomicCAS(&parent[a], a, b) == a) return;
+  }
+}
+
+// float64 boundary test: sum_k (a_k/255 - b_k/255)^2 <= r2, sequential, no FMA
+__device__ __forceinline__ bool boundary_neighbor(uint32_t ka, uint32_t kb, double r2) {
+  double d = 0.0;
+  {
+    double t = __dsub_rn(__ddiv_rn((double)key_r(ka), 255.0), __ddiv_rn((double)key_r(kb), 255.0));
+    d = __dadd_rn(d, __dmul_rn(t, t));
+  }
+  {
+    double t = __dsub_rn(__ddiv_rn((double)key_g(ka), 255.0), __ddiv_rn((double)key_g(kb), 255.0));
+    d = __dadd_rn(d, __dmul_rn(t, t));
+  }
+  {
+    double t = __dsub_rn(__ddiv_rn((double)key_b(ka), 255.0), __ddiv_rn((double)key_b(kb), 255.0));
+    d = __dadd_rn(d, __dmul_rn(t, t));
+  }
+  return d <= r2;
+}
+
+__device__ __forceinline__ bool is_neighbor(uint32_t ka, uint32_t kb, int thr, int boundary, double r2) {
+  const int d2 = dist2_keys(ka, kb);
+  if (d2 <= thr) return true;
+  if (d2 == boundary) return boundary_neighbor(ka, kb, r2);
+  return false;
+}
+
+template <bool kLds>
+__device__ void eps_components_body(const uint32_t* __restrict__ gkeys, int n, int thr, int boundary, double r2,
+                                    int32_t* __restrict__ labels_out, int32_t* __restrict__ ncomp_out, EpsArrays A,
+                                    unsigned* cell_start /* [kMaxCells+1] */, unsigned* cell_fill /* [kMaxCells] */,
+                                    unsigned* red /* [16] */) {
+  const int tid = threadIdx.x;
+  // effective squared radius for geometric pruning
+  const int reach2 = boundary >= 0 ? boundary : thr;
+  // clique cell side: largest s with 3 (s-1)^2 <= reach2 (conservative for the boundary case: use thr)
+  int s = 1;
+  while (3 * s * s <= thr) ++s;                         // now 3 (s-1)^2 <= thr < 3 s^2
+  const bool clique = s >= 16;
+  if (!clique) s = 16;
+  const int G = (255 / s) + 1;                          // cells per axis (<= 16)
+  const int n_cells = G * G * G;
+
+  for (int i = tid; i < n; i += blockDim.x) {
+    A.keys[i] = gkeys[i];
+    A.parent[i] = i;
+  }
+  for (int c = tid; c <= n_cells; c += blockDim.x) cell_start[c] = 0;
+  for (int c = tid; c < n_cells; c += blockDim.x) cell_fill[c] = 0;
+  __syncthreads();
+  // histogram
+  for (int i = tid; i < n; i += blockDim.x) {
+    const uint32_t k = A.keys[i];
+    const int cell = ((int)key_r(k) / s * G + (int)key_g(k) / s) * G + (int)key_b(k) / s;
+    atomicAdd(&cell_start[cell + 1], 1u);
+  }
+  __syncthreads();
+  // inclusive scan over n_cells+1 entries (<= 4097): each thread owns 9 consecutive entries
+  {
+    constexpr int per = (kMaxCells + 1 + kEpsThreads - 1) / kEpsThreads;  // 9
+    unsigned loc[per];
+    unsigned sum = 0;
+    for (int j = 0; j < per; ++j) {
+      int c = tid * per + j;
+      loc[j] = c <= n_cells ? cell_start[c] : 0u;
+      sum += loc[j];
+    }
+    unsigned tot;
+    unsigned base = block_exscan<unsigned>(sum, red, &tot);
+    for (int j = 0; j < per; ++j) {
+      int c = tid * per + j;
+      base += loc[j];
+      if (c <= n_cells) cell_start[c] = base;        // cell_start[c] = #points in cells < c
+    }
+  }
+  __syncthreads();
+  for (int i = tid; i < n; i += blockDim.x) {
+    const uint32_t k = A.keys[i];
+    const int cell = ((int)key_r(k) / s * G + (int)key_g(k) / s) * G + (int)key_b(k) / s;
+    const unsigned pos = cell_start[cell] + atomicAdd(&cell_fill[cell], 1u);
+    A.perm[pos] = i;
+  }
+  __syncthreads();
+  if (clique) {
+    // every point joins the first-listed point of its cell
+    for (int p = tid; p < n; p += blockDim.x) {
+      const uint32_t i = A.perm[p];
+      const uint32_t k = A.keys[i];
+      const int cell = ((int)key_r(k) / s * G + (int)key_g(k) / s) * G + (int)key_b(k) / s;
+      const uint32_t rep = A.perm[cell_start[cell]];
+      if (rep != i) uf_union(A.parent, i, rep);
+    }
+    __syncthreads();
+  }
+  // neighbour pass: one wave per (cell A, forward neighbour offset) task
+  int R = 0;
+  while ((long long)(R * s) * (R * s) <= reach2 + 0ll && R < G) ++R;  // cells farther than R apart cannot hold a pair
+  // a pair of cells dx apart on an axis has min coordinate gap max(0, (dx-1)*s + 1)
+  const int span = 2 * R + 1;
+  const int n_off = span * span * span;
+  const int lane = tid & 63, wave = tid >> 6, n_waves = blockDim.x >> 6;
+  const long long n_tasks = (long long)n_cells * n_off;
+  for (long long t = wave; t < n_tasks; t += n_waves) {
+    const int ca = (int)(t / n_off);
+    const unsigned a0 = cell_start[ca], na = cell_start[ca + 1] - a0;
+    if (na == 0) { continue; }
+    const int o = (int)(t % n_off);
+    const int dz = o % span - R, dy = (o / span) % span - R, dx = o / (span * span) - R;
+    // forward half only (each unordered cell pair once); same cell handled when !clique
+    if (dx < 0 || (dx == 0 && (dy < 0 || (dy == 0 && dz < 0)))) continue;
+    const bool same = dx == 0 && dy == 0 && dz == 0;
+    if (same && clique) continue;
+    const int ax = ca / (G * G), ay = (ca / G) % G, az = ca % G;
+    const int bx = ax + dx, by = ay + dy, bz = az + dz;
+    if (bx < 0 || bx >= G || by < 0 || by >= G || bz < 0 || bz >= G) continue;
+    const int cb = (bx * G + by) * G + bz;
+    const unsigned b0 = cell_start[cb], nb = cell_start[cb + 1] - b0;
+    if (nb == 0) continue;
+    {
+      const int gx = dx ? (abs(dx) - 1) * s + 1 : 0, gy = dy ? (abs(dy) - 1) * s + 1 : 0, gz = dz ? (abs(dz) - 1) * s + 1 : 0;
+      if (gx * gx + gy * gy + gz * gz > reach2) continue;
+    }
+    if (clique) {
+      const uint32_t repa = A.perm[a0], repb = A.perm[b0];
+      if (uf_find(A.parent, repa) == uf_find(A.parent, repb)) continue;  // already connected
+      const unsigned total = na * nb;
+      for (unsigned base = 0; base < total; base += 64) {
+        const unsigned p = base + lane;
+        bool hit = false;
+        if (p < total) {
+          const uint32_t ka = A.keys[A.perm[a0 + p / nb]], kb = A.keys[A.perm[b0 + p % nb]];
+          hit = is_neighbor(ka, kb, thr, boundary, r2);
+        }
+        if (__any(hit)) {
+          if (lane == 0) uf_union(A.parent, repa, repb);
+          break;
+        }
+      }
+    } else {
+      const unsigned total = na * nb;
+      for (unsigned base = 0; base < total; base += 64) {
+        const unsigned p = base + lane;
+        if (p < total) {
+          const unsigned ia = p / nb, ib = p % nb;
+          if (!same || ia < ib) {
+            const uint32_t i = A.perm[a0 + ia], j = A.perm[b0 + ib];
+            if (is_neighbor(A.keys[i], A.keys[j], thr, boundary, r2)) uf_union(A.parent, i, j);
+          }
+        }
+      }
+    }
+  }
+  __syncthreads();
+  // K4 labelling: root = smallest member index; label = rank of the root among roots
+  for (int i = tid; i < n; i += blockDim.x) A.perm[i] = 0;
+  __syncthreads();
+  for (int i = tid; i < n; i += blockDim.x) {
+    const uint32_t r = uf_find(A.parent, i);
+    A.parent[i] = r;                                    // full compression (own entry only)
+    if (r == (uint32_t)i) A.perm[i] = 1;
+  }
+  __syncthreads();
+  {
+    const int per = (n + blockDim.x - 1) / blockDim.x;
+    const int lo = tid * per, hi = min(lo + per, n);
+    unsigned sum = 0;
+    for (int i = lo; i < hi; ++i) sum += A.perm[i];
+    unsigned tot;
+    unsigned base = block_exscan<unsigned>(sum, red, &tot);
+    for (int i = lo; i < hi; ++i) {
+      const unsigned f = A.perm[i];
+      A.perm[i] = base;                                 // exclusive rank of index i among roots
+      base += f;
+    }
+    if (tid == 0) *ncomp_out = (int32_t)tot;
+  }
+  __syncthreads();
+  for (int i = tid; i < n; i += blockDim.x) labels_out[i] = (int32_t)A.perm[A.parent[i]];
+}
+
+__global__ __launch_bounds__(kEpsThreads) void eps_components_kernel(const uint32_t* __restrict__ keys, const int32_t* __restrict__ desc,
+                                                                      const double* __restrict__ r2, int32_t* __restrict__ labels_out,
+                                                                      int32_t* __restrict__ ncomp_out, uint32_t* __restrict__ gwork,
+                                                                      int work_stride) {
+  __shared__ uint32_t s_keys[RHCCQ_EPS_LDS_MAX];
+  __shared__ uint32_t s_parent[RHCCQ_EPS_LDS_MAX];
+  __shared__ uint32_t s_perm[RHCCQ_EPS_LDS_MAX];
+  __shared__ unsigned s_cell_start[kMaxCells + 1];
+  __shared__ unsigned s_cell_fill[kMaxCells];
+  __shared__ unsigned s_red[16];
+  const int p = blockIdx.x;
+  const int off = desc[p * 4 + 0], n = desc[p * 4 + 1], thr = desc[p * 4 + 2], boundary = desc[p * 4 + 3];
+  if (n <= 0) {
+    if (threadIdx.x == 0) ncomp_out[p] = 0;
+    return;
+  }
+  EpsArrays A;
+  if (n <= RHCCQ_EPS_LDS_MAX) {
+    A.keys = s_keys; A.parent = s_parent; A.perm = s_perm;
+    eps_components_body<true>(keys + off, n, thr, boundary, r2[p], labels_out + off, ncomp_out + p, A, s_cell_start, s_cell_fill, s_red);
+  } else {
+    uint32_t* w = gwork + (size_t)p * 3 * work_stride;
+    A.keys = w; A.parent = w + work_stride; A.perm = w + 2 * (size_t)work_stride;
+    eps_components_body<false>(keys + off, n, thr, boundary, r2[p], labels_out + off, ncomp_out + p, A, s_cell_start, s_cell_fill, s_red);
+  }
+}
+
+}  // namespace rhccq
+
+using namespace rhccq;
+
+extern "C" int rhccq_eps_components(rhccq_ctx* ctx, const uint32_t* keys, const int32_t* desc, const double* r2, int32_t n_prob,
+                                    int32_t max_n, int32_t* labels_out, int32_t* ncomp_out) {
+  if (!ctx || !keys || !desc || !r2 || !labels_out || !ncomp_out || n_prob <= 0 || max_n < 0)
+    return rhccq_fail(ctx, RHCCQ_E_ARG, "eps_components: bad argument");
+  uint32_t* gwork = nullptr;
+  int stride = 0;
+  if (max_n > RHCCQ_EPS_LDS_MAX) {
+    // oversize problems run the same code from global memory (slow path, API completeness)
+    stride = (max_n + 63) & ~63;
+    const size_t bytes = (size_t)n_prob * 3 * stride * sizeof(uint32_t);
+    if (ctx->scratch_bytes < bytes) {
+      if (ctx->scratch) RHCCQ_HIP(ctx, hipFree(ctx->scratch));
+      ctx->scratch = nullptr;
+      ctx->scratch_bytes = 0;
+      RHCCQ_HIP(ctx, hipMalloc(&ctx->scratch, bytes));
+      ctx->scratch_bytes = bytes;
+    }
+    gwork = (uint32_t*)ctx->scratch;
+  }
+  hipLaunchKernelGGL(eps_components_kernel, dim3(n_prob), dim3(kEpsThreads), 0, ctx->stream, keys, desc, r2, labels_out, ncomp_out, gwork, stride);
+  RHCCQ_LAUNCH_CHECK(ctx);
+  return 0;
+}

@@ -1,0 +1,106 @@
+// Shared device helpers for the RHCCQ gfx950 kernels (wave64, 256 CUs, 160 KiB LDS/CU).
+#pragma once
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+
+#include <string>
+
+#include "../../include/rhccq.h"
+
+struct rhccq_ctx {
+  int device = 0;
+  hipStream_t stream = nullptr;
+  bool own_stream = false;
+  std::string err;
+  // small persistent device scratch (descriptor tables handed over from the host)
+  void* scratch = nullptr;
+  size_t scratch_bytes = 0;
+};
+
+#define RHCCQ_HIP(ctx, expr)                                                        \
+  do {                                                                              \
+    hipError_t _e = (expr);                                                         \
+    if (_e != hipSuccess) {                                                         \
+      (ctx)->err = std::string(#expr) + ": " + hipGetErrorString(_e);               \
+      return RHCCQ_E_HIP;                                                           \
+    }                                                                               \
+  } while (0)
+
+#define RHCCQ_LAUNCH_CHECK(ctx)                                                     \
+  do {                                                                              \
+    hipError_t _e = hipGetLastError();                                              \
+    if (_e != hipSuccess) {                                                         \
+      (ctx)->err = std::string("kernel launch: ") + hipGetErrorString(_e);          \
+      return RHCCQ_E_HIP;                                                           \
+    }                                                                               \
+  } while (0)
+
+static inline int rhccq_fail(rhccq_ctx* ctx, int code, const char* msg) {
+  if (ctx) ctx->err = msg;
+  return code;
+}
+
+// copy a small host table into the context's device scratch (async on the stream; the host
+// buffer is copied by value into a pinned-free staging std::string kept alive by the ctx)
+int rhccq_upload(rhccq_ctx* ctx, const void* host, size_t bytes, void** dev_out);
+
+namespace rhccq {
+
+constexpr int kWave = 64;
+
+__device__ __forceinline__ uint32_t key_r(uint32_t k) { return (k >> 16) & 255u; }
+__device__ __forceinline__ uint32_t key_g(uint32_t k) { return (k >> 8) & 255u; }
+__device__ __forceinline__ uint32_t key_b(uint32_t k) { return k & 255u; }
+
+// exact integer squared distance between two packed colours
+__device__ __forceinline__ int dist2_keys(uint32_t a, uint32_t b) {
+  int dr = (int)key_r(a) - (int)key_r(b);
+  int dg = (int)key_g(a) - (int)key_g(b);
+  int db = (int)key_b(a) - (int)key_b(b);
+  return __mul24(dr, dr) + __mul24(dg, dg) + __mul24(db, db);
+}
+
+template <typename T>
+__device__ __forceinline__ T wave_sum(T v) {
+#pragma unroll
+  for (int o = 32; o > 0; o >>= 1) v += __shfl_down(v, o, 64);
+  return v;  // valid in lane 0
+}
+
+// block-wide sum; `red` must hold blockDim.x/64 elements; result returned to every thread
+template <typename T>
+__device__ __forceinline__ T block_sum(T v, T* red) {
+  const int lane = threadIdx.x & 63, w = threadIdx.x >> 6, nw = (blockDim.x + 63) >> 6;
+  v = wave_sum(v);
+  __syncthreads();
+  if (lane == 0) red[w] = v;
+  __syncthreads();
+  T t = 0;
+  for (int i = 0; i < nw; ++i) t += red[i];
+  return t;
+}
+
+// block-wide exclusive scan of one value per thread (blockDim.x multiple of 64, <= 1024);
+// `red` holds blockDim.x/64 + 1 elements; total returned through *total
+template <typename T>
+__device__ __forceinline__ T block_exscan(T v, T* red, T* total) {
+  const int lane = threadIdx.x & 63, w = threadIdx.x >> 6, nw = (blockDim.x + 63) >> 6;
+  T inc = v;
+#pragma unroll
+  for (int o = 1; o < 64; o <<= 1) {
+    T t = __shfl_up(inc, o, 64);
+    if (lane >= o) inc += t;
+  }
+  __syncthreads();
+  if (lane == 63) red[w] = inc;
+  __syncthreads();
+  T base = 0, tot = 0;
+  for (int i = 0; i < nw; ++i) {
+    if (i < w) base += red[i];
+    tot += red[i];
+  }
+  if (total) *total = tot;
+  return base + inc - v;
+}
+
+}  // namespace rhccq

@@ -1,0 +1,409 @@
+"""Thin Python wrappers over the C ABI: torch tensors own device memory, kernels run on torch's
+current HIP stream.  Names follow the reference's domain: jobs (segments / crops), palettes, keys
+(uint32 R<<16|G<<8|B held in int32 tensors), labels, components.
+
+Reference functions served (paths relative to the reference root):
+  unique_colors            encoder/compression/clustering.py:4-103   (get_all_unique_colors)
+  clustering_params        encoder/compression/clustering.py:108-135
+  eps_components           encoder/compression/clustering.py:233-235 (DBSCAN.fit_predict)
+  kmeans_split             encoder/compression/clustering.py:720-775 (KMeans.fit_predict)
+  minibatch_kmeans         encoder/compression/clustering.py:207-230 (MiniBatchKMeans.fit_predict)
+  cluster_means            encoder/compression/clustering.py:304-310,346-355
+  remap / decode           encoder/compression/clustering.py:373-377, decoder/.../uncompression.py:209
+  merge_firstpos / paint   encoder/compression/merging.py:52-82
+"""
+import ctypes as C
+import math
+
+import numpy as np
+import torch
+
+from . import _lib
+from ._lib import MbkProblem, RhccqError
+
+INT_MAX = 2 ** 31 - 1
+BITMAP_WORDS = 524288
+MINIBATCH_THRESHOLD = 10000          # clustering.py:205
+SEED = 42                            # random_state=42 at every sklearn call site of the reference
+
+
+def pack_rgb(rgb):
+    rgb = np.asarray(rgb, dtype=np.uint8).reshape(-1, 3).astype(np.uint32)
+    return (rgb[:, 0] << 16) | (rgb[:, 1] << 8) | rgb[:, 2]
+
+
+def unpack_rgb(keys):
+    keys = np.asarray(keys).astype(np.uint32)
+    return np.stack([(keys >> 16) & 255, (keys >> 8) & 255, keys & 255], axis=1).astype(np.uint8)
+
+
+def clustering_params(n_colors, quality):
+    """compute_clustering_params through the C ABI (host-only entry point)."""
+    lib = _lib.load()
+    if quality == 0:
+        raise ZeroDivisionError("float division by zero")     # clustering.py:129 behaviour
+    eps, mc = C.c_double(), C.c_int64()
+    rc = lib.rhccq_params(int(n_colors), float(quality), C.byref(eps), C.byref(mc))
+    if rc:
+        raise RhccqError(f"rhccq_params failed ({rc})")
+    return eps.value, 1, mc.value
+
+
+def eps_threshold(eps):
+    lib = _lib.load()
+    thr, bnd, r2 = C.c_int32(), C.c_int32(), C.c_double()
+    rc = lib.rhccq_eps_threshold(float(eps), C.byref(thr), C.byref(bnd), C.byref(r2))
+    if rc:
+        raise RhccqError(f"rhccq_eps_threshold({eps}) failed ({rc})")
+    return thr.value, bnd.value, r2.value
+
+
+class _MtStream:
+    """numpy legacy MT19937 RandomState(42): u0 = the draw consumed by choice() for the first centre,
+    then the uniform(size=T) draws of k-means++ are consecutive doubles.  Every KMeans fit of the
+    reference restarts from seed 42, so one cached prefix serves all split problems."""
+
+    def __init__(self):
+        self.host = np.zeros(0)
+        self.dev = None
+
+    def ensure(self, n, device):
+        if len(self.host) < n + 1:
+            m = max(n + 1, 2 * len(self.host), 1 << 16)
+            self.host = np.random.RandomState(SEED).random_sample(m)
+            self.dev = None
+        if self.dev is None or self.dev.device != device:
+            self.dev = torch.from_numpy(self.host[1:].copy()).to(device)
+        return self.dev
+
+    def u0(self):
+        if len(self.host) == 0:
+            self.host = np.random.RandomState(SEED).random_sample(1 << 16)
+            self.dev = None
+        return self.host[0]
+
+
+_first_cache = {}
+
+
+def first_centre_index(n, u0):
+    """RandomState.choice(n, p=ones/n): searchsorted(cumsum(p)/cumsum(p)[-1], u0, 'right')."""
+    key = (n, u0)
+    if key not in _first_cache:
+        p = np.full(n, 1.0) / np.float64(n)
+        cdf = np.cumsum(p)
+        cdf /= cdf[-1]
+        _first_cache[key] = min(int(np.searchsorted(cdf, u0, side="right")), n - 1)
+    return _first_cache[key]
+
+
+class Rhccq:
+    """One context per (process, device).  All methods take / return torch CUDA tensors unless a
+    name says numpy."""
+
+    def __init__(self, device=0):
+        if not torch.cuda.is_available():
+            raise RhccqError("no HIP device visible: the RHCCQ product path needs an MI355X (there is no CPU fallback)")
+        self.lib = _lib.load()
+        self.device = torch.device("cuda", device)
+        torch.cuda.set_device(self.device)
+        self.stream = torch.cuda.current_stream(self.device)
+        h = C.c_void_p()
+        rc = self.lib.rhccq_ctx_create(device, C.c_void_p(self.stream.cuda_stream), C.byref(h))
+        if rc:
+            raise RhccqError(f"rhccq_ctx_create failed ({rc})")
+        self.ctx = h
+        self.mt = _MtStream()
+
+    def close(self):
+        if getattr(self, "ctx", None):
+            self.lib.rhccq_ctx_destroy(self.ctx)
+            self.ctx = None
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
+
+    # -- helpers --------------------------------------------------------------------------------
+    def _check(self, rc, what):
+        if rc:
+            msg = self.lib.rhccq_last_error(self.ctx)
+            raise RhccqError(f"{what} failed ({rc}): {msg.decode() if msg else ''}")
+
+    @staticmethod
+    def _p(t):
+        return C.c_void_p(t.data_ptr()) if t is not None else C.c_void_p(0)
+
+    def dev(self, arr, dtype=None):
+        t = torch.from_numpy(np.ascontiguousarray(arr))
+        if dtype is not None:
+            t = t.to(dtype)
+        return t.to(self.device, non_blocking=False)
+
+    def zeros(self, shape, dtype):
+        return torch.zeros(shape, dtype=dtype, device=self.device)
+
+    def empty(self, shape, dtype):
+        return torch.empty(shape, dtype=dtype, device=self.device)
+
+    def _class_args(self, labels, job_base):
+        n = len(job_base)
+        ptrs = (C.c_void_p * n)(*[(l.data_ptr() if l is not None else 0) for l in labels])
+        bases = (C.c_int32 * n)(*[int(b) for b in job_base])
+        return n, ptrs, bases
+
+    # -- K0 / K1 ----------------------------------------------------------------------------------
+    def new_job_state(self, n_jobs):
+        bitmaps = self.zeros((n_jobs, BITMAP_WORDS), torch.int32)
+        stats = torch.tensor([INT_MAX, -1, INT_MAX, -1, 0, 0], dtype=torch.int32, device=self.device).repeat(n_jobs, 1).contiguous()
+        return bitmaps, stats
+
+    def job_scan(self, rgb, labels, job_base, bitmaps, stats, black_is_colour):
+        H, W = rgb.shape[0], rgb.shape[1]
+        n, ptrs, bases = self._class_args(labels, job_base)
+        self._check(self.lib.rhccq_job_scan(self.ctx, self._p(rgb), H, W, n, ptrs, bases, int(black_is_colour),
+                                            self._p(bitmaps), self._p(stats)), "job_scan")
+
+    def job_set_black(self, bitmaps, jobs):
+        if len(jobs) == 0:
+            return
+        j = self.dev(np.asarray(jobs, dtype=np.int32))
+        self._check(self.lib.rhccq_job_set_black(self.ctx, self._p(bitmaps), self._p(j), len(jobs)), "job_set_black")
+
+    def bitmap_count(self, bitmaps):
+        n_jobs = bitmaps.shape[0]
+        chunk = self.empty((n_jobs, 512), torch.int32)
+        counts = self.empty((n_jobs,), torch.int32)
+        self._check(self.lib.rhccq_bitmap_count(self.ctx, self._p(bitmaps), n_jobs, self._p(chunk), self._p(counts)), "bitmap_count")
+        return chunk, counts
+
+    def bitmap_emit(self, bitmaps, chunk, pal_off, total, want_keys=True):
+        n_jobs = bitmaps.shape[0]
+        prefix = self.empty((n_jobs, BITMAP_WORDS), torch.int32)
+        keys = self.empty((max(int(total), 1),), torch.int32) if want_keys else None
+        self._check(self.lib.rhccq_bitmap_emit(self.ctx, self._p(bitmaps), n_jobs, self._p(chunk), self._p(pal_off),
+                                               self._p(prefix), self._p(keys)), "bitmap_emit")
+        return prefix, keys
+
+    def job_blackfix(self, rgb, labels, job_base, needs_fix, best):
+        H, W = rgb.shape[0], rgb.shape[1]
+        n, ptrs, bases = self._class_args(labels, job_base)
+        self._check(self.lib.rhccq_job_blackfix(self.ctx, self._p(rgb), H, W, n, ptrs, bases, self._p(needs_fix), self._p(best)),
+                    "job_blackfix")
+
+    def job_index(self, rgb, labels, job_base, bitmaps, prefix, pal_off, fix_key=None, want_idx=True, first_pos=None):
+        H, W = rgb.shape[0], rgb.shape[1]
+        n, ptrs, bases = self._class_args(labels, job_base)
+        idx = self.empty((n, H * W), torch.int32) if want_idx else None
+        self._check(self.lib.rhccq_job_index(self.ctx, self._p(rgb), H, W, n, ptrs, bases, self._p(bitmaps), self._p(prefix),
+                                             self._p(pal_off), self._p(fix_key), self._p(idx), self._p(first_pos)), "job_index")
+        return idx
+
+    def frame_remap(self, rgb, labels, job_base, bitmaps, prefix, pal_off, fix_key, lut, default_index, out_dtype):
+        H, W = rgb.shape[0], rgb.shape[1]
+        n, ptrs, bases = self._class_args(labels, job_base)
+        out = self.empty((H, W), out_dtype)
+        self._check(self.lib.rhccq_frame_remap(self.ctx, self._p(rgb), H, W, n, ptrs, bases, self._p(bitmaps), self._p(prefix),
+                                               self._p(pal_off), self._p(fix_key), self._p(lut), int(default_index), self._p(out),
+                                               out.element_size()), "frame_remap")
+        return out
+
+    def unique_colors(self, rgb):
+        """get_all_unique_colors core: rgb uint8[H,W,3] (device) -> (keys int32[P] sorted, idx int32[H*W])."""
+        assert rgb.dtype == torch.uint8 and rgb.is_contiguous() and rgb.shape[-1] == 3
+        bitmaps, stats = self.new_job_state(1)
+        self.job_scan(rgb, [None], [0], bitmaps, stats, black_is_colour=True)
+        chunk, counts = self.bitmap_count(bitmaps)
+        total = int(counts.cpu()[0])
+        pal_off = self.zeros((1,), torch.int64)
+        prefix, keys = self.bitmap_emit(bitmaps, chunk, pal_off, total)
+        idx = self.job_index(rgb, [None], [0], bitmaps, prefix, pal_off)
+        return keys[:total], idx[0]
+
+    # -- K3 / K4 ----------------------------------------------------------------------------------
+    def eps_components(self, key_list, eps_list):
+        """Batched DBSCAN(min_samples=1) labels.  key_list: numpy uint32/int arrays; returns
+        (list of int32 numpy label arrays, list of component counts)."""
+        n_prob = len(key_list)
+        if n_prob == 0:
+            return [], []
+        sizes = [len(k) for k in key_list]
+        offs = np.concatenate([[0], np.cumsum(sizes)]).astype(np.int64)
+        if offs[-1] == 0:
+            return [np.zeros(0, np.int32) for _ in key_list], [0] * n_prob
+        desc = np.zeros((n_prob, 4), np.int32)
+        r2 = np.zeros(n_prob, np.float64)
+        for i, e in enumerate(eps_list):
+            thr, bnd, rr = eps_threshold(e)
+            desc[i] = (offs[i], sizes[i], thr, bnd)
+            r2[i] = rr
+        keys = self.dev(np.concatenate([np.asarray(k).astype(np.int64) for k in key_list]).astype(np.int32))
+        d_desc, d_r2 = self.dev(desc), self.dev(r2)
+        labels = self.empty((int(offs[-1]),), torch.int32)
+        ncomp = self.empty((n_prob,), torch.int32)
+        self._check(self.lib.rhccq_eps_components(self.ctx, self._p(keys), self._p(d_desc), self._p(d_r2), n_prob, int(max(sizes)),
+                                                  self._p(labels), self._p(ncomp)), "eps_components")
+        lab = labels.cpu().numpy()
+        nc = ncomp.cpu().numpy()
+        return [lab[offs[i]:offs[i + 1]] for i in range(n_prob)], [int(v) for v in nc]
+
+    # -- K7 -----------------------------------------------------------------------------------------
+    def kmeans_split(self, key_list, k_list, return_info=False):
+        """Batched KMeans(k, random_state=42).fit_predict labels (KM64).  numpy in / numpy out."""
+        n_prob = len(key_list)
+        if n_prob == 0:
+            return ([], []) if return_info else []
+        sizes = [len(k) for k in key_list]
+        offs = np.concatenate([[0], np.cumsum(sizes)]).astype(np.int64)
+        koff = np.concatenate([[0], np.cumsum(k_list)]).astype(np.int64)
+        desc = np.zeros((n_prob, 6), np.int32)
+        need = 1
+        u0 = self.mt.u0()
+        for i, (n, k) in enumerate(zip(sizes, k_list)):
+            assert 1 <= k <= n
+            T = 2 + int(math.log(k))
+            desc[i] = (offs[i], n, k, 0, first_centre_index(n, u0), T)
+            need = max(need, (k - 1) * T)
+        rand = self.mt.ensure(need, self.device)
+        keys = self.dev(np.concatenate([np.asarray(k).astype(np.int64) for k in key_list]).astype(np.int32))
+        d_desc, d_koff = self.dev(desc), self.dev(koff[:-1].copy())
+        work = self.empty((8 * int(koff[-1]) + 8,), torch.float64)
+        labels = self.empty((int(offs[-1]),), torch.int32)
+        info = self.zeros((n_prob, 4), torch.int32)
+        self._check(self.lib.rhccq_kmeans(self.ctx, self._p(keys), self._p(d_desc), self._p(d_koff), self._p(rand), n_prob,
+                                          int(max(sizes)), self._p(work), self._p(labels), self._p(info)), "kmeans")
+        lab = labels.cpu().numpy()
+        out = [lab[offs[i]:offs[i + 1]] for i in range(n_prob)]
+        if return_info:
+            return out, info.cpu().numpy()
+        return out
+
+    # -- K2 -----------------------------------------------------------------------------------------
+    def cluster_means(self, keys, labels, k):
+        """floor-mean colour per label: keys int32[n] device, labels int32[n] device -> int32[k] keys."""
+        sums = self.zeros((max(k, 1), 4), torch.int64)
+        self._check(self.lib.rhccq_cluster_sums(self.ctx, self._p(keys), self._p(labels), keys.numel(), self._p(sums)), "cluster_sums")
+        out = self.empty((max(k, 1),), torch.int32)
+        self._check(self.lib.rhccq_cluster_means(self.ctx, self._p(sums), k, self._p(out)), "cluster_means")
+        return out[:k], sums[:k]
+
+    # -- K8 -----------------------------------------------------------------------------------------
+    def minibatch_kmeans(self, key_list, k_list, return_info=False, poll_steps=64):
+        """Batched MiniBatchKMeans(k, batch_size=1000, random_state=42).fit_predict labels in the
+        canonical arithmetic of oracle.minibatch_kmeans_labels.  numpy in / numpy out."""
+        n_prob = len(key_list)
+        if n_prob == 0:
+            return ([], []) if return_info else []
+        probs = (MbkProblem * n_prob)()
+        sizes = [len(k) for k in key_list]
+        offs = np.concatenate([[0], np.cumsum(sizes)]).astype(np.int64)
+        koff = np.concatenate([[0], np.cumsum(k_list)]).astype(np.int64)
+        init_list, rand_list = [], []
+        ioff = roff = 0
+        max_steps = 0
+        for i, (n, k) in enumerate(zip(sizes, k_list)):
+            rs = np.random.RandomState(SEED)
+            bs = min(1000, n)
+            init_size = 3 * bs
+            if init_size < k:
+                init_size = 3 * k
+            init_size = min(init_size, n)
+            rs.randint(0, n, init_size)                      # validation_indices: stream position only
+            init_idx = np.sort(rs.randint(0, n, init_size)) if init_size < n else np.arange(n)
+            T = 2 + int(math.log(k))
+            first = first_centre_index(init_size, rs.random_sample())
+            u = rs.uniform(size=max((k - 1) * T, 1))
+            p = probs[i]
+            p.off, p.n, p.k, p.koff = int(offs[i]), n, k, int(koff[i])
+            p.init_off, p.init_n, p.rand_off, p.first, p.T = ioff, init_size, roff, first, T
+            init_list.append(init_idx.astype(np.int32))
+            rand_list.append(u)
+            ioff += init_size
+            roff += len(u)
+            max_steps = max(max_steps, (100 * n) // bs)
+        keys = self.dev(np.concatenate([np.asarray(k).astype(np.int64) for k in key_list]).astype(np.int32))
+        d_init = self.dev(np.concatenate(init_list))
+        d_rand = self.dev(np.concatenate(rand_list))
+        K = int(koff[-1])
+        centres = self.zeros((K, 4), torch.float64)
+        chosen = self.zeros((K,), torch.int32)
+        self._check(self.lib.rhccq_mbk_init(self.ctx, self._p(keys), probs, n_prob, self._p(d_init), self._p(d_rand),
+                                            self._p(centres), self._p(chosen)), "mbk_init")
+        weights = self.zeros((K,), torch.float64)
+        state = self.zeros((n_prob, 8), torch.float64)
+        wbytes = int(self.lib.rhccq_mbk_work_bytes(probs, n_prob))
+        work = self.empty((max(wbytes, 8),), torch.uint8)
+        step = 0
+        while step < max_steps:
+            ns = min(poll_steps, max_steps - step)
+            self._check(self.lib.rhccq_mbk_steps(self.ctx, self._p(keys), probs, n_prob, step, ns, SEED, self._p(centres),
+                                                 self._p(weights), self._p(state), self._p(work), wbytes), "mbk_steps")
+            step += ns
+            st = state.cpu().numpy()
+            if all(st[i, 4] != 0 or st[i, 5] >= (100 * sizes[i]) // min(1000, sizes[i]) for i in range(n_prob)):
+                break
+        labels = self.empty((int(offs[-1]),), torch.int32)
+        self._check(self.lib.rhccq_mbk_assign(self.ctx, self._p(keys), probs, n_prob, self._p(centres), self._p(work), wbytes,
+                                              self._p(labels)), "mbk_assign")
+        lab = labels.cpu().numpy()
+        out = [lab[offs[i]:offs[i + 1]] for i in range(n_prob)]
+        if return_info:
+            return out, {"state": state.cpu().numpy(), "centres": centres.cpu().numpy(), "chosen": chosen.cpu().numpy(),
+                         "koff": koff, "weights": weights.cpu().numpy()}
+        return out
+
+    # -- K6 / decode ------------------------------------------------------------------------------
+    def remap(self, idx, lut):
+        out = torch.empty_like(idx)
+        self._check(self.lib.rhccq_remap(self.ctx, self._p(idx), idx.numel(), self._p(lut), lut.numel(), self._p(out)), "remap")
+        return out
+
+    def decode(self, idx, palette):
+        """palette uint8[K,3] device, idx uint8/uint16(int16 storage)/int32 device flat -> uint8[n,3]."""
+        out = self.empty((idx.numel(), 3), torch.uint8)
+        self._check(self.lib.rhccq_decode(self.ctx, self._p(idx), idx.element_size(), idx.numel(), self._p(palette),
+                                          palette.shape[0], self._p(out)), "decode")
+        return out
+
+    # -- K5 ---------------------------------------------------------------------------------------
+    def merge_firstpos(self, idx, h, w, top, left, canvas_h, canvas_w, pal_n):
+        fp = torch.full((max(pal_n, 1),), INT_MAX, dtype=torch.int32, device=self.device)
+        self._check(self.lib.rhccq_merge_firstpos(self.ctx, self._p(idx), h, w, top, left, canvas_h, canvas_w, pal_n, self._p(fp)),
+                    "merge_firstpos")
+        return fp[:pal_n]
+
+    def merge_paint(self, idx, h, w, top, left, canvas, lut, pal_n):
+        self._check(self.lib.rhccq_merge_paint(self.ctx, self._p(idx), h, w, top, left, canvas.shape[0], canvas.shape[1],
+                                               self._p(lut), pal_n, self._p(canvas)), "merge_paint")
+
+    # -- extension ----------------------------------------------------------------------------------
+    def luma_qstep(self, rgb, roi_mask, block, q_roi, q_bg):
+        H, W = rgb.shape[0], rgb.shape[1]
+        luma = self.empty((H, W), torch.float32)
+        qstep = self.empty((H // block, W // block), torch.float32)
+        self._check(self.lib.rhccq_luma_qstep(self.ctx, self._p(rgb), self._p(roi_mask), H, W, block, float(q_roi), float(q_bg),
+                                              self._p(luma), self._p(qstep)), "luma_qstep")
+        return luma, qstep
+
+    def dct_quant(self, plane, block, qstep, want_coef=True):
+        H, W = plane.shape
+        coef = self.empty((H, W), torch.float32) if want_coef else None
+        q = self.empty((H, W), torch.int16)
+        self._check(self.lib.rhccq_dct_quant(self.ctx, self._p(plane), H, W, block, self._p(qstep), self._p(coef), self._p(q)), "dct_quant")
+        return coef, q
+
+    def sync(self):
+        self._check(self.lib.rhccq_sync(self.ctx), "sync")
+
+
+_default = {}
+
+
+def default_context(device=None):
+    if device is None:
+        device = torch.cuda.current_device() if torch.cuda.is_available() else 0
+    if device not in _default:
+        _default[device] = Rhccq(device)
+    return _default[device]

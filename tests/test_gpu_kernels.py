@@ -1,0 +1,178 @@
+"""HIP kernels (through the C ABI) vs the CPU oracle, primitive by primitive.  GPU only."""
+import os
+
+import numpy as np
+import pytest
+
+pytestmark = pytest.mark.gpu
+
+G = os.path.join(os.path.dirname(__file__), "golden")
+
+
+@pytest.fixture(scope="module")
+def rh():
+    import torch
+    from roibasedimagecompression_amd.ops import Rhccq
+    assert torch.cuda.is_available()
+    return Rhccq(0)
+
+
+@pytest.fixture(scope="module")
+def O():
+    from oracle import rhccq_oracle
+    return rhccq_oracle
+
+
+def load(name):
+    return np.load(os.path.join(G, name), allow_pickle=False)
+
+
+def test_unique_colors_golden_and_random(rh, O):
+    import torch
+    g = load("g1_unique.npz")
+    imgs = [g[f"img{i}"] for i in range(int(g["n"]))]
+    rng = np.random.default_rng(1)
+    imgs.append(rng.integers(0, 256, (201, 303, 3), dtype=np.uint8))          # ragged, n_px % 4 != 0
+    imgs.append(rng.integers(0, 3, (64, 64, 3), dtype=np.uint8))              # heavy duplicates incl. black
+    imgs.append(np.full((5, 7, 3), 255, np.uint8))
+    for im in imgs:
+        keys, idx = rh.unique_colors(torch.from_numpy(im.copy()).to(rh.device))
+        pal, oidx = O.unique_colors(im)
+        assert np.array_equal(keys.cpu().numpy().astype(np.uint32), O.pack_rgb(pal))
+        assert np.array_equal(idx.cpu().numpy(), oidx)
+
+
+def test_eps_components_golden(rh):
+    g = load("g3_dbscan.npz")
+    eps = [float(e) for e in g["eps"]]
+    from roibasedimagecompression_amd.ops import pack_rgb
+    keys, es, want = [], [], []
+    for name in g["names"]:
+        P = g[f"pal_{name}"]
+        for ei, e in enumerate(eps):
+            keys.append(pack_rgb(P)); es.append(e); want.append(g[f"lab_{name}_{ei}"])
+    labs, nc = rh.eps_components(keys, es)
+    for i, (l, w) in enumerate(zip(labs, want)):
+        assert np.array_equal(l, w), (i, es[i])
+        assert nc[i] == w.max() + 1
+
+
+def test_eps_components_random_vs_oracle(rh, O):
+    rng = np.random.default_rng(7)
+    keys, es = [], []
+    for n, hi in ((1, 256), (2, 256), (700, 256), (5000, 256), (10240, 256), (9000, 40), (3000, 12)):
+        P = np.unique(rng.integers(0, hi, (n, 3)).astype(np.uint8), axis=0)
+        P = P[rng.permutation(len(P))]                      # merged palettes are NOT sorted
+        for e in (1.0, 2.0, 5.0, 12.8, 25.6, 27.0, 32.0, 51.2, 102.4):
+            keys.append(O.pack_rgb(P)); es.append(e)
+    labs, _ = rh.eps_components(keys, es)
+    for k, e, l in zip(keys, es, labs):
+        if len(k) > 6000 and e < 25:
+            continue                                         # oracle too slow there; covered by properties below
+        assert np.array_equal(l, O.eps_components(O.unpack_rgb(k), e)), (len(k), e)
+
+
+def test_eps_components_oversize_global_path(rh, O):
+    rng = np.random.default_rng(3)
+    P = np.unique(rng.integers(0, 256, (12000, 3)).astype(np.uint8), axis=0)
+    labs, nc = rh.eps_components([O.pack_rgb(P)], [6.0])
+    assert np.array_equal(labs[0], O.eps_components(P, 6.0))
+
+
+def test_kmeans_split_vs_oracle(rh, O):
+    g = load("g3_dbscan.npz")
+    cases = []
+    for name, ks in (("lenna64", (2, 12, 25, 67)), ("rand500", (2, 3, 25, 150, 500)), ("lenna_final", (5, 67, 146)),
+                     ("dark", (5, 25, 150)), ("lattice", (5, 67)), ("rand3000", (12, 150)), ("gapped", (2, 41))):
+        P = g[f"pal_{name}"]
+        for k in ks:
+            cases.append((P, k))
+    labs, info = rh.kmeans_split([O.pack_rgb(P) for P, _ in cases], [k for _, k in cases], return_info=True)
+    for (P, k), l, inf in zip(cases, labs, info):
+        ol, oi = O.kmeans_labels(P, k, return_info=True)
+        assert np.array_equal(l, ol), (len(P), k, inf, oi["n_iter"], (l == ol).mean())
+        assert inf[0] == oi["n_iter"] and bool(inf[1]) == oi["strict"] and inf[2] == oi["relocated"]
+
+
+def test_kmeans_split_large_k_and_global_path(rh, O):
+    rng = np.random.default_rng(11)
+    P = np.unique(rng.integers(0, 256, (2600, 3)).astype(np.uint8), axis=0)       # k > 1024: centres in global memory
+    P2 = np.unique(rng.integers(0, 64, (11000, 3)).astype(np.uint8), axis=0)      # n > LDS max: points in global memory
+    labs = rh.kmeans_split([O.pack_rgb(P), O.pack_rgb(P2)], [1300, 7])
+    assert np.array_equal(labs[0], O.kmeans_labels(P, 1300))
+    assert np.array_equal(labs[1], O.kmeans_labels(P2, 7))
+
+
+def test_cluster_means(rh, O):
+    import torch
+    rng = np.random.default_rng(5)
+    P = rng.integers(0, 256, (5000, 3)).astype(np.uint8)
+    lab = rng.integers(-1, 37, 5000).astype(np.int32)
+    keys = torch.from_numpy(O.pack_rgb(P).astype(np.int32)).to(rh.device)
+    means, sums = rh.cluster_means(keys, torch.from_numpy(lab).to(rh.device), 37)
+    want = np.stack([P[lab == j].astype(np.int64).sum(0) // max((lab == j).sum(), 1) for j in range(37)])
+    assert np.array_equal(O.unpack_rgb(means.cpu().numpy()), want.astype(np.uint8))
+
+
+def test_minibatch_vs_oracle_bit_exact(rh, O):
+    g = load("g10_minibatch.npz")
+    pal, _ = O.unique_colors(g["img"])
+    pal = pal[~np.all(pal == 0, axis=1)]
+    rng = np.random.default_rng(2)
+    P2 = np.unique(rng.integers(0, 256, (30000, 3)).astype(np.uint8), axis=0)
+    cases = [(pal, int(np.ceil(len(pal) * 0.2 / 10))), (pal, int(np.ceil(len(pal) * 0.1 / 10))), (P2, 450)]
+    labs, info = rh.minibatch_kmeans([O.pack_rgb(P) for P, _ in cases], [k for _, k in cases], return_info=True)
+    for i, ((P, k), l) in enumerate(zip(cases, labs)):
+        ol, oi = O.minibatch_kmeans_labels(P, k, return_info=True)
+        st = info["state"][i]
+        assert int(st[5]) == oi["n_steps"], (st, oi["n_steps"])
+        c = info["centres"][info["koff"][i]:info["koff"][i + 1], :3]
+        assert np.array_equal(c, oi["centers"]), np.abs(c - oi["centers"]).max()
+        assert np.array_equal(l, ol), (l == ol).mean()
+
+
+def test_merge_kernels_and_remap_decode(rh, O):
+    import torch
+    g = load("g5_merge.npz")
+    from roibasedimagecompression_amd.palette import merge_components
+    for name in g["names"]:
+        comps = []
+        for ci in range(int(g[f"{name}_n"])):
+            m = g[f"{name}_c{ci}_meta"]
+            comps.append({"top_left": (int(m[0]), int(m[1])), "shape": (int(m[2]), int(m[3])),
+                          "palette": g[f"{name}_c{ci}_pal"], "indices": g[f"{name}_c{ci}_idx"]})
+        out = merge_components(rh, comps, tuple(int(v) for v in g[f"{name}_bbox"]))
+        assert np.array_equal(np.asarray(out["palette"]).reshape(-1, 3), g[f"{name}_out_pal"]), name
+        assert np.array_equal(np.asarray(out["indices"]).reshape(-1), g[f"{name}_out_idx"]), name
+    rng = np.random.default_rng(9)
+    idx = rng.integers(0, 500, 100003).astype(np.int32)
+    lut = rng.integers(0, 9999, 500).astype(np.int32)
+    got = rh.remap(torch.from_numpy(idx).to(rh.device), torch.from_numpy(lut).to(rh.device)).cpu().numpy()
+    assert np.array_equal(got, lut[idx])
+    pal = rng.integers(0, 256, (500, 3)).astype(np.uint8)
+    for dt in (np.uint8, np.int16, np.int32):
+        ii = (idx % (200 if dt == np.uint8 else 500)).astype(dt)
+        rec = rh.decode(torch.from_numpy(ii).to(rh.device), torch.from_numpy(pal).to(rh.device)).cpu().numpy()
+        assert np.array_equal(rec, pal[ii.astype(np.int64)])
+
+
+@pytest.mark.parametrize("block", [8, 16])
+def test_dct_quant_extension(rh, O, block):
+    """EXTENSION (no reference counterpart): vs scipy.fft.dctn(type=2, norm='ortho').  Tolerance:
+    coefficients within 1e-5 relative to the block DC scale (255*block); quantised integers exact."""
+    import torch
+    rng = np.random.default_rng(4)
+    rgb = rng.integers(0, 256, (96, 160, 3), dtype=np.uint8)
+    roi = np.zeros((96, 160), np.uint8)
+    roi[20:50, 30:100] = 1
+    luma, qstep = rh.luma_qstep(torch.from_numpy(rgb).to(rh.device), torch.from_numpy(roi).to(rh.device), block, 4.0, 16.0)
+    r, gch, b = (rgb[..., i].astype(np.float32) for i in range(3))
+    want_luma = (np.float32(0.299) * r + np.float32(0.587) * gch) + np.float32(0.114) * b
+    assert np.array_equal(luma.cpu().numpy(), want_luma)
+    tiles = roi.reshape(96 // block, block, 160 // block, block).max(axis=(1, 3))
+    want_q = np.where(tiles > 0, 4.0, 16.0).astype(np.float32)
+    assert np.array_equal(qstep.cpu().numpy(), want_q)
+    coef, q = rh.dct_quant(luma, block, qstep)
+    oc, oq = O.dct_quant_blocks(want_luma, block, want_q.astype(np.float64))
+    assert np.abs(coef.cpu().numpy() - oc).max() <= 1e-5 * 255 * block
+    assert np.array_equal(q.cpu().numpy(), oq)
