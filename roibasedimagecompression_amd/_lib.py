@@ -72,6 +72,9 @@ def load():
     if not os.path.exists(LIB_PATH):
         raise RhccqError(f"{LIB_PATH} is missing: run `python -m roibasedimagecompression_amd.build` "
                          "(or __graft_entry__.build()); there is no CPU fallback for the product path")
+    # torch bundles its own libamdhip64; it must be in the process BEFORE this library is loaded so that
+    # both resolve to ONE HIP runtime (torch owns device memory and streams, this library launches on them)
+    import torch  # noqa: F401
     lib = C.CDLL(LIB_PATH)
     for name, (res, args) in PROTOTYPES.items():
         fn = getattr(lib, name)          # AttributeError if the symbol is not exported

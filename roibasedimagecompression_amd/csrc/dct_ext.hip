@@ -26,13 +26,14 @@ __global__ __launch_bounds__(256) void dct_quant_kernel(const float* __restrict_
     const double s = u == 0 ? sqrt(1.0 / B) : sqrt(2.0 / B);
     basis[u][x] = s * cospi((double)((2 * x + 1) * u) / (double)(2 * B));
   }
-  const int tiles_x = W / kTile;
+  const int tiles_x = (W + kTile - 1) / kTile;     // edge tiles hold whole blocks (H, W multiples of B)
   const int ty = blockIdx.x / tiles_x, tx = blockIdx.x % tiles_x;
   const int r0 = ty * kTile, c0 = tx * kTile;
   // load: thread -> row tid/8, 4 consecutive columns (float4, coalesced 128 B per row)
   {
     const int r = tid >> 3, c = (tid & 7) * 4;
-    const float4 v = *reinterpret_cast<const float4*>(plane + (size_t)(r0 + r) * W + c0 + c);
+    float4 v = make_float4(0.f, 0.f, 0.f, 0.f);
+    if (r0 + r < H && c0 + c < W) v = *reinterpret_cast<const float4*>(plane + (size_t)(r0 + r) * W + c0 + c);
     tile[r][c] = v.x; tile[r][c + 1] = v.y; tile[r][c + 2] = v.z; tile[r][c + 3] = v.w;
   }
   __syncthreads();
@@ -52,6 +53,7 @@ __global__ __launch_bounds__(256) void dct_quant_kernel(const float* __restrict_
 #pragma unroll
     for (int y = 0; y < B; ++y) acc = fma(tmp[by * B + y][c], basis[v][y], acc);
     const int gr = r0 + rv, gc = c0 + c;
+    if (gr >= H || gc >= W) continue;
     const double qs = (double)qstep[(size_t)(gr / B) * (W / B) + gc / B];
     if (coef_out) coef_out[(size_t)gr * W + gc] = (float)acc;
     q_out[(size_t)gr * W + gc] = (int16_t)rint(acc / qs);
@@ -89,9 +91,9 @@ extern "C" {
 int rhccq_dct_quant(rhccq_ctx* ctx, const float* plane, int32_t H, int32_t W, int32_t block, const float* qstep, float* coef_out,
                     int16_t* q_out) {
   if (!ctx || !plane || !qstep || !q_out || H <= 0 || W <= 0) return rhccq_fail(ctx, RHCCQ_E_ARG, "dct_quant: bad argument");
-  if (H % kTile || W % kTile) return rhccq_fail(ctx, RHCCQ_E_ARG, "dct_quant: H and W must be multiples of 32");
+  if ((block != 8 && block != 16) || H % block || W % block) return rhccq_fail(ctx, RHCCQ_E_ARG, "dct_quant: block must be 8 or 16 and divide H and W");
   if (((uintptr_t)plane & 15u) != 0) return rhccq_fail(ctx, RHCCQ_E_ARG, "dct_quant: plane must be 16-byte aligned");
-  const int grid = (H / kTile) * (W / kTile);
+  const int grid = ((H + kTile - 1) / kTile) * ((W + kTile - 1) / kTile);
   if (block == 8) hipLaunchKernelGGL(dct_quant_kernel<8>, dim3(grid), dim3(256), 0, ctx->stream, plane, H, W, qstep, coef_out, q_out);
   else if (block == 16) hipLaunchKernelGGL(dct_quant_kernel<16>, dim3(grid), dim3(256), 0, ctx->stream, plane, H, W, qstep, coef_out, q_out);
   else return rhccq_fail(ctx, RHCCQ_E_ARG, "dct_quant: block must be 8 or 16");

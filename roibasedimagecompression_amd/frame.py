@@ -1,0 +1,276 @@
+"""Fused frame encoder: the three-level RHCCQ palette hierarchy of rhccq.ipynb:978-1039
+(subregion_quantization -> region_quantization x2 -> quantize_image) for one RGB frame whose
+ROI / non-ROI segment label maps are given (ROI detection and SLIC are upstream).
+
+Per-pixel work runs in four streaming HIP passes (scan, [black-fix], first-position, final remap);
+everything between them is palette-space work: HIP kernels for the clustering (K3/K4/K7/K8/K2) and
+small numpy bookkeeping for the reference's ordering rules (first-seen merge order, black first,
+passthrough of single components).  A pixel's index is never materialised between the levels: the
+three levels are composed into one LUT per (segment, level-1 palette index) and applied once.
+
+Reference semantics reproduced (paths relative to the reference root):
+  encoder/compression/subregions.py:315-449,634-679   per-segment crop(+2 px), black-in-segment fix,
+                                                     unique colours, cluster(q), merge per region
+  encoder/compression/regions.py:9-70                 merge per class on the frame canvas, cluster(2q)
+  encoder/compression/image.py:243-286                merge ROI + non-ROI, cluster(q3), index dtype
+  encoder/compression/merging.py:16-21,52-82          single-component passthrough, reversed painting,
+                                                     first-seen global palette, black = 0 = transparent
+"""
+import time
+
+import numpy as np
+import torch
+
+from .ops import INT_MAX, clustering_params, unpack_rgb
+from .palette import cluster_palettes
+
+__all__ = ["ClassSpec", "FrameEncoder"]
+
+_FP_NONE = np.int64(INT_MAX)
+
+
+class ClassSpec:
+    """One region class (ROI or non-ROI) of a frame.
+
+    labels      int32[H,W] device tensor: 0 = pixel not in the class, s >= 1 = SLIC segment id
+                (ids are global within the class, ascending inside each region as the reference
+                iterates them, slic.py:158-160);
+    seg_region  int array[n_seg]: region index of segment id s (entry s-1);
+    region_bbox int array[R,4]: (minr, minc, maxr, maxc) of each connected region (roi.py:349-358);
+    quality     level-1 quality of the class (rhccq.ipynb:584-585)."""
+
+    def __init__(self, labels, seg_region, region_bbox, quality):
+        self.labels = labels
+        self.seg_region = np.asarray(seg_region, dtype=np.int64)
+        self.region_bbox = np.asarray(region_bbox, dtype=np.int64).reshape(-1, 4)
+        self.quality = quality
+        self.n_seg = len(self.seg_region)
+
+
+class _Comp:
+    """A component of the hierarchy in palette space."""
+    __slots__ = ("keys", "fp", "top_left", "shape", "maps", "merged")
+
+    def __init__(self, keys, fp, top_left, shape, maps, merged):
+        self.keys = keys          # uint32[K] palette keys (palette order)
+        self.fp = fp              # int64[K] first absolute raster position showing the entry
+        self.top_left = top_left
+        self.shape = shape
+        self.maps = maps          # {job: int32[P_job]} level-1 palette index -> index into keys
+        self.merged = merged      # True: canvas semantics (index 0 = black = uncovered)
+
+
+def _scatter_min(n, idx, val):
+    out = np.full(n, _FP_NONE, np.int64)
+    np.minimum.at(out, idx, val)
+    return out
+
+
+def _merge(comps, bbox):
+    """merge_region_components_simple in palette space (merging.py:8-120)."""
+    if not comps:
+        return None
+    if len(comps) == 1:
+        return comps[0]
+    seqs = []
+    for c in reversed(comps):
+        valid = np.nonzero((c.keys != 0) & (c.fp < _FP_NONE))[0]
+        seqs.append(c.keys[valid[np.argsort(c.fp[valid], kind="stable")]])
+    allk = np.concatenate(seqs) if seqs else np.zeros(0, np.uint32)
+    u, first = np.unique(allk, return_index=True)
+    order = np.argsort(first, kind="stable")
+    gkeys = np.concatenate([np.zeros(1, np.uint32), u[order]])
+    rank = np.empty(len(u), np.int64)
+    rank[order] = np.arange(1, len(u) + 1)
+    gfp = np.full(len(gkeys), _FP_NONE, np.int64)
+    maps = {}
+    for c in comps:
+        valid = (c.keys != 0) & (c.fp < _FP_NONE)
+        lut = np.zeros(len(c.keys), np.int32)                  # black / unused -> canvas 0
+        pos = np.searchsorted(u, c.keys[valid])
+        lut[valid] = rank[pos]
+        np.minimum.at(gfp, lut[valid], c.fp[valid])
+        for job, m in c.maps.items():
+            maps[job] = lut[m]
+    minr, minc, maxr, maxc = bbox
+    return _Comp(gkeys, gfp, (minr, minc), (maxr - minr, maxc - minc), maps, True)
+
+
+class FrameEncoder:
+    def __init__(self, rh):
+        self.rh = rh
+        self.timings = {}
+
+    def _t(self, name, t0, sync=False):
+        if sync:
+            torch.cuda.synchronize()
+        self.timings[name] = self.timings.get(name, 0.0) + (time.perf_counter() - t0)
+
+    # ------------------------------------------------------------------------------------------
+    def encode(self, rgb, classes, want_levels=False, profile=False):
+        """rgb: uint8[H,W,3] device tensor; classes: [ClassSpec] in precedence order (ROI first).
+        Returns dict(palette uint8[K,3], indices (device tensor [H,W], dtype by max index),
+        indices_dtype, shape, top_left, levels (optional))."""
+        rh = self.rh
+        self.timings = {}
+        H, W = int(rgb.shape[0]), int(rgb.shape[1])
+        assert rgb.dtype == torch.uint8 and rgb.is_contiguous()
+        labels = [c.labels for c in classes]
+        job_base = np.concatenate([[0], np.cumsum([c.n_seg for c in classes])]).astype(np.int64)
+        n_jobs = int(job_base[-1])
+        if n_jobs == 0:
+            raise ValueError("no segments")
+        # ---- pass 1: per-segment stats + colour bitmaps (K0 + K1a) ------------------------------
+        t0 = time.perf_counter()
+        bitmaps, stats = rh.new_job_state(n_jobs)
+        rh.job_scan(rgb, labels, job_base[:-1], bitmaps, stats, black_is_colour=False)
+        st = stats.cpu().numpy().astype(np.int64)
+        self._t("scan", t0)
+        t0 = time.perf_counter()
+        count, n_black = st[:, 4], st[:, 5]
+        present = count > 0
+        # crop = tight bbox +-2 px clamped to the region (subregions.py:346-352)
+        job_class = np.repeat(np.arange(len(classes)), [c.n_seg for c in classes])
+        job_region = np.concatenate([c.seg_region for c in classes])
+        rb = np.concatenate([c.region_bbox[c.seg_region] for c in classes]) if n_jobs else np.zeros((0, 4), np.int64)
+        r0 = np.maximum(rb[:, 0], st[:, 0] - 2)
+        r1 = np.minimum(rb[:, 2] - 1, st[:, 1] + 2)
+        c0 = np.maximum(rb[:, 1], st[:, 2] - 2)
+        c1 = np.minimum(rb[:, 3] - 1, st[:, 3] + 2)
+        crop_area = (r1 - r0 + 1) * (c1 - c0 + 1)
+        has_bg = present & (crop_area > count)
+        needs_fix = present & (n_black > 0) & (count > n_black)           # subregions.py:393-421
+        all_black = present & (n_black > 0) & (count == n_black)
+        fix_key = None
+        if needs_fix.any():
+            best = torch.full((n_jobs,), -1, dtype=torch.int64, device=rh.device)      # ~0ull
+            rh.job_blackfix(rgb, labels, job_base[:-1], rh.dev(needs_fix.astype(np.uint8)), best)
+            pos = (best.cpu().numpy().view(np.uint64) & np.uint64((1 << 40) - 1)).astype(np.int64)
+            px = rgb.reshape(-1, 3)[torch.from_numpy(np.where(needs_fix, pos, 0)).to(rh.device)].cpu().numpy().astype(np.uint32)
+            fk = ((px[:, 0] << 16) | (px[:, 1] << 8) | px[:, 2]).astype(np.uint32)
+            fk[~needs_fix] = 0
+            fix_key = rh.dev(fk.astype(np.int64).astype(np.int32))
+        black_jobs = np.nonzero(has_bg | all_black)[0]
+        rh.job_set_black(bitmaps, black_jobs)
+        chunk, counts = rh.bitmap_count(bitmaps)
+        P = counts.cpu().numpy().astype(np.int64)
+        pal_off = np.concatenate([[0], np.cumsum(P)]).astype(np.int64)
+        d_pal_off = rh.dev(pal_off[:-1].copy())
+        total = int(pal_off[-1])
+        prefix, keys_dev = rh.bitmap_emit(bitmaps, chunk, d_pal_off, total)
+        first_pos = torch.full((max(total, 1),), INT_MAX, dtype=torch.int32, device=rh.device)
+        rh.job_index(rgb, labels, job_base[:-1], bitmaps, prefix, d_pal_off, fix_key, want_idx=False, first_pos=first_pos)
+        keys_all = keys_dev[:total].cpu().numpy().astype(np.uint32)
+        fp_all = first_pos[:total].cpu().numpy().astype(np.int64)
+        self._t("unique", t0)
+        # ---- level 1: cluster every segment palette (subregions.py:426-449) -----------------------
+        t0 = time.perf_counter()
+        jobs, job_ids = [], []
+        for j in np.nonzero(present)[0]:
+            q = classes[job_class[j]].quality
+            eps, _, mc = clustering_params(int(P[j]), q)
+            jobs.append({"keys": keys_all[pal_off[j]:pal_off[j + 1]], "quality": q, "eps": eps, "mc": mc})
+            job_ids.append(j)
+        res = cluster_palettes(rh, jobs)
+        self._t("level1_cluster", t0)
+        t0 = time.perf_counter()
+        seg_comp = {}
+        for j, (nk, mp, info) in zip(job_ids, res):
+            fp_new = _scatter_min(len(nk), mp, fp_all[pal_off[j]:pal_off[j + 1]])
+            seg_comp[j] = _Comp(nk, fp_new, (int(r0[j]), int(c0[j])), (int(r1[j] - r0[j] + 1), int(c1[j] - c0[j] + 1)),
+                                {int(j): mp.astype(np.int32)}, False)
+        levels = {"level1": [], "level2": []} if want_levels else None
+        lvl2, q2s = [], []
+        for ci, cls in enumerate(classes):
+            regs = []
+            for r in range(len(cls.region_bbox)):
+                segs = [seg_comp[j] for j in range(job_base[ci], job_base[ci + 1]) if job_region[j] == r and j in seg_comp]
+                if not segs:
+                    continue
+                regs.append(_merge(segs, tuple(int(v) for v in cls.region_bbox[r])))     # subregions.py:637-652
+            if want_levels:
+                levels["level1"].append(regs)
+            q2 = min(cls.quality * 2, 100)
+            q2s.append(q2)
+            if not regs:
+                continue                                                                  # rhccq.ipynb:1009-1013
+            lvl2.append((ci, _merge(regs, (0, 0, H, W)), q2))
+        self._t("merge12", t0)
+        t0 = time.perf_counter()
+        # ---- level 2: cluster each class palette (regions.py:52-68) ---------------------------------
+        jobs2 = []
+        for ci, comp, q2 in lvl2:
+            eps, _, mc = clustering_params(len(comp.keys), q2)
+            jobs2.append({"keys": comp.keys, "quality": q2, "eps": eps, "mc": mc})
+        res2 = cluster_palettes(rh, jobs2)
+        comps3 = []
+        for (ci, comp, q2), (nk, mp, info) in zip(lvl2, res2):
+            fp_new = _scatter_min(len(nk), mp, comp.fp)
+            c2 = _Comp(nk, fp_new, comp.top_left, comp.shape, {job: mp[m] for job, m in comp.maps.items()}, comp.merged)
+            comps3.append(c2)
+        if want_levels:
+            levels["level2"] = comps3
+        self._t("level2", t0)
+        t0 = time.perf_counter()
+        # ---- level 3: merge classes, cluster (image.py:246-280) -------------------------------------
+        if not comps3:
+            raise IndexError("no components")
+        q3 = min(sum(q2s), 100)
+        multi = len(comps3) > 1
+        m3c = _merge(comps3, (0, 0, H, W))
+        eps, _, mc = clustering_params(len(m3c.keys), q3)
+        (fk3, mp3, info3), = cluster_palettes(rh, [{"keys": m3c.keys, "quality": q3, "eps": eps, "mc": mc}])
+        self._t("level3", t0)
+        t0 = time.perf_counter()
+        # ---- compose the three levels into one LUT per (segment, level-1 index) ---------------------
+        lut = np.full(max(total, 1), -1, np.int32)
+        for c2 in comps3:
+            for job, m in c2.maps.items():
+                if multi:
+                    painted = c2.keys[m] != 0                           # black = transparent (merging.py:75)
+                    v = np.where(painted, mp3[m3c.maps[job]], -1)
+                else:
+                    v = mp3[m]
+                lut[pal_off[job]:pal_off[job + 1]] = v
+        if multi:
+            default_index = int(mp3[0])
+        else:
+            blk = np.nonzero(fk3 == 0)[0]
+            default_index = int(blk[0]) if len(blk) else 0
+        max_index = int(max(lut.max(initial=0), default_index))
+        out_dtype = torch.uint8 if max_index < 256 else (torch.int16 if max_index < 65536 else torch.int32)
+        dtype_name = "uint8" if max_index < 256 else ("uint16" if max_index < 65536 else "uint32")
+        d_lut = rh.dev(lut)
+        self._t("compose", t0)
+        t0 = time.perf_counter()
+        out = rh.frame_remap(rgb, labels, job_base[:-1], bitmaps, prefix, d_pal_off, fix_key, d_lut, default_index, out_dtype)
+        self._t("remap", t0, sync=profile)
+        result = {"palette": unpack_rgb(fk3), "indices": out, "indices_dtype": dtype_name,
+                  "shape": (H, W) if multi else tuple(m3c.shape), "top_left": (0, 0) if multi else tuple(m3c.top_left),
+                  "quality3": q3, "n_unique": P, "info3": info3}
+        if want_levels:
+            levels["pal_off"] = pal_off
+            levels["seg_comp"] = seg_comp
+            levels["state"] = (bitmaps, prefix, d_pal_off, fix_key, job_base)
+            result["levels"] = levels
+        return result
+
+    # ------------------------------------------------------------------------------------------
+    def render_component(self, rgb, classes, levels, comp, class_index=None):
+        """Index map (device int32 [h,w]) of one level-1/level-2 component as the reference would
+        return it: canvas semantics for merged components, crop semantics for single segments."""
+        rh = self.rh
+        bitmaps, prefix, d_pal_off, fix_key, job_base = levels["state"]
+        pal_off = levels["pal_off"]
+        lut = np.full(max(int(pal_off[-1]), 1), -1, np.int32)
+        for job, m in comp.maps.items():
+            lut[pal_off[job]:pal_off[job + 1]] = m
+        default = 0
+        if not comp.merged:
+            blk = np.nonzero(comp.keys == 0)[0]
+            default = int(blk[0]) if len(blk) else 0
+        labels = [c.labels for c in classes]
+        full = rh.frame_remap(rgb, labels, job_base[:-1], bitmaps, prefix, d_pal_off, fix_key, rh.dev(lut), default, torch.int32)
+        r, c = comp.top_left
+        h, w = comp.shape
+        return full[r:r + h, c:c + w].contiguous()

@@ -1,0 +1,104 @@
+"""Fused frame encoder (HIP path) vs the oracle's three-level chain and vs the reference's golden
+outputs.  GPU only."""
+import os
+
+import numpy as np
+import pytest
+
+pytestmark = pytest.mark.gpu
+G = os.path.join(os.path.dirname(__file__), "golden")
+
+
+@pytest.fixture(scope="module")
+def rh():
+    from roibasedimagecompression_amd.ops import Rhccq
+    return Rhccq(0)
+
+
+def specs_from_labels(rh, lab_list, qualities):
+    """one region per class, bbox = tight bbox of the class mask; lab: 0 = none, ids 1.."""
+    import torch
+    from roibasedimagecompression_amd.frame import ClassSpec
+    specs, oracle_classes = [], []
+    for lab, q in zip(lab_list, qualities):
+        mask = lab > 0
+        rows, cols = np.where(mask)
+        bbox = (int(rows.min()), int(cols.min()), int(rows.max()) + 1, int(cols.max()) + 1)
+        n_seg = int(lab.max())
+        specs.append(ClassSpec(torch.from_numpy(lab.astype(np.int32)).to(rh.device), np.zeros(n_seg, np.int64), [bbox], q))
+        sl = (slice(bbox[0], bbox[2]), slice(bbox[1], bbox[3]))
+        oracle_classes.append([{"bbox": bbox, "bbox_mask": mask[sl], "seglabels": lab[sl].astype(np.int32)}])
+    return specs, oracle_classes
+
+
+def run_both(rh, img, lab_list, qualities):
+    import torch
+    from oracle import rhccq_oracle as O
+    from roibasedimagecompression_amd.frame import FrameEncoder
+    specs, oc = specs_from_labels(rh, lab_list, qualities)
+    enc = FrameEncoder(rh)
+    out = enc.encode(torch.from_numpy(img.copy()).to(rh.device), specs)
+    ref = O.encode_frame(img, oc, qualities)
+    return out, ref
+
+
+def indices_np(out):
+    idx = out["indices"].cpu().numpy()
+    if out["indices_dtype"] == "uint16":
+        idx = idx.view(np.uint16)
+    return idx.astype(np.int64)
+
+
+@pytest.mark.parametrize("tag", ["lenna64", "poster64", "kodak96"])
+def test_frame_vs_oracle_and_golden(rh, tag):
+    g = np.load(os.path.join(G, "g6_chain.npz"))
+    img = g[f"{tag}_img"]
+    labs = [g[f"{tag}_lab_roi"] + 1, g[f"{tag}_lab_non"] + 1]
+    qs = [int(v) for v in g[f"{tag}_q"]]
+    out, ref = run_both(rh, img, labs, qs)
+    fin = ref["final"]
+    # HIP path == oracle, bit for bit (palette, indices, dtype)
+    assert np.array_equal(out["palette"], np.asarray(fin["palette"]).reshape(-1, 3))
+    assert np.array_equal(indices_np(out).reshape(-1), np.asarray(fin["indices"]).reshape(-1))
+    assert out["indices_dtype"] == fin["indices_dtype"]
+    # vs the reference's own output: Tier A when the k-means partitions reproduce, else Tier B
+    gp, gi = g[f"{tag}_fin_pal"], g[f"{tag}_fin_idx"]
+    exact = np.array_equal(out["palette"], gp) and np.array_equal(indices_np(out).reshape(-1), gi)
+    rec = out["palette"][indices_np(out)].reshape(img.shape).astype(np.float64)
+    gref = gp[gi].reshape(img.shape).astype(np.float64)
+    p_mine = 10 * np.log10(255 ** 2 / np.mean((rec - img) ** 2))
+    p_ref = 10 * np.log10(255 ** 2 / np.mean((gref - img) ** 2))
+    print(tag, "Tier A" if exact else "Tier B", p_mine, p_ref)
+    assert abs(p_mine - p_ref) < 0.5
+    if tag == "poster64":
+        assert exact
+
+
+def test_frame_many_segments_photo_and_poster(rh):
+    """cfg1-like: 256x256, 8x8 grid of segments per class, (20,10) preset; black pixels inside
+    segments; HIP path == oracle bit for bit."""
+    from roibasedimagecompression_amd import synth
+    H = W = 256
+    for name, img in (("photo", synth.photo(H, W, 1234)), ("poster", synth.poster(H, W, 1235))):
+        img = img.copy()
+        img[40:44, 100:140] = 0                                  # in-segment black -> K0b
+        (lr, nr, _), (ln, nn, _) = synth.frame_classes(H, W, (8, 8))
+        out, ref = run_both(rh, img, [lr, ln], [20, 10])
+        fin = ref["final"]
+        assert np.array_equal(out["palette"], np.asarray(fin["palette"]).reshape(-1, 3)), name
+        assert np.array_equal(indices_np(out).reshape(-1), np.asarray(fin["indices"]).reshape(-1)), name
+
+
+def test_frame_minibatch_branch_and_single_class(rh):
+    """A segment with >= 10 000 colours takes the MiniBatchKMeans branch; one class only ->
+    level-3 passthrough of a single component."""
+    from roibasedimagecompression_amd import synth
+    H, W = 192, 256
+    img = synth.photo(H, W, 77, sigma=6.0)
+    lab = np.ones((H, W), np.int32)
+    lab[:, W // 2:] = 2
+    out, ref = run_both(rh, img, [lab], [20])
+    fin = ref["final"]
+    assert (out["n_unique"] >= 10000).any()
+    assert np.array_equal(out["palette"], np.asarray(fin["palette"]).reshape(-1, 3))
+    assert np.array_equal(indices_np(out).reshape(-1), np.asarray(fin["indices"]).reshape(-1))

@@ -162,14 +162,14 @@ def test_dct_quant_extension(rh, O, block):
     coefficients within 1e-5 relative to the block DC scale (255*block); quantised integers exact."""
     import torch
     rng = np.random.default_rng(4)
-    rgb = rng.integers(0, 256, (96, 160, 3), dtype=np.uint8)
-    roi = np.zeros((96, 160), np.uint8)
+    rgb = rng.integers(0, 256, (112, 176, 3), dtype=np.uint8)     # not a multiple of the 32x32 staging tile
+    roi = np.zeros((112, 176), np.uint8)
     roi[20:50, 30:100] = 1
     luma, qstep = rh.luma_qstep(torch.from_numpy(rgb).to(rh.device), torch.from_numpy(roi).to(rh.device), block, 4.0, 16.0)
     r, gch, b = (rgb[..., i].astype(np.float32) for i in range(3))
     want_luma = (np.float32(0.299) * r + np.float32(0.587) * gch) + np.float32(0.114) * b
     assert np.array_equal(luma.cpu().numpy(), want_luma)
-    tiles = roi.reshape(96 // block, block, 160 // block, block).max(axis=(1, 3))
+    tiles = roi.reshape(112 // block, block, 176 // block, block).max(axis=(1, 3))
     want_q = np.where(tiles > 0, 4.0, 16.0).astype(np.float32)
     assert np.array_equal(qstep.cpu().numpy(), want_q)
     coef, q = rh.dct_quant(luma, block, qstep)
