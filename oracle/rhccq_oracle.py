@@ -57,7 +57,7 @@ __all__ = [
     "minibatch_kmeans_labels", "cluster_palette", "merge_components", "segment_crop",
     "level1_region", "region_quantization", "quantize_image", "optimal_index_dtype",
     "encode_frame", "pack_container", "container_bytes", "load_container", "decode_container",
-    "dct_quant_blocks", "counter_hash",
+    "dct_quant_blocks", "counter_hash", "morton3",
 ]
 
 MINIBATCH_THRESHOLD = 10000  # clustering.py:205
@@ -329,6 +329,19 @@ def counter_hash(seed, stream, counter):
     return z
 
 
+def morton3(keys):
+    """24-bit Z-order code of packed colours: bit i of R, G, B -> bits 3i+2, 3i+1, 3i."""
+    def spread(v):
+        v = v.astype(np.uint32) & np.uint32(0xFF)
+        v = (v | (v << np.uint32(16))) & np.uint32(0xFF0000FF)
+        v = (v | (v << np.uint32(8))) & np.uint32(0x0F00F00F)
+        v = (v | (v << np.uint32(4))) & np.uint32(0xC30C30C3)
+        v = (v | (v << np.uint32(2))) & np.uint32(0x49249249)
+        return v
+    keys = np.asarray(keys, dtype=np.uint32)
+    return (spread(keys >> np.uint32(16)) << np.uint32(2)) | (spread(keys >> np.uint32(8)) << np.uint32(1)) | spread(keys)
+
+
 def _bounded(z, n):
     """(high 32 bits of z * n) >> 32  -> [0, n)."""
     return ((z >> np.uint64(32)) * np.uint64(n)) >> np.uint64(32)
@@ -357,8 +370,10 @@ def minibatch_kmeans_labels(points, k, seed=42, batch_size=1000, max_iter=100,
     canonical choices that make it reproducible on a GPU:
 
       * init: validation_indices and init_indices are drawn from the MT19937 stream exactly as
-        sklearn does (randint(0,n,init_size) twice); the init sample is then SORTED ascending
-        (deviation: sklearn keeps draw order) and greedy k-means++ runs on it in exact integers;
+        sklearn does (randint(0,n,init_size) twice); the init sample is then ordered by
+        (Morton code of the colour, index) -- deviation: sklearn keeps draw order; Z-order makes 64
+        consecutive samples a compact box, which is what lets the GPU prune exactly -- and greedy
+        k-means++ runs on it in exact integers;
       * step s draws its batch as idx_b = bounded(counter_hash(seed, 2*s, b), n), b < batch;
       * E-step distance dist = csq_j + (-2 * dot) on raw 0..255 coordinates, first arg-min;
       * centre update c = (c*w + S_int) * (1/(w+cnt)) with S_int the exact integer sum of the
@@ -380,10 +395,8 @@ def minibatch_kmeans_labels(points, k, seed=42, batch_size=1000, max_iter=100,
         init_size = 3 * k
     init_size = min(init_size, n)
     rs.randint(0, n, init_size)                        # validation_indices (stream position only)
-    if init_size < n:
-        init_indices = np.sort(rs.randint(0, n, init_size))
-    else:
-        init_indices = np.arange(n)
+    init_indices = rs.randint(0, n, init_size) if init_size < n else np.arange(n)
+    init_indices = init_indices[np.lexsort((init_indices, morton3(pack_rgb(P[init_indices]))))]
     cidx = kmeanspp_int(P[init_indices], k, rs)
     C = X[init_indices[cidx]].copy()
     W = np.zeros(k, np.float64)

@@ -78,23 +78,87 @@ __device__ __forceinline__ int box_dist2(uint32_t k, uint32_t lo, uint32_t hi) {
   return __mul24(dr, dr) + __mul24(dg, dg) + __mul24(db, db);
 }
 
-// per problem scratch layout (all u32 unless noted), nb = ceil(init_n / 64), np = nb * 64:
-//   skey[np] closest[np] lo[nb] hi[nb] bmax[nb] bsum[nb]
+// per problem scratch layout (u32): skey[np] closest[np] and, when the block tables do not fit LDS,
+// lo[nb] hi[nb] bmax[nb] bsum[nb]   (nb = ceil(init_n / 64), np = nb * 64)
+constexpr int kInitLdsBlocks = 4096;   // block tables in LDS up to 262144 init samples (64 KB)
+
+struct InitTables {
+  uint32_t* lo;     // per block: packed min corner of the bounding box
+  uint32_t* hi;     // packed max corner
+  uint32_t* bmax;   // max closest distance in the block
+  uint32_t* bsum;   // sum of closest distances in the block
+};
+
+// distance work of one candidate / the winner over the blocks [chunk0, nb) visited with stride
+// `chunk_stride`; kCommit = false: returns sum over samples of max(closest - d, 0);
+// kCommit = true: lowers closest[] and refreshes bmax / bsum of the touched blocks.
+template <bool kCommit>
+__device__ __forceinline__ unsigned long long visit_blocks(uint32_t ck, int nb, int chunk0, int chunk_stride, const uint32_t* skey,
+                                                           uint32_t* closest, InitTables tb) {
+  const int lane = threadIdx.x & 63;
+  unsigned long long delta = 0;
+  for (int chunk = chunk0; chunk < nb; chunk += chunk_stride) {
+    const int b = chunk + lane;
+    const bool hit = b < nb && (unsigned)box_dist2(ck, tb.lo[b], tb.hi[b]) < tb.bmax[b];
+    unsigned long long mask = __ballot(hit);
+    while (mask) {
+      // up to four hit blocks per round so that their loads are in flight together
+      int bb[4];
+#pragma unroll
+      for (int q = 0; q < 4; ++q) {
+        if (mask) { bb[q] = chunk + __ffsll((long long)mask) - 1; mask &= mask - 1; }
+        else bb[q] = -1;
+      }
+      uint32_t kk[4], cl[4];
+#pragma unroll
+      for (int q = 0; q < 4; ++q) {
+        const int i = (max(bb[q], 0) << 6) + lane;
+        kk[q] = skey[i];
+        cl[q] = closest[i];
+      }
+#pragma unroll
+      for (int q = 0; q < 4; ++q) {
+        if (bb[q] < 0) continue;
+        const unsigned d = (unsigned)dist2_keys(ck, kk[q]);
+        if (!kCommit) {
+          delta += cl[q] > d ? cl[q] - d : 0u;
+        } else {
+          unsigned c2 = cl[q];
+          if (d < c2) { c2 = d; closest[(bb[q] << 6) + lane] = d; }
+          unsigned dm = c2, ds = c2;
+#pragma unroll
+          for (int o = 32; o > 0; o >>= 1) {
+            dm = max(dm, (unsigned)__shfl_down(dm, o, 64));
+            ds += __shfl_down(ds, o, 64);
+          }
+          if (lane == 0) { tb.bmax[bb[q]] = dm; tb.bsum[bb[q]] = ds; }
+        }
+      }
+    }
+  }
+  return delta;
+}
+
 __global__ __launch_bounds__(kInitThreads) void mbk_init_kernel(const uint32_t* __restrict__ keys, const MbkP* __restrict__ probs,
                                                                 const int32_t* __restrict__ init_idx, const double* __restrict__ rand,
                                                                 double* __restrict__ centres, int32_t* __restrict__ chosen,
                                                                 uint32_t* scratch, const long long* __restrict__ scratch_off) {
   __shared__ InitShared sh;
+  __shared__ uint32_t s_tab[4 * kInitLdsBlocks];
+  __shared__ int s_cblock[kTMaxI];
+  __shared__ unsigned long long s_cbase[kTMaxI];
   const MbkP P = probs[blockIdx.x];
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
   const int n = (int)P.init_n, k = (int)P.k, T = P.T;
   const int nb = (n + 63) >> 6, np = nb << 6;
   uint32_t* skey = scratch + scratch_off[blockIdx.x];
   uint32_t* closest = skey + np;
-  uint32_t* lo = closest + np;
-  uint32_t* hi = lo + nb;
-  uint32_t* bmax = hi + nb;
-  uint32_t* bsum = bmax + nb;
+  InitTables tb;
+  if (nb <= kInitLdsBlocks) {
+    tb.lo = s_tab; tb.hi = s_tab + kInitLdsBlocks; tb.bmax = s_tab + 2 * kInitLdsBlocks; tb.bsum = s_tab + 3 * kInitLdsBlocks;
+  } else {
+    tb.lo = closest + np; tb.hi = tb.lo + nb; tb.bmax = tb.hi + nb; tb.bsum = tb.bmax + nb;
+  }
   int32_t* cho = chosen + P.koff;
   // ---- gather the sample, boxes ------------------------------------------------------------------
   for (int i = tid; i < np; i += kInitThreads) {
@@ -119,10 +183,10 @@ __global__ __launch_bounds__(kInitThreads) void mbk_init_kernel(const uint32_t* 
       ds += __shfl_down(ds, o, 64);
     }
     if (lane == 0) {
-      lo[b] = (r0 << 16) | (g0 << 8) | b0;
-      hi[b] = (r1 << 16) | (g1 << 8) | b1;
-      bmax[b] = dm;
-      bsum[b] = ds;                                     // <= 64 * 195075 fits 32 bits
+      tb.lo[b] = (r0 << 16) | (g0 << 8) | b0;
+      tb.hi[b] = (r1 << 16) | (g1 << 8) | b1;
+      tb.bmax[b] = dm;
+      tb.bsum[b] = ds;                                  // <= 64 * 195075 fits 32 bits
     }
   }
   if (tid == 0) cho[0] = P.first;
@@ -130,14 +194,14 @@ __global__ __launch_bounds__(kInitThreads) void mbk_init_kernel(const uint32_t* 
   const int perb = (nb + kInitThreads - 1) / kInitThreads;
   const int blo = min(tid * perb, nb), bhi = min(blo + perb, nb);
   for (int c = 1; c < k; ++c) {
-    // ---- sample T candidates: searchsorted(cumsum(closest), u * pot, 'left') ----------------------
+    // ---- locate the block of each of the T thresholds u * pot in the cumulative sum ---------------
     unsigned long long loc = 0;
-    for (int b = blo; b < bhi; ++b) loc += bsum[b];
+    for (int b = blo; b < bhi; ++b) loc += tb.bsum[b];
     unsigned long long pot;
     const unsigned long long base = init_exscan64(loc, sh, &pot);
     const double dpot = (double)pot;
     const double* u = rand + P.rand_off + (size_t)(c - 1) * T;
-    if (tid < T) sh.cand[tid] = (u[tid] * dpot <= 0.0) ? 0 : n - 1;
+    if (tid < T) s_cblock[tid] = -1;
     __syncthreads();
     if (loc > 0) {
       for (int t = 0; t < T; ++t) {
@@ -145,41 +209,38 @@ __global__ __launch_bounds__(kInitThreads) void mbk_init_kernel(const uint32_t* 
         if ((double)base < r && r <= (double)(base + loc)) {
           unsigned long long cum = base;
           int b = blo;
-          for (; b < bhi; ++b) {
-            if ((double)(cum + bsum[b]) >= r) break;
-            cum += bsum[b];
+          for (; b < bhi - 1; ++b) {
+            if ((double)(cum + tb.bsum[b]) >= r) break;
+            cum += tb.bsum[b];
           }
-          if (b >= bhi) b = bhi - 1;
-          int i = b << 6;
-          const int iend = min(i + 64, n);
-          for (; i < iend; ++i) {
-            cum += closest[i];
-            if ((double)cum >= r) break;
-          }
-          sh.cand[t] = i < iend ? i : iend - 1;
+          s_cblock[t] = b;
+          s_cbase[t] = cum;
         }
       }
     }
     __syncthreads();
-    // ---- potential of each candidate: pot - sum over improved samples of (closest - d) ------------
+    // ---- one wave per candidate: in-block search (np.searchsorted 'left'), then its potential ------
     for (int t = wave; t < T; t += kInitWaves) {
-      const uint32_t ck = skey[sh.cand[t]];
-      unsigned long long delta = 0;
-      for (int chunk = 0; chunk < nb; chunk += 64) {
-        const int b = chunk + lane;
-        const bool hit = b < nb && (unsigned)box_dist2(ck, lo[b], hi[b]) < bmax[b];
-        unsigned long long mask = __ballot(hit);
-        while (mask) {
-          const int bb = chunk + __ffsll((long long)mask) - 1;
-          mask &= mask - 1;
-          const int i = (bb << 6) + lane;
-          const unsigned d = (unsigned)dist2_keys(ck, skey[i]);
-          const unsigned cl = closest[i];
-          delta += cl > d ? cl - d : 0u;
+      const double r = u[t] * dpot;
+      const int b = s_cblock[t];
+      int cand;
+      if (b < 0) {
+        cand = r <= 0.0 ? 0 : n - 1;
+      } else {
+        const int i = (b << 6) + lane;
+        unsigned long long inc = i < n ? closest[i] : 0u;
+#pragma unroll
+        for (int o = 1; o < 64; o <<= 1) {
+          const unsigned long long tv = __shfl_up(inc, o, 64);
+          if (lane >= o) inc += tv;
         }
+        const unsigned long long m = __ballot(i < n && (double)(s_cbase[t] + inc) >= r);
+        cand = m ? (b << 6) + __ffsll((long long)m) - 1 : min((b << 6) + 63, n - 1);
       }
+      const uint32_t ck = skey[cand];
+      unsigned long long delta = visit_blocks<false>(ck, nb, 0, 64, skey, closest, tb);
       delta = wave_sum(delta);
-      if (lane == 0) sh.pots[t] = pot - delta;
+      if (lane == 0) { sh.pots[t] = pot - delta; sh.cand[t] = cand; }
     }
     __syncthreads();
     int best = 0;
@@ -187,28 +248,8 @@ __global__ __launch_bounds__(kInitThreads) void mbk_init_kernel(const uint32_t* 
     for (int t = 1; t < T; ++t)
       if (sh.pots[t] < bp) { bp = sh.pots[t]; best = t; }
     const int bi = sh.cand[best];
-    const uint32_t kb = skey[bi];
-    // ---- commit the winner --------------------------------------------------------------------------
-    for (int chunk = wave * 64; chunk < nb; chunk += kInitWaves * 64) {
-      const int b = chunk + lane;
-      const bool hit = b < nb && (unsigned)box_dist2(kb, lo[b], hi[b]) < bmax[b];
-      unsigned long long mask = __ballot(hit);
-      while (mask) {
-        const int bb = chunk + __ffsll((long long)mask) - 1;
-        mask &= mask - 1;
-        const int i = (bb << 6) + lane;
-        const unsigned d = (unsigned)dist2_keys(kb, skey[i]);
-        unsigned cl = closest[i];
-        if (d < cl) { cl = d; closest[i] = d; }
-        unsigned dm = cl, ds = cl;
-#pragma unroll
-        for (int o = 32; o > 0; o >>= 1) {
-          dm = max(dm, (unsigned)__shfl_down(dm, o, 64));
-          ds += __shfl_down(ds, o, 64);
-        }
-        if (lane == 0) { bmax[bb] = dm; bsum[bb] = ds; }
-      }
-    }
+    // ---- commit the winner (all waves, disjoint block ranges) ------------------------------------------
+    visit_blocks<true>(skey[bi], nb, wave * 64, kInitWaves * 64, skey, closest, tb);
     if (tid == 0) cho[c] = bi;
     __syncthreads();
   }

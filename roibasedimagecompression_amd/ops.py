@@ -37,6 +37,19 @@ def unpack_rgb(keys):
     return np.stack([(keys >> 16) & 255, (keys >> 8) & 255, keys & 255], axis=1).astype(np.uint8)
 
 
+def morton3(keys):
+    """24-bit Z-order code of packed colours: bit i of R, G, B -> bits 3i+2, 3i+1, 3i."""
+    def spread(v):
+        v = v.astype(np.uint32) & np.uint32(0xFF)
+        v = (v | (v << np.uint32(16))) & np.uint32(0xFF0000FF)
+        v = (v | (v << np.uint32(8))) & np.uint32(0x0F00F00F)
+        v = (v | (v << np.uint32(4))) & np.uint32(0xC30C30C3)
+        v = (v | (v << np.uint32(2))) & np.uint32(0x49249249)
+        return v
+    keys = np.asarray(keys).astype(np.uint32)
+    return (spread(keys >> np.uint32(16)) << np.uint32(2)) | (spread(keys >> np.uint32(8)) << np.uint32(1)) | spread(keys)
+
+
 def clustering_params(n_colors, quality):
     """compute_clustering_params through the C ABI (host-only entry point)."""
     lib = _lib.load()
@@ -311,7 +324,10 @@ class Rhccq:
                 init_size = 3 * k
             init_size = min(init_size, n)
             rs.randint(0, n, init_size)                      # validation_indices: stream position only
-            init_idx = np.sort(rs.randint(0, n, init_size)) if init_size < n else np.arange(n)
+            init_idx = rs.randint(0, n, init_size) if init_size < n else np.arange(n)
+            # canonical sample order: (Morton code of the colour, index): 64 consecutive samples form a
+            # compact box, which is what the exact block pruning of mbk_init_kernel relies on
+            init_idx = init_idx[np.lexsort((init_idx, morton3(np.asarray(key_list[i])[init_idx])))]
             T = 2 + int(math.log(k))
             first = first_centre_index(init_size, rs.random_sample())
             u = rs.uniform(size=max((k - 1) * T, 1))

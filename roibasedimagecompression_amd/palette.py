@@ -60,22 +60,31 @@ def cluster_palettes(rh, jobs):
         labs = rh.minibatch_kmeans([jobs[s]["keys"][nb_idx[s]] for s in mb_jobs], ks)
         for s, l in zip(mb_jobs, labs):
             labels[s] = l
-    # ---- classify clusters, build split trees (breadth first on the device, depth-first output order)
-    smalls, larges = [[] for _ in range(S)], [[] for _ in range(S)]
+    # ---- classify clusters (vectorised: a 4K segment has ~30 000 of them), build split trees for the
+    # oversize ones (breadth first on the device, depth-first output order)
+    small_leaf = [None] * S        # per job: leaf id (within the job's small clusters) per label, -1 = oversize
+    n_small = [0] * S
+    larges = [[] for _ in range(S)]
     frontier = []
     for s in range(S):
         if labels[s] is None:
             continue
         lab = labels[s]
-        order = np.argsort(lab, kind="stable")
-        bounds = np.flatnonzero(np.diff(lab[order])) + 1
-        for rel in np.split(order, bounds):               # ascending label; ascending index inside
-            if len(rel) > jobs[s]["mc"]:
-                node = _Node(s, rel)
+        cnt = np.bincount(lab)
+        present = cnt > 0
+        big = cnt > jobs[s]["mc"]
+        is_small = present & ~big
+        sl = np.full(len(cnt), -1, np.int64)
+        sl[is_small] = np.arange(int(is_small.sum()))          # ascending label order
+        small_leaf[s] = sl
+        n_small[s] = int(is_small.sum())
+        if big.any():
+            order = np.argsort(lab, kind="stable")
+            starts = np.concatenate([[0], np.cumsum(cnt)])
+            for l in np.nonzero(big)[0]:                       # ascending label; ascending index inside
+                node = _Node(s, order[starts[l]:starts[l + 1]])
                 larges[s].append(node)
                 frontier.append(node)
-            else:
-                smalls[s].append(rel)
     while frontier:
         todo = [(nd, _n_splits(len(nd.members), jobs[nd.seg]["mc"])) for nd in frontier]
         run = [(nd, k) for nd, k in todo if k > 0]
@@ -99,55 +108,56 @@ def cluster_palettes(rh, jobs):
     plan = []
     for s in range(S):
         keys = jobs[s]["keys"]
-        P = len(keys)
         black = np.nonzero(keys == 0)[0]
         if labels[s] is None:
             plan.append(None)
             continue
-        leaves = [(rel, False) for rel in smalls[s]]
+        split_leaves = []
 
         def walk(nd):
             if nd.children is None:
-                leaves.append((nd.members, True))
+                split_leaves.append(nd.members)
             else:
                 for ch in nd.children:
                     walk(ch)
         for nd in larges[s]:
             walk(nd)
-        leaf_of = np.full(len(nb_idx[s]), -1, np.int32)
-        for li, (rel, _) in enumerate(leaves):
-            leaf_of[rel] = leaf_base + li
+        leaf_of = small_leaf[s][labels[s]]                      # -1 where the point sits in an oversize cluster
+        for li, rel in enumerate(split_leaves):
+            leaf_of[rel] = n_small[s] + li
+        n_leaves = n_small[s] + len(split_leaves)
         all_keys.append(keys[nb_idx[s]])
-        all_leaf.append(leaf_of)
-        plan.append((black, leaves, leaf_base))
-        leaf_base += len(leaves)
+        all_leaf.append((leaf_of + leaf_base).astype(np.int32))
+        plan.append((black, leaf_of, split_leaves, n_leaves, leaf_base))
+        leaf_base += n_leaves
     means = None
     if leaf_base:
-        dk = torch.from_numpy(np.concatenate(all_keys).astype(np.int64).astype(np.int32)).to(rh.device)
+        dk = torch.from_numpy(np.concatenate(all_keys).view(np.int32)).to(rh.device)
         dl = torch.from_numpy(np.concatenate(all_leaf)).to(rh.device)
-        means = rh.cluster_means(dk, dl, leaf_base)[0].cpu().numpy().astype(np.uint32)
+        means = rh.cluster_means(dk, dl, leaf_base)[0].cpu().numpy().view(np.uint32)
     for s in range(S):
         keys = jobs[s]["keys"]
         P = len(keys)
         if plan[s] is None:                                # only black: returned unchanged (clustering.py:197-199)
             results.append((keys.copy(), np.arange(P, dtype=np.int32), {"branch": "none"}))
             continue
-        black, leaves, base = plan[s]
+        black, leaf_of, split_leaves, n_leaves, base = plan[s]
         nb = nb_idx[s]
         mapping = np.zeros(P, np.int32)
         mapping[black] = np.arange(len(black))
-        new_keys = np.concatenate([np.zeros(len(black), np.uint32), means[base:base + len(leaves)]])
-        has_dups = len(np.unique(keys)) != P
-        if has_dups:
+        new_keys = np.concatenate([np.zeros(len(black), np.uint32), means[base:base + n_leaves]])
+        mapping[nb] = (len(black) + leaf_of) & 0xFFFF       # uint16 mapping_array (clustering.py:373)
+        if split_leaves and len(np.unique(keys)) != P:
+            # find_color_index (clustering.py:803-808): a split child maps only the FIRST palette row equal
+            # to each of its colours; later duplicate rows stay unmapped (0)
             order = np.argsort(keys, kind="stable")
             skeys = keys[order]
-        for li, (rel, from_split) in enumerate(leaves):
-            tgt = nb[rel]
-            if from_split and has_dups:                    # find_color_index: first equal row only
-                tgt = np.unique(order[np.searchsorted(skeys, keys[tgt], side="left")])
-            mapping[tgt] = (len(black) + li) & 0xFFFF       # uint16 mapping_array (clustering.py:373)
+            for li, rel in enumerate(split_leaves):
+                tgt = nb[rel]
+                first = order[np.searchsorted(skeys, keys[tgt], side="left")]
+                mapping[tgt[first != tgt]] = 0
         info = {"branch": "minibatch" if len(nb) >= MINIBATCH_THRESHOLD else "dbscan",
-                "n_clusters": len(smalls[s]) + len(larges[s]), "n_large": len(larges[s])}
+                "n_clusters": n_small[s] + len(larges[s]), "n_large": len(larges[s])}
         results.append((new_keys, mapping, info))
     return results
 
