@@ -1,0 +1,6 @@
+"""Drop-in for the reference's encoder/compression/compression.py: same names, MI355X implementation in
+roibasedimagecompression_amd.api.compression."""
+from roibasedimagecompression_amd.api.compression import *  # noqa: F401,F403
+from roibasedimagecompression_amd.api import compression as _impl
+
+globals().update({k: v for k, v in vars(_impl).items() if not k.startswith("__")})

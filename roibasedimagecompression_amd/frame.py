@@ -107,12 +107,10 @@ class FrameEncoder:
         self.timings[name] = self.timings.get(name, 0.0) + (time.perf_counter() - t0)
 
     # ------------------------------------------------------------------------------------------
-    def encode(self, rgb, classes, want_levels=False, profile=False):
-        """rgb: uint8[H,W,3] device tensor; classes: [ClassSpec] in precedence order (ROI first).
-        Returns dict(palette uint8[K,3], indices (device tensor [H,W], dtype by max index),
-        indices_dtype, shape, top_left, levels (optional))."""
+    def prepare(self, rgb, classes):
+        """Per-pixel passes 1-3 (K0, K0b, K1): per-segment stats, colour bitmaps, sorted palettes and
+        the first raster position of every palette entry.  Returns the frame state dict."""
         rh = self.rh
-        self.timings = {}
         H, W = int(rgb.shape[0]), int(rgb.shape[1])
         assert rgb.dtype == torch.uint8 and rgb.is_contiguous()
         labels = [c.labels for c in classes]
@@ -120,7 +118,6 @@ class FrameEncoder:
         n_jobs = int(job_base[-1])
         if n_jobs == 0:
             raise ValueError("no segments")
-        # ---- pass 1: per-segment stats + colour bitmaps (K0 + K1a) ------------------------------
         t0 = time.perf_counter()
         bitmaps, stats = rh.new_job_state(n_jobs)
         rh.job_scan(rgb, labels, job_base[:-1], bitmaps, stats, black_is_colour=False)
@@ -132,7 +129,7 @@ class FrameEncoder:
         # crop = tight bbox +-2 px clamped to the region (subregions.py:346-352)
         job_class = np.repeat(np.arange(len(classes)), [c.n_seg for c in classes])
         job_region = np.concatenate([c.seg_region for c in classes])
-        rb = np.concatenate([c.region_bbox[c.seg_region] for c in classes]) if n_jobs else np.zeros((0, 4), np.int64)
+        rb = np.concatenate([c.region_bbox[c.seg_region] for c in classes])
         r0 = np.maximum(rb[:, 0], st[:, 0] - 2)
         r1 = np.minimum(rb[:, 2] - 1, st[:, 1] + 2)
         c0 = np.maximum(rb[:, 1], st[:, 2] - 2)
@@ -149,9 +146,8 @@ class FrameEncoder:
             px = rgb.reshape(-1, 3)[torch.from_numpy(np.where(needs_fix, pos, 0)).to(rh.device)].cpu().numpy().astype(np.uint32)
             fk = ((px[:, 0] << 16) | (px[:, 1] << 8) | px[:, 2]).astype(np.uint32)
             fk[~needs_fix] = 0
-            fix_key = rh.dev(fk.astype(np.int64).astype(np.int32))
-        black_jobs = np.nonzero(has_bg | all_black)[0]
-        rh.job_set_black(bitmaps, black_jobs)
+            fix_key = rh.dev(fk.view(np.int32))
+        rh.job_set_black(bitmaps, np.nonzero(has_bg | all_black)[0])
         chunk, counts = rh.bitmap_count(bitmaps)
         P = counts.cpu().numpy().astype(np.int64)
         pal_off = np.concatenate([[0], np.cumsum(P)]).astype(np.int64)
@@ -160,42 +156,66 @@ class FrameEncoder:
         prefix, keys_dev = rh.bitmap_emit(bitmaps, chunk, d_pal_off, total)
         first_pos = torch.full((max(total, 1),), INT_MAX, dtype=torch.int32, device=rh.device)
         rh.job_index(rgb, labels, job_base[:-1], bitmaps, prefix, d_pal_off, fix_key, want_idx=False, first_pos=first_pos)
-        keys_all = keys_dev[:total].cpu().numpy().astype(np.uint32)
+        keys_all = keys_dev[:total].cpu().numpy().view(np.uint32)
         fp_all = first_pos[:total].cpu().numpy().astype(np.int64)
         self._t("unique", t0)
-        # ---- level 1: cluster every segment palette (subregions.py:426-449) -----------------------
+        return {"H": H, "W": W, "rgb": rgb, "classes": classes, "labels": labels, "job_base": job_base, "n_jobs": n_jobs,
+                "bitmaps": bitmaps, "prefix": prefix, "pal_off": pal_off, "d_pal_off": d_pal_off, "fix_key": fix_key,
+                "keys_all": keys_all, "fp_all": fp_all, "P": P, "present": present, "job_class": job_class,
+                "job_region": job_region, "crop": (r0, r1, c0, c1), "total": total}
+
+    def level1(self, S):
+        """Cluster every segment palette (subregions.py:426-449) and merge per region
+        (subregions.py:634-679).  Returns per class the list of region components."""
+        rh = self.rh
+        classes, pal_off, job_base = S["classes"], S["pal_off"], S["job_base"]
+        r0, r1, c0, c1 = S["crop"]
         t0 = time.perf_counter()
         jobs, job_ids = [], []
-        for j in np.nonzero(present)[0]:
-            q = classes[job_class[j]].quality
-            eps, _, mc = clustering_params(int(P[j]), q)
-            jobs.append({"keys": keys_all[pal_off[j]:pal_off[j + 1]], "quality": q, "eps": eps, "mc": mc})
+        for j in np.nonzero(S["present"])[0]:
+            q = classes[S["job_class"][j]].quality
+            eps, _, mc = clustering_params(int(S["P"][j]), q)
+            jobs.append({"keys": S["keys_all"][pal_off[j]:pal_off[j + 1]], "quality": q, "eps": eps, "mc": mc})
             job_ids.append(j)
         res = cluster_palettes(rh, jobs)
         self._t("level1_cluster", t0)
         t0 = time.perf_counter()
         seg_comp = {}
         for j, (nk, mp, info) in zip(job_ids, res):
-            fp_new = _scatter_min(len(nk), mp, fp_all[pal_off[j]:pal_off[j + 1]])
+            fp_new = _scatter_min(len(nk), mp, S["fp_all"][pal_off[j]:pal_off[j + 1]])
             seg_comp[j] = _Comp(nk, fp_new, (int(r0[j]), int(c0[j])), (int(r1[j] - r0[j] + 1), int(c1[j] - c0[j] + 1)),
                                 {int(j): mp.astype(np.int32)}, False)
-        levels = {"level1": [], "level2": []} if want_levels else None
-        lvl2, q2s = [], []
+        per_class = []
         for ci, cls in enumerate(classes):
             regs = []
             for r in range(len(cls.region_bbox)):
-                segs = [seg_comp[j] for j in range(job_base[ci], job_base[ci + 1]) if job_region[j] == r and j in seg_comp]
-                if not segs:
-                    continue
-                regs.append(_merge(segs, tuple(int(v) for v in cls.region_bbox[r])))     # subregions.py:637-652
-            if want_levels:
-                levels["level1"].append(regs)
+                segs = [seg_comp[j] for j in range(job_base[ci], job_base[ci + 1]) if S["job_region"][j] == r and j in seg_comp]
+                # subregions.py:637-679: > 1 components are merged on the region canvas, one is kept as is
+                regs.append(_merge(segs, tuple(int(v) for v in cls.region_bbox[r])) if segs else None)
+            per_class.append(regs)
+        self._t("merge1", t0)
+        return per_class
+
+    def encode(self, rgb, classes, want_levels=False, profile=False):
+        """rgb: uint8[H,W,3] device tensor; classes: [ClassSpec] in precedence order (ROI first).
+        Returns dict(palette uint8[K,3], indices (device tensor [H,W], dtype by max index),
+        indices_dtype, shape, top_left, levels (optional))."""
+        rh = self.rh
+        self.timings = {}
+        S = self.prepare(rgb, classes)
+        H, W, pal_off, total = S["H"], S["W"], S["pal_off"], S["total"]
+        per_class = self.level1(S)
+        t0 = time.perf_counter()
+        levels = {"level1": per_class, "level2": []} if want_levels else None
+        lvl2, q2s = [], []
+        for ci, cls in enumerate(classes):
+            regs = [r for r in per_class[ci] if r is not None]
             q2 = min(cls.quality * 2, 100)
             q2s.append(q2)
             if not regs:
                 continue                                                                  # rhccq.ipynb:1009-1013
             lvl2.append((ci, _merge(regs, (0, 0, H, W)), q2))
-        self._t("merge12", t0)
+        self._t("merge2", t0)
         t0 = time.perf_counter()
         # ---- level 2: cluster each class palette (regions.py:52-68) ---------------------------------
         jobs2 = []
@@ -243,25 +263,24 @@ class FrameEncoder:
         d_lut = rh.dev(lut)
         self._t("compose", t0)
         t0 = time.perf_counter()
-        out = rh.frame_remap(rgb, labels, job_base[:-1], bitmaps, prefix, d_pal_off, fix_key, d_lut, default_index, out_dtype)
+        out = rh.frame_remap(rgb, S["labels"], S["job_base"][:-1], S["bitmaps"], S["prefix"], S["d_pal_off"], S["fix_key"], d_lut,
+                             default_index, out_dtype)
         self._t("remap", t0, sync=profile)
         result = {"palette": unpack_rgb(fk3), "indices": out, "indices_dtype": dtype_name,
                   "shape": (H, W) if multi else tuple(m3c.shape), "top_left": (0, 0) if multi else tuple(m3c.top_left),
-                  "quality3": q3, "n_unique": P, "info3": info3}
+                  "quality3": q3, "n_unique": S["P"], "info3": info3}
         if want_levels:
-            levels["pal_off"] = pal_off
-            levels["seg_comp"] = seg_comp
-            levels["state"] = (bitmaps, prefix, d_pal_off, fix_key, job_base)
+            levels["state"] = S
             result["levels"] = levels
         return result
 
     # ------------------------------------------------------------------------------------------
-    def render_component(self, rgb, classes, levels, comp, class_index=None):
+    def render_component(self, S, comp):
         """Index map (device int32 [h,w]) of one level-1/level-2 component as the reference would
-        return it: canvas semantics for merged components, crop semantics for single segments."""
+        return it: canvas semantics for merged components (uncovered = 0 = black), crop semantics for a
+        single segment (background = the palette's black entry)."""
         rh = self.rh
-        bitmaps, prefix, d_pal_off, fix_key, job_base = levels["state"]
-        pal_off = levels["pal_off"]
+        pal_off = S["pal_off"]
         lut = np.full(max(int(pal_off[-1]), 1), -1, np.int32)
         for job, m in comp.maps.items():
             lut[pal_off[job]:pal_off[job + 1]] = m
@@ -269,8 +288,8 @@ class FrameEncoder:
         if not comp.merged:
             blk = np.nonzero(comp.keys == 0)[0]
             default = int(blk[0]) if len(blk) else 0
-        labels = [c.labels for c in classes]
-        full = rh.frame_remap(rgb, labels, job_base[:-1], bitmaps, prefix, d_pal_off, fix_key, rh.dev(lut), default, torch.int32)
+        full = rh.frame_remap(S["rgb"], S["labels"], S["job_base"][:-1], S["bitmaps"], S["prefix"], S["d_pal_off"], S["fix_key"],
+                              rh.dev(lut), default, torch.int32)
         r, c = comp.top_left
         h, w = comp.shape
         return full[r:r + h, c:c + w].contiguous()

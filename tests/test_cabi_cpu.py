@@ -1,0 +1,142 @@
+"""CPU-side checks of the boundary: the C-ABI library loads and exports every symbol include/rhccq.h
+declares; host-only entry points agree with the oracle; the mirror modules import under the
+reference's names; the container code (host side) is byte-exact against the reference's files."""
+import json
+import os
+import re
+
+import numpy as np
+import pytest
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+G = os.path.join(ROOT, "tests", "golden")
+
+
+def test_header_symbols_exported_and_bound():
+    from roibasedimagecompression_amd import _lib
+    hdr = open(os.path.join(ROOT, "include", "rhccq.h")).read()
+    declared = set(re.findall(r"\b(rhccq_[a-z0-9_]+)\s*\(", hdr))
+    declared -= {"rhccq_ctx", "rhccq_mbk_problem"}
+    lib = _lib.load()
+    assert declared, "no declarations parsed"
+    for name in sorted(declared):
+        assert hasattr(lib, name), f"{name} declared in include/rhccq.h but not exported"
+        assert name in _lib.PROTOTYPES, f"{name} has no ctypes prototype"
+    assert set(_lib.PROTOTYPES) <= declared
+    assert lib.rhccq_abi_version() == 1
+
+
+def test_params_and_eps_threshold_match_oracle():
+    from oracle import rhccq_oracle as O
+    from roibasedimagecompression_amd import ops
+    for n, q, eps_hex, ms, mc in json.load(open(os.path.join(G, "g2_params.json"))):
+        e, m, c = ops.clustering_params(n, q)
+        assert float(e).hex() == eps_hex and m == ms and c == mc
+    with pytest.raises(ZeroDivisionError):
+        ops.clustering_params(10, 0)
+    for q in list(range(1, 101)) + [12.5, 33.3]:
+        eps = 128 - 1.28 * q
+        if eps == 0:
+            eps = 1
+        thr, bnd, r2 = ops.eps_threshold(eps)
+        assert (thr, bnd) == O.eps_threshold(eps)
+        assert r2 == (np.float64(eps) / np.float64(255.0)) ** 2
+    for eps in (1.0, 3.0, 32.0, 64.0, 96.0, 12.8, 0.5):
+        assert ops.eps_threshold(eps)[:2] == O.eps_threshold(eps)
+
+
+def test_no_cpu_fallback_without_gpu():
+    import torch
+    from roibasedimagecompression_amd import RhccqError
+    from roibasedimagecompression_amd.ops import Rhccq
+    if torch.cuda.is_available():
+        pytest.skip("GPU present")
+    with pytest.raises(RhccqError):
+        Rhccq(0)
+
+
+def test_product_package_never_imports_oracle():
+    pkg = os.path.join(ROOT, "roibasedimagecompression_amd")
+    for d, _, files in os.walk(pkg):
+        for f in files:
+            if f.endswith(".py"):
+                src = open(os.path.join(d, f)).read()
+                assert "import oracle" not in src and "from oracle" not in src, os.path.join(d, f)
+    for top in ("encoder", "decoder"):
+        for d, _, files in os.walk(os.path.join(ROOT, top)):
+            for f in files:
+                if f.endswith(".py"):
+                    assert "oracle" not in open(os.path.join(d, f)).read()
+
+
+def test_reference_import_surface():
+    from encoder.compression.clustering import compute_clustering_params, cluster_palette_colors_parallel, get_all_unique_colors  # noqa: F401
+    from encoder.compression.merging import merge_region_components_simple, visualize_merged_result  # noqa: F401
+    from encoder.compression.subregions import subregion_quantization  # noqa: F401
+    from encoder.compression.regions import region_quantization  # noqa: F401
+    from encoder.compression.image import quantize_image  # noqa: F401
+    from encoder.compression.compression import (save_compressed, compress_palette, compress_indices_simple_optimized,  # noqa: F401
+                                                 lossless_compress_optimized, optimize_compressed_dtype)
+    from decoder.uncompression.uncompression import (lossless_decompress, load_compressed, decompress_color_quantization,  # noqa: F401
+                                                     partial_decompress_color_quantization)
+    from encoder.ROI.edges import compute_local_density, suggest_automatic_threshold, get_edge_map  # noqa: F401
+    from encoder.ROI.roi import extract_regions, extract_roi_nonroi  # noqa: F401
+    from encoder.subregions.split_score import calculate_split_score, normalize_result  # noqa: F401
+    from encoder.subregions.slic import visualize_split_analysis, enhanced_slic_with_texture, extract_slic_segment_boundaries  # noqa: F401
+    from encoder.enhancer.clahe import get_enhanced_image  # noqa: F401
+    assert compute_clustering_params(2274, 20, color_space="lab") == (102.4, 1, 91)
+    assert get_all_unique_colors(np.zeros((0, 0, 3), np.uint8), (0, 0)) is None
+    assert merge_region_components_simple([], (0, 0, 4, 4)) == []
+    with pytest.raises(NotImplementedError):
+        extract_regions(None, None, None)
+
+
+def test_index_list_behaves_like_a_list():
+    from roibasedimagecompression_amd.segment import IndexList
+    a = IndexList(np.array([3, 1, 1, 2, 1], np.int32))
+    assert len(a) == 5 and a.count(1) == 3 and a[0] == 3 and list(a) == [3, 1, 1, 2, 1]
+    assert np.array(a).reshape(1, 5).tolist() == [[3, 1, 1, 2, 1]] and a == [3, 1, 1, 2, 1] and a.tolist() == [3, 1, 1, 2, 1]
+    assert max(a) == 3 and a[1:3].tolist() == [1, 1]
+
+
+def test_container_bytes_and_safe_loader(tmp_path):
+    from encoder.compression.compression import lossless_compress_optimized, save_compressed, optimize_compressed_dtype
+    from decoder.uncompression.uncompression import load_compressed, lossless_decompress
+    g = np.load(os.path.join(G, "g7_container.npz"))
+    pal = [[int(v) for v in r] for r in g["pal"]]
+    idx = g["idx"].tolist()
+    pkg = lossless_compress_optimized(pal, idx, tuple(int(v) for v in g["shape"]))
+    assert pkg["p"] == g["p"].tobytes() and pkg["i"] == g["i"].tobytes() and pkg["d"] == str(g["d"]) and pkg["l"] == int(g["l"])
+    fn = tmp_path / "x.rhccq"
+    size = save_compressed(pkg, str(fn))
+    raw = open(os.path.join(G, "g7_lenna64.rhccq"), "rb").read()
+    assert fn.read_bytes() == raw and size == len(raw) - 1       # reference returns len + 8 for a 9-byte header
+    back = load_compressed(os.path.join(G, "g7_lenna64.rhccq"))
+    p2, i2, s2 = lossless_decompress(back)
+    assert [list(c) for c in p2] == pal and i2 == idx and tuple(s2) == tuple(g["shape"])
+    assert optimize_compressed_dtype({"indices": idx, "palette": pal})["indices_dtype"] == "uint8"
+    with pytest.raises(TypeError):
+        lossless_compress_optimized(pal, (1, 2, 3), (1, 3))
+    import pickle, struct, zlib
+    evil = zlib.compress(pickle.dumps(os.getcwd))
+    bad = tmp_path / "evil.rhccq"
+    bad.write_bytes(b"RHCCQ" + struct.pack("<I", len(evil)) + evil)
+    with pytest.raises(Exception):
+        load_compressed(str(bad))
+
+
+def test_decoder_kat_files():
+    import hashlib
+    from decoder.uncompression.uncompression import load_compressed, lossless_decompress
+    kat = json.load(open(os.path.join(G, "g8_rhccq_kat.json")))
+    seen = 0
+    for key, rec in kat.items():
+        fn = os.path.join(G, os.path.basename(key))
+        if not os.path.exists(fn) or hashlib.sha256(open(fn, "rb").read()).hexdigest() != rec["file_sha256"]:
+            continue
+        pal, idx, shape = lossless_decompress(load_compressed(fn))
+        assert [int(v) for v in shape] == rec["shape"] and len(pal) == rec["l"]
+        assert hashlib.sha256(np.array(pal, np.uint8).tobytes()).hexdigest() == rec["palette_sha256"]
+        assert hashlib.sha256(np.array(idx, np.dtype(rec["d"])).tobytes()).hexdigest() == rec["indices_sha256"]
+        seen += 1
+    assert seen >= 3

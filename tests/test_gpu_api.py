@@ -1,0 +1,106 @@
+"""The reference's Python interface (encoder.compression.*, decoder.uncompression.*) served by the HIP
+path, checked against the oracle and the reference's golden outputs.  GPU only."""
+import os
+
+import numpy as np
+import pytest
+
+pytestmark = pytest.mark.gpu
+G = os.path.join(os.path.dirname(__file__), "golden")
+
+
+def arrs(seg):
+    return np.array(seg["palette"], dtype=np.int64).reshape(-1, 3).astype(np.uint8), np.array(seg["indices"]).reshape(-1).astype(np.int64)
+
+
+def test_unique_and_cluster_palette_functions():
+    from oracle import rhccq_oracle as O
+    from encoder.compression.clustering import get_all_unique_colors, compute_clustering_params, cluster_palette_colors_parallel
+    g = np.load(os.path.join(G, "g4_cluster.npz"))
+    exact = 0
+    for i in range(int(g["n"])):
+        img, q = g[f"img{i}"], int(g[f"q{i}"])
+        d = get_all_unique_colors(img, (3, 4))
+        pal, idx = O.unique_colors(img)
+        p0, i0 = arrs(d)
+        assert np.array_equal(p0, pal) and np.array_equal(i0, idx) and d["actual_colors"] == len(pal)
+        assert d["top_left"] == (3, 4) and d["shape"] == img.shape[:2] and d["indices"].count(0) == int((idx == 0).sum())
+        eps, ms, mc = compute_clustering_params(d["actual_colors"], q, color_space="lab")
+        o = cluster_palette_colors_parallel(q, d, eps=eps, min_samples=1, max_colors_per_cluster=mc)
+        npal, nidx = O.cluster_palette(q, pal, idx, eps, mc)
+        p1, i1 = arrs(o)
+        assert np.array_equal(p1, npal) and np.array_equal(i1, nidx), (i, q)          # HIP path == oracle
+        assert o["compressed_colors"] == len(npal)
+        exact += np.array_equal(p1, g[f"pal{i}"]) and np.array_equal(i1, g[f"idx{i}"])  # == the reference itself
+    assert exact >= 15
+    black = get_all_unique_colors(np.zeros((4, 4, 3), np.uint8), (0, 0))
+    assert cluster_palette_colors_parallel(20, black, eps=102.4, min_samples=1, max_colors_per_cluster=1) is black
+    with pytest.raises(NotImplementedError):
+        cluster_palette_colors_parallel(20, black, eps=102.4, min_samples=2, max_colors_per_cluster=1)
+
+
+def test_merge_function_golden():
+    from encoder.compression.merging import merge_region_components_simple
+    g = np.load(os.path.join(G, "g5_merge.npz"))
+    for name in g["names"]:
+        comps = []
+        for ci in range(int(g[f"{name}_n"])):
+            m = g[f"{name}_c{ci}_meta"]
+            comps.append({"top_left": (int(m[0]), int(m[1])), "shape": (int(m[2]), int(m[3])),
+                          "palette": g[f"{name}_c{ci}_pal"].tolist(), "indices": g[f"{name}_c{ci}_idx"].tolist()})
+        out = merge_region_components_simple(comps, tuple(int(v) for v in g[f"{name}_bbox"]))
+        assert len(out) == 1
+        p, i = arrs(out[0])
+        m = g[f"{name}_out_meta"]
+        assert np.array_equal(p, g[f"{name}_out_pal"]) and np.array_equal(i, g[f"{name}_out_idx"]), name
+        assert tuple(out[0]["top_left"]) == (m[0], m[1]) and tuple(out[0]["shape"]) == (m[2], m[3]) and out[0]["actual_colors"] == m[4]
+
+
+@pytest.mark.parametrize("tag", ["lenna64", "poster64", "kodak96"])
+def test_notebook_flow_through_the_mirror(tag, tmp_path):
+    """rhccq.ipynb cells 10-18 driven through the mirrored functions (SLIC replaced by the fixture's label
+    map through the `segmenter` hook): every level equals the oracle bit for bit; file round-trips."""
+    from oracle import rhccq_oracle as O
+    from encoder.compression.subregions import subregion_quantization
+    from encoder.compression.regions import region_quantization
+    from encoder.compression.image import quantize_image
+    from encoder.compression.compression import lossless_compress_optimized, save_compressed
+    from decoder.uncompression.uncompression import load_compressed, decompress_color_quantization
+    g = np.load(os.path.join(G, "g6_chain.npz"))
+    img = g[f"{tag}_img"]
+    H, W = img.shape[:2]
+    qs = [int(v) for v in g[f"{tag}_q"]]
+    regions, oracle_classes = [], []
+    for key in ("lab_roi", "lab_non"):
+        lab = g[f"{tag}_{key}"] + 1
+        mask = lab > 0
+        rows, cols = np.where(mask)
+        bbox = (int(rows.min()), int(cols.min()), int(rows.max()) + 1, int(cols.max()) + 1)
+        sl = (slice(bbox[0], bbox[2]), slice(bbox[1], bbox[3]))
+        regions.append(([{"bbox": bbox, "bbox_mask": mask[sl]}], lab[sl].astype(np.int32)))
+        oracle_classes.append([{"bbox": bbox, "bbox_mask": mask[sl], "seglabels": lab[sl].astype(np.int32)}])
+    ref = O.encode_frame(img, oracle_classes, qs)
+    l1 = [subregion_quantization(img, regs, quality=q, subregion_type=t, segmenter=lambda im, m, s=seg: s)
+          for (regs, seg), q, t in zip(regions, qs, ("ROI", "nonROI"))]
+    for ci in range(2):
+        p, i = arrs(l1[ci][0][0])
+        r = ref["level1"][ci][0]
+        assert np.array_equal(p, np.asarray(r["palette"]).reshape(-1, 3)) and np.array_equal(i, np.asarray(r["indices"]).reshape(-1))
+        assert tuple(l1[ci][0][0]["top_left"]) == tuple(r["top_left"]) and tuple(l1[ci][0][0]["shape"]) == tuple(r["shape"])
+    q2 = [min(q * 2, 100) for q in qs]
+    roi2 = region_quantization(l1[0], quality=q2[0], original_image_height=H, original_image_width=W)
+    non2 = region_quantization(l1[1], quality=q2[1], original_image_height=H, original_image_width=W)
+    for got, r in ((roi2[0], ref["level2"][0]), (non2[0], ref["level2"][1])):
+        p, i = arrs(got)
+        assert np.array_equal(p, np.asarray(r["palette"]).reshape(-1, 3)) and np.array_equal(i, np.asarray(r["indices"]).reshape(-1))
+    fin = quantize_image(roi2 + non2, quality=min(sum(q2), 100), original_image_height=H, original_image_width=W)
+    p, i = arrs(fin)
+    assert np.array_equal(p, np.asarray(ref["final"]["palette"]).reshape(-1, 3))
+    assert np.array_equal(i, np.asarray(ref["final"]["indices"]).reshape(-1))
+    assert fin["indices_dtype"] == ref["final"]["indices_dtype"]
+    pk = lossless_compress_optimized(fin["palette"], np.array(fin["indices"]).reshape(H, W), fin["shape"])
+    fn = tmp_path / "out.rhccq"
+    save_compressed(pk, str(fn))
+    assert fn.read_bytes() == O.container_bytes(O.pack_container(p, i, (H, W)))
+    rec = decompress_color_quantization(load_compressed(str(fn)))["image"]
+    assert np.array_equal(rec, p[i].reshape(H, W, 3))
