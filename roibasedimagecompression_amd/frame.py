@@ -106,6 +106,10 @@ class FrameEncoder:
             torch.cuda.synchronize()
         self.timings[name] = self.timings.get(name, 0.0) + (time.perf_counter() - t0)
 
+    def reduce_first_positions(self, arrays):
+        """hook of the tiled (multi-GPU) encoder; a single GPU sees the whole frame"""
+        return arrays
+
     # ------------------------------------------------------------------------------------------
     def prepare(self, rgb, classes):
         """Per-pixel passes 1-3 (K0, K0b, K1): per-segment stats, colour bitmaps, sorted palettes and
@@ -181,8 +185,9 @@ class FrameEncoder:
         self._t("level1_cluster", t0)
         t0 = time.perf_counter()
         seg_comp = {}
-        for j, (nk, mp, info) in zip(job_ids, res):
-            fp_new = _scatter_min(len(nk), mp, S["fp_all"][pal_off[j]:pal_off[j + 1]])
+        fps = self.reduce_first_positions([_scatter_min(len(nk), mp, S["fp_all"][pal_off[j]:pal_off[j + 1]])
+                                           for j, (nk, mp, info) in zip(job_ids, res)])
+        for j, (nk, mp, info), fp_new in zip(job_ids, res, fps):
             seg_comp[j] = _Comp(nk, fp_new, (int(r0[j]), int(c0[j])), (int(r1[j] - r0[j] + 1), int(c1[j] - c0[j] + 1)),
                                 {int(j): mp.astype(np.int32)}, False)
         per_class = []
