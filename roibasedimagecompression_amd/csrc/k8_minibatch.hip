@@ -40,13 +40,17 @@ struct MbkP {  // device copy of rhccq_mbk_problem
 
 constexpr int kInitThreads = 1024;
 constexpr int kInitWaves = kInitThreads / 64;
-constexpr int kTMaxI = 24;
+constexpr int kTMaxI = 16;   // n_local_trials = 2 + int(ln k) <= 16 for k < 1.2e6; one wave per candidate
 
 struct InitShared {
   unsigned long long scan_red[kInitWaves + 1];
   unsigned long long red64[kInitWaves];
   unsigned long long pots[kTMaxI];
   int cand[kTMaxI];
+  uint32_t ckey[kTMaxI];
+  unsigned long long delta[kTMaxI];
+  unsigned long long pot;
+  int n_touch, n_items, overflow;
 };
 
 __device__ __forceinline__ unsigned long long init_exscan64(unsigned long long v, InitShared& sh, unsigned long long* total) {
@@ -78,65 +82,361 @@ __device__ __forceinline__ int box_dist2(uint32_t k, uint32_t lo, uint32_t hi) {
   return __mul24(dr, dr) + __mul24(dg, dg) + __mul24(db, db);
 }
 
-// per problem scratch layout (u32): skey[np] closest[np] and, when the block tables do not fit LDS,
-// lo[nb] hi[nb] bmax[nb] bsum[nb]   (nb = ceil(init_n / 64), np = nb * 64)
-constexpr int kInitLdsBlocks = 4096;   // block tables in LDS up to 262144 init samples (64 KB)
+// per problem scratch layout: samp[np] (uint2 = {key, closest}) and, when the tables do not fit LDS,
+// lo[nb] hi[nb] bmax[nb] bsum[nb] sblo[nsb] sbhi[nsb] sbmax[nsb]
+//   nb = ceil(init_n / 64) blocks of 64 samples, np = nb * 64, nsb = ceil(nb / 16) super-blocks
+constexpr int kInitLdsBlocks = 4096;   // tables in LDS up to 262144 init samples (64 KB + 3 KB)
+constexpr int kInitLdsSuper = kInitLdsBlocks / 16;
 
 struct InitTables {
   uint32_t* lo;     // per block: packed min corner of the bounding box
   uint32_t* hi;     // packed max corner
   uint32_t* bmax;   // max closest distance in the block
   uint32_t* bsum;   // sum of closest distances in the block
+  uint32_t* sblo;   // per super-block (16 blocks): box, max of bmax (may lag high), exact sum of bsum
+  uint32_t* sbhi;
+  uint32_t* sbmax;
+  uint32_t* sbsum;
 };
 
-// distance work of one candidate / the winner over the blocks [chunk0, nb) visited with stride
-// `chunk_stride`; kCommit = false: returns sum over samples of max(closest - d, 0);
-// kCommit = true: lowers closest[] and refreshes bmax / bsum of the touched blocks.
-template <bool kCommit>
-__device__ __forceinline__ unsigned long long visit_blocks(uint32_t ck, int nb, int chunk0, int chunk_stride, const uint32_t* skey,
-                                                           uint32_t* closest, InitTables tb) {
+#ifdef RHCCQ_STAMPS   // diagnostic build only (tools_stamps.py): per-phase cycle shares of the init chain
+__device__ unsigned long long g_init_stamps[16];
+#define STAMP(slot)                                  \
+  do {                                               \
+    const unsigned long long _t = clock64();        \
+    _acc[slot] += _t - _last;                        \
+    _last = _t;                                      \
+  } while (0)
+#else
+#define STAMP(slot) do {} while (0)
+#endif
+
+// ---- wave helpers on DPP (VALU, no LDS crossbar): sums / max of one u32 per lane ---------------------
+__device__ __forceinline__ unsigned dpp_row_sum(unsigned v) {
+  v += (unsigned)__builtin_amdgcn_update_dpp(0, (int)v, 0xB1, 0xF, 0xF, true);    // quad_perm [1,0,3,2]
+  v += (unsigned)__builtin_amdgcn_update_dpp(0, (int)v, 0x4E, 0xF, 0xF, true);    // quad_perm [2,3,0,1]
+  v += (unsigned)__builtin_amdgcn_update_dpp(0, (int)v, 0x141, 0xF, 0xF, true);   // row_half_mirror
+  v += (unsigned)__builtin_amdgcn_update_dpp(0, (int)v, 0x140, 0xF, 0xF, true);   // row_mirror
+  return v;                                                                        // every lane: sum of its row of 16
+}
+__device__ __forceinline__ unsigned dpp_row_max(unsigned v) {
+  v = max(v, (unsigned)__builtin_amdgcn_update_dpp(0, (int)v, 0xB1, 0xF, 0xF, true));
+  v = max(v, (unsigned)__builtin_amdgcn_update_dpp(0, (int)v, 0x4E, 0xF, 0xF, true));
+  v = max(v, (unsigned)__builtin_amdgcn_update_dpp(0, (int)v, 0x141, 0xF, 0xF, true));
+  v = max(v, (unsigned)__builtin_amdgcn_update_dpp(0, (int)v, 0x140, 0xF, 0xF, true));
+  return v;
+}
+// wave-uniform results (scalar): sum (< 2^32 required) / max over the 64 lanes
+__device__ __forceinline__ unsigned wave_sum_u32(unsigned v) {
+  v = dpp_row_sum(v);
+  return (unsigned)__builtin_amdgcn_readlane((int)v, 0) + (unsigned)__builtin_amdgcn_readlane((int)v, 16) +
+         (unsigned)__builtin_amdgcn_readlane((int)v, 32) + (unsigned)__builtin_amdgcn_readlane((int)v, 48);
+}
+__device__ __forceinline__ unsigned wave_max_u32(unsigned v) {
+  v = dpp_row_max(v);
+  return max(max((unsigned)__builtin_amdgcn_readlane((int)v, 0), (unsigned)__builtin_amdgcn_readlane((int)v, 16)),
+             max((unsigned)__builtin_amdgcn_readlane((int)v, 32), (unsigned)__builtin_amdgcn_readlane((int)v, 48)));
+}
+__device__ __forceinline__ unsigned long long wave_incscan_u64(unsigned long long v) {
   const int lane = threadIdx.x & 63;
-  unsigned long long delta = 0;
-  for (int chunk = chunk0; chunk < nb; chunk += chunk_stride) {
-    const int b = chunk + lane;
-    const bool hit = b < nb && (unsigned)box_dist2(ck, tb.lo[b], tb.hi[b]) < tb.bmax[b];
-    unsigned long long mask = __ballot(hit);
-    while (mask) {
-      // up to four hit blocks per round so that their loads are in flight together
-      int bb[4];
+#pragma unroll
+  for (int o = 1; o < 64; o <<= 1) {
+    const unsigned long long t = __shfl_up(v, o, 64);
+    if (lane >= o) v += t;
+  }
+  return v;
+}
+
+// Exact two-level pruning: a (super-)block is skipped when the new centre `ck` is at least as far from its
+// bounding box as the largest closest-distance inside it (then no sample of it can improve).
+// enumerate_hits: one wave, all super-blocks; calls f(block) wave-uniformly for every block that may improve.
+template <typename F>
+__device__ __forceinline__ void enumerate_hits(uint32_t ck, int nb, int nsb, const InitTables& tb, F&& f) {
+  const int lane = threadIdx.x & 63;
+  for (int base = 0; base < nsb; base += 64) {
+    const int sb = base + lane;
+    const bool hsb = sb < nsb && (unsigned)box_dist2(ck, tb.sblo[sb], tb.sbhi[sb]) < tb.sbmax[sb];
+    unsigned long long msb = __ballot(hsb);
+    while (msb) {
+      // four hit super-blocks per round: lane -> (which super-block, which of its 16 blocks)
+      int sbi[4];
 #pragma unroll
       for (int q = 0; q < 4; ++q) {
-        if (mask) { bb[q] = chunk + __ffsll((long long)mask) - 1; mask &= mask - 1; }
-        else bb[q] = -1;
+        if (msb) { sbi[q] = base + __ffsll((long long)msb) - 1; msb &= msb - 1; }
+        else sbi[q] = -1;
       }
-      uint32_t kk[4], cl[4];
+      const int which = lane >> 4;
+      const int my_sb = which == 0 ? sbi[0] : which == 1 ? sbi[1] : which == 2 ? sbi[2] : sbi[3];
+      const int b = my_sb * 16 + (lane & 15);
+      const bool hb = my_sb >= 0 && b < nb && (unsigned)box_dist2(ck, tb.lo[b], tb.hi[b]) < tb.bmax[b];
+      f(__ballot(hb), b, hb);
+    }
+  }
+}
+
+// lower closest[] of block b against centre ck; refresh bmax / bsum / sbsum; note the super-block as touched
+__device__ __forceinline__ void commit_block(int b, uint32_t ck, uint2* samp, const InitTables& tb, int* touch, int* n_touch, int touch_cap) {
+  const int lane = threadIdx.x & 63;
+  const uint2 sv = samp[(b << 6) + lane];
+  const unsigned d = (unsigned)dist2_keys(ck, sv.x);
+  unsigned c2 = sv.y;
+  if (d < c2) { c2 = d; samp[(b << 6) + lane].y = d; }
+  const unsigned dm = wave_max_u32(c2), ds = wave_sum_u32(c2);
+  if (lane == 0) {
+    const unsigned old = tb.bsum[b];
+    tb.bmax[b] = dm;
+    tb.bsum[b] = ds;
+    if (old != ds) atomicSub(&tb.sbsum[b >> 4], old - ds);
+    const int slot = atomicAdd(n_touch, 1);
+    if (slot < touch_cap) touch[slot] = b >> 4;
+  }
+}
+
+constexpr int kMaxItems = 16384;           // (candidate, block) work items per step held in LDS
+constexpr int kMaxTouch = 1024;
+
+__device__ __forceinline__ void init_body(const uint32_t* __restrict__ keys, const MbkP& P, const int32_t* __restrict__ init_idx,
+                                          const double* __restrict__ rand, double* __restrict__ centres, int32_t* __restrict__ cho,
+                                          uint2* samp, InitTables tb, InitShared& sh, double* s_u /* [2][kTMaxI] */, int* s_touch,
+                                          uint32_t* s_items /* nullptr: no work list (tables in global memory) */) {
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const int n = (int)P.init_n, k = (int)P.k, T = P.T;
+  const int nb = (n + 63) >> 6, np = nb << 6, nsb = (nb + 15) >> 4;
+  // ---- gather the sample, first centre, block tables -----------------------------------------------
+  const uint32_t kf = keys[P.off + init_idx[P.init_off + P.first]];
+  for (int i = tid; i < np; i += kInitThreads) {
+    const int src = i < n ? i : n - 1;                  // padding repeats the last sample with closest = 0
+    const uint32_t kk = keys[P.off + init_idx[P.init_off + src]];
+    samp[i] = make_uint2(kk, i < n ? (unsigned)dist2_keys(kk, kf) : 0u);
+  }
+  __syncthreads();
+  for (int b = wave; b < nb; b += kInitWaves) {
+    const uint2 sv = samp[(b << 6) + lane];
+    unsigned r0 = key_r(sv.x), r1 = r0, g0 = key_g(sv.x), g1 = g0, b0 = key_b(sv.x), b1 = b0;
 #pragma unroll
-      for (int q = 0; q < 4; ++q) {
-        const int i = (max(bb[q], 0) << 6) + lane;
-        kk[q] = skey[i];
-        cl[q] = closest[i];
-      }
-#pragma unroll
-      for (int q = 0; q < 4; ++q) {
-        if (bb[q] < 0) continue;
-        const unsigned d = (unsigned)dist2_keys(ck, kk[q]);
-        if (!kCommit) {
-          delta += cl[q] > d ? cl[q] - d : 0u;
-        } else {
-          unsigned c2 = cl[q];
-          if (d < c2) { c2 = d; closest[(bb[q] << 6) + lane] = d; }
-          unsigned dm = c2, ds = c2;
-#pragma unroll
-          for (int o = 32; o > 0; o >>= 1) {
-            dm = max(dm, (unsigned)__shfl_down(dm, o, 64));
-            ds += __shfl_down(ds, o, 64);
+    for (int o = 32; o > 0; o >>= 1) {
+      r0 = min(r0, (unsigned)__shfl_down(r0, o, 64)); r1 = max(r1, (unsigned)__shfl_down(r1, o, 64));
+      g0 = min(g0, (unsigned)__shfl_down(g0, o, 64)); g1 = max(g1, (unsigned)__shfl_down(g1, o, 64));
+      b0 = min(b0, (unsigned)__shfl_down(b0, o, 64)); b1 = max(b1, (unsigned)__shfl_down(b1, o, 64));
+    }
+    const unsigned dm = wave_max_u32(sv.y), ds = wave_sum_u32(sv.y);   // <= 64 * 195075 fits 32 bits
+    if (lane == 0) {
+      tb.lo[b] = (r0 << 16) | (g0 << 8) | b0;
+      tb.hi[b] = (r1 << 16) | (g1 << 8) | b1;
+      tb.bmax[b] = dm;
+      tb.bsum[b] = ds;
+    }
+  }
+  __syncthreads();
+  unsigned long long psum = 0;
+  for (int sb = tid; sb < nsb; sb += kInitThreads) {
+    unsigned r0 = 255, g0 = 255, b0 = 255, r1 = 0, g1 = 0, b1 = 0, m = 0, sum = 0;
+    for (int b = sb * 16; b < min(sb * 16 + 16, nb); ++b) {
+      const uint32_t l = tb.lo[b], h = tb.hi[b];
+      r0 = min(r0, key_r(l)); g0 = min(g0, key_g(l)); b0 = min(b0, key_b(l));
+      r1 = max(r1, key_r(h)); g1 = max(g1, key_g(h)); b1 = max(b1, key_b(h));
+      m = max(m, tb.bmax[b]);
+      sum += tb.bsum[b];                                // <= 16 * 64 * 195075 < 2^32
+    }
+    tb.sblo[sb] = (r0 << 16) | (g0 << 8) | b0;
+    tb.sbhi[sb] = (r1 << 16) | (g1 << 8) | b1;
+    tb.sbmax[sb] = m;
+    tb.sbsum[sb] = sum;
+    psum += sum;
+  }
+  psum = block_sum<unsigned long long>(psum, sh.red64);
+  if (tid == 0) { cho[0] = P.first; sh.n_touch = 0; sh.pot = psum; sh.n_items = 0; sh.overflow = 0; }
+  if (tid < kTMaxI) sh.delta[tid] = 0;
+  if (tid < T && k > 1) s_u[T + tid] = rand[P.rand_off + tid];         // uniforms of step 1 -> buffer 1
+  __syncthreads();
+  const int persb = (nsb + 63) >> 6;                     // super-blocks per lane in the level-1 search
+#ifdef RHCCQ_STAMPS
+  unsigned long long _acc[8] = {0, 0, 0, 0, 0, 0, 0, 0};
+  unsigned long long _last = clock64();
+#endif
+  for (int c = 1; c < k; ++c) {
+    const double* u = s_u + (c & 1) * T;
+    // the next step's uniforms are a cold line in HBM: fetch them now, park them in LDS at the end of the step
+    double u_next = 0.0;
+    if (tid < T && c + 1 < k) u_next = rand[P.rand_off + (size_t)c * T + tid];
+    const unsigned long long pot = sh.pot;
+    const int n_touched = min(sh.n_touch, kMaxTouch);
+    // ================= phase 1: waves t < T -- pick candidate t, list the blocks it can improve ===========
+    if (wave < T) {
+      const int t = wave;
+      const double r = u[t] * (double)pot;
+      // np.searchsorted(cumsum(closest), r, 'left') through super-block / block / sample sums (all exact)
+      int cand = r <= 0.0 ? 0 : n - 1;
+      uint32_t ck = 0;
+      bool found = false;
+      {
+        unsigned long long loc = 0;
+        const int s0 = lane * persb;
+        for (int i = 0; i < persb; ++i) loc += (s0 + i < nsb) ? tb.sbsum[s0 + i] : 0u;
+        const unsigned long long inc = wave_incscan_u64(loc);
+        const unsigned long long exc = inc - loc;
+        const unsigned long long m1 = __ballot(loc > 0 && (double)exc < r && r <= (double)inc);
+        if (m1) {
+          const int src = __ffsll((long long)m1) - 1;
+          unsigned long long cum = exc;
+          int sb = s0;
+          for (int i = 0; i < persb - 1; ++i) {          // walk inside the owning lane's chunk
+            const unsigned v = (sb < nsb) ? tb.sbsum[sb] : 0u;
+            if ((double)(cum + v) >= r) break;
+            cum += v;
+            ++sb;
           }
-          if (lane == 0) { tb.bmax[bb[q]] = dm; tb.bsum[bb[q]] = ds; }
+          sb = __shfl(sb, src, 64);
+          cum = __shfl(cum, src, 64);
+          // level 2: the 16 blocks of the super-block
+          const int b2 = sb * 16 + (lane & 15);
+          const unsigned long long v2 = (lane < 16 && b2 < nb) ? tb.bsum[b2] : 0u;
+          const unsigned long long inc2 = wave_incscan_u64(v2);
+          const unsigned long long m2 = __ballot(lane < 16 && v2 > 0 && (double)(cum + inc2 - v2) < r && r <= (double)(cum + inc2));
+          if (m2) {
+            const int l2 = __ffsll((long long)m2) - 1;
+            const int b = sb * 16 + l2;
+            const unsigned long long cum2 = cum + __shfl(inc2 - v2, l2, 64);
+            // level 3: the 64 samples of the block
+            const int i = (b << 6) + lane;
+            const uint2 sv = samp[i];
+            const unsigned long long inc3 = wave_incscan_u64(i < n ? sv.y : 0u);
+            const unsigned long long m3 = __ballot(i < n && (double)(cum2 + inc3) >= r);
+            const int l3 = m3 ? __ffsll((long long)m3) - 1 : min(63, n - 1 - (b << 6));
+            cand = (b << 6) + l3;
+            ck = (uint32_t)__shfl((int)sv.x, l3, 64);
+            found = true;
+          }
+        }
+      }
+      if (!found) ck = samp[cand].x;
+      STAMP(0);
+      if (lane == 0) { sh.cand[t] = cand; sh.ckey[t] = ck; }
+      if (s_items) {
+        enumerate_hits(ck, nb, nsb, tb, [&](unsigned long long mb, int b, bool hb) {
+          const int cnt = __popcll(mb);
+          if (cnt == 0) return;
+          int base = 0;
+          if (lane == 0) base = atomicAdd(&sh.n_items, cnt);
+          base = __shfl(base, 0, 64);
+          if (base + cnt > kMaxItems) { if (lane == 0) sh.overflow = 1; return; }
+          if (hb) s_items[base + __popcll(mb & ((1ull << lane) - 1ull))] = ((uint32_t)t << 24) | (uint32_t)b;
+        });
+      }
+      STAMP(1);
+    } else {
+      // idle waves refresh the super-block maxima the previous winner touched (a stale, larger sbmax is
+      // conservative, so the candidate waves may read either value)
+      for (int i = (tid - T * 64); i < n_touched * 16; i += kInitThreads - T * 64) {
+        const int sb = s_touch[i >> 4], b = sb * 16 + (i & 15);
+        unsigned m = b < nb ? tb.bmax[b] : 0u;
+#pragma unroll
+        for (int o = 8; o > 0; o >>= 1) m = max(m, (unsigned)__shfl_xor((int)m, o, 64));
+        if ((i & 15) == 0) tb.sbmax[sb] = m;
+      }
+    }
+    __syncthreads();
+    STAMP(2);
+    const bool use_list = s_items != nullptr && sh.overflow == 0;
+    const int n_items = sh.n_items;
+    // ================= phase 2: potentials ==================================================================
+    if (use_list) {
+      // all waves share the (candidate, block) items evenly; 8 items (8 x 512 B of samples) in flight per wave
+      for (int i0 = wave * 8; i0 < n_items; i0 += kInitWaves * 8) {
+        uint32_t it[8];
+        uint2 sv[8];
+#pragma unroll
+        for (int q = 0; q < 8; ++q) {
+          it[q] = i0 + q < n_items ? s_items[i0 + q] : 0xffffffffu;
+          sv[q] = samp[((it[q] == 0xffffffffu ? 0u : (it[q] & 0xffffffu)) << 6) + lane];
+        }
+#pragma unroll
+        for (int q = 0; q < 8; ++q) {
+          if (it[q] == 0xffffffffu) continue;
+          const int t = it[q] >> 24;
+          const unsigned d = (unsigned)dist2_keys(sh.ckey[t], sv[q].x);
+          const unsigned s = wave_sum_u32(sv[q].y > d ? sv[q].y - d : 0u);
+          if (lane == 0 && s) atomicAdd(&sh.delta[t], (unsigned long long)s);
+        }
+      }
+    } else {
+      for (int t = wave; t < T; t += kInitWaves) {
+        const uint32_t ck = sh.ckey[t];
+        unsigned long long delta = 0;
+        enumerate_hits(ck, nb, nsb, tb, [&](unsigned long long mb, int b, bool hb) {
+          while (mb) {
+            const int p = __ffsll((long long)mb) - 1;
+            mb &= mb - 1;
+            const int bb = __shfl(b, p, 64);
+            const uint2 sv = samp[(bb << 6) + lane];
+            const unsigned d = (unsigned)dist2_keys(ck, sv.x);
+            delta += sv.y > d ? sv.y - d : 0u;
+          }
+        });
+        delta = wave_sum(delta);
+        if (lane == 0) sh.delta[t] = delta;
+      }
+    }
+    __syncthreads();
+    STAMP(3);
+    // ================= phase 3: greedy choice + commit ======================================================
+    int best = 0;
+    unsigned long long bd = sh.delta[0];                 // largest reduction == smallest potential; first wins ties
+    for (int t = 1; t < T; ++t)
+      if (sh.delta[t] > bd) { bd = sh.delta[t]; best = t; }
+    const uint32_t kb = sh.ckey[best];
+    if (tid == 0) sh.n_touch = 0;
+    __syncthreads();
+    if (use_list) {
+      for (int i = wave; i < n_items; i += kInitWaves) {
+        const uint32_t it = s_items[i];
+        if ((int)(it >> 24) == best) commit_block((int)(it & 0xffffffu), kb, samp, tb, s_touch, &sh.n_touch, kMaxTouch);
+      }
+    } else {
+      // wave w owns super-blocks sb = w (mod 16)
+      for (int base = 0; base * kInitWaves + wave < nsb; base += 64) {
+        const int sb = (base + lane) * kInitWaves + wave;
+        const bool hsb = sb < nsb && (unsigned)box_dist2(kb, tb.sblo[sb], tb.sbhi[sb]) < tb.sbmax[sb];
+        unsigned long long msb = __ballot(hsb);
+        while (msb) {
+          const int s = (base + __ffsll((long long)msb) - 1) * kInitWaves + wave;
+          msb &= msb - 1;
+          const int b = s * 16 + (lane & 15);
+          const bool hb = lane < 16 && b < nb && (unsigned)box_dist2(kb, tb.lo[b], tb.hi[b]) < tb.bmax[b];
+          unsigned long long mb = __ballot(hb);
+          while (mb) {
+            const int p = __ffsll((long long)mb) - 1;
+            mb &= mb - 1;
+            commit_block(s * 16 + p, kb, samp, tb, s_touch, &sh.n_touch, kMaxTouch);
+          }
         }
       }
     }
+    if (tid == 0) { cho[c] = sh.cand[best]; sh.pot = pot - bd; sh.n_items = 0; sh.overflow = 0; }
+    if (tid < T) { s_u[((c + 1) & 1) * T + tid] = u_next; sh.delta[tid] = 0; }
+    __syncthreads();
+    STAMP(4);
+    // more touched super-blocks than the list holds (only in the first steps): refresh all of them
+    if (sh.n_touch > kMaxTouch) {
+      for (int sb = tid; sb < nsb; sb += kInitThreads) {
+        unsigned m = 0;
+        for (int b = sb * 16; b < min(sb * 16 + 16, nb); ++b) m = max(m, tb.bmax[b]);
+        tb.sbmax[sb] = m;
+      }
+      if (tid == 0) sh.n_touch = 0;
+      __syncthreads();
+    }
   }
-  return delta;
+#ifdef RHCCQ_STAMPS
+  if (tid == 0 && blockIdx.x == gridDim.x - 1)
+    for (int i = 0; i < 8; ++i) g_init_stamps[i] += _acc[i];
+#endif
+  for (int j = tid; j < k; j += kInitThreads) {
+    const uint32_t kk = samp[cho[j]].x;
+    const double c0 = (double)key_r(kk), c1 = (double)key_g(kk), c2 = (double)key_b(kk);
+    double* C = centres + (P.koff + j) * 4;
+    C[0] = c0; C[1] = c1; C[2] = c2; C[3] = (c0 * c0 + c1 * c1) + c2 * c2;
+  }
 }
 
 __global__ __launch_bounds__(kInitThreads) void mbk_init_kernel(const uint32_t* __restrict__ keys, const MbkP* __restrict__ probs,
@@ -144,121 +444,24 @@ __global__ __launch_bounds__(kInitThreads) void mbk_init_kernel(const uint32_t* 
                                                                 double* __restrict__ centres, int32_t* __restrict__ chosen,
                                                                 uint32_t* scratch, const long long* __restrict__ scratch_off) {
   __shared__ InitShared sh;
-  __shared__ uint32_t s_tab[4 * kInitLdsBlocks];
-  __shared__ int s_cblock[kTMaxI];
-  __shared__ unsigned long long s_cbase[kTMaxI];
+  __shared__ uint32_t s_tab[4 * kInitLdsBlocks + 4 * kInitLdsSuper];
+  __shared__ uint32_t s_items[kMaxItems];
+  __shared__ double s_u[2 * kTMaxI];
+  __shared__ int s_touch[kMaxTouch];
   const MbkP P = probs[blockIdx.x];
-  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
-  const int n = (int)P.init_n, k = (int)P.k, T = P.T;
-  const int nb = (n + 63) >> 6, np = nb << 6;
-  uint32_t* skey = scratch + scratch_off[blockIdx.x];
-  uint32_t* closest = skey + np;
+  const int nb = ((int)P.init_n + 63) >> 6, np = nb << 6, nsb = (nb + 15) >> 4;
+  uint2* samp = reinterpret_cast<uint2*>(scratch + scratch_off[blockIdx.x]);
   InitTables tb;
   if (nb <= kInitLdsBlocks) {
     tb.lo = s_tab; tb.hi = s_tab + kInitLdsBlocks; tb.bmax = s_tab + 2 * kInitLdsBlocks; tb.bsum = s_tab + 3 * kInitLdsBlocks;
+    tb.sblo = s_tab + 4 * kInitLdsBlocks; tb.sbhi = tb.sblo + kInitLdsSuper; tb.sbmax = tb.sbhi + kInitLdsSuper;
+    tb.sbsum = tb.sbmax + kInitLdsSuper;
+    init_body(keys, P, init_idx, rand, centres, chosen + P.koff, samp, tb, sh, s_u, s_touch, s_items);
   } else {
-    tb.lo = closest + np; tb.hi = tb.lo + nb; tb.bmax = tb.hi + nb; tb.bsum = tb.bmax + nb;
-  }
-  int32_t* cho = chosen + P.koff;
-  // ---- gather the sample, boxes ------------------------------------------------------------------
-  for (int i = tid; i < np; i += kInitThreads) {
-    const int src = i < n ? i : n - 1;                  // padding repeats the last sample
-    skey[i] = keys[P.off + init_idx[P.init_off + src]];
-  }
-  __syncthreads();
-  const uint32_t kf = skey[P.first];
-  for (int b = wave; b < nb; b += kInitWaves) {
-    const int i = (b << 6) + lane;
-    const uint32_t kk = skey[i];
-    unsigned r0 = key_r(kk), r1 = r0, g0 = key_g(kk), g1 = g0, b0 = key_b(kk), b1 = b0;
-    unsigned d = i < n ? (unsigned)dist2_keys(kk, kf) : 0u;
-    closest[i] = d;
-    unsigned dm = d, ds = d;
-#pragma unroll
-    for (int o = 32; o > 0; o >>= 1) {
-      r0 = min(r0, (unsigned)__shfl_down(r0, o, 64)); r1 = max(r1, (unsigned)__shfl_down(r1, o, 64));
-      g0 = min(g0, (unsigned)__shfl_down(g0, o, 64)); g1 = max(g1, (unsigned)__shfl_down(g1, o, 64));
-      b0 = min(b0, (unsigned)__shfl_down(b0, o, 64)); b1 = max(b1, (unsigned)__shfl_down(b1, o, 64));
-      dm = max(dm, (unsigned)__shfl_down(dm, o, 64));
-      ds += __shfl_down(ds, o, 64);
-    }
-    if (lane == 0) {
-      tb.lo[b] = (r0 << 16) | (g0 << 8) | b0;
-      tb.hi[b] = (r1 << 16) | (g1 << 8) | b1;
-      tb.bmax[b] = dm;
-      tb.bsum[b] = ds;                                  // <= 64 * 195075 fits 32 bits
-    }
-  }
-  if (tid == 0) cho[0] = P.first;
-  __syncthreads();
-  const int perb = (nb + kInitThreads - 1) / kInitThreads;
-  const int blo = min(tid * perb, nb), bhi = min(blo + perb, nb);
-  for (int c = 1; c < k; ++c) {
-    // ---- locate the block of each of the T thresholds u * pot in the cumulative sum ---------------
-    unsigned long long loc = 0;
-    for (int b = blo; b < bhi; ++b) loc += tb.bsum[b];
-    unsigned long long pot;
-    const unsigned long long base = init_exscan64(loc, sh, &pot);
-    const double dpot = (double)pot;
-    const double* u = rand + P.rand_off + (size_t)(c - 1) * T;
-    if (tid < T) s_cblock[tid] = -1;
-    __syncthreads();
-    if (loc > 0) {
-      for (int t = 0; t < T; ++t) {
-        const double r = u[t] * dpot;
-        if ((double)base < r && r <= (double)(base + loc)) {
-          unsigned long long cum = base;
-          int b = blo;
-          for (; b < bhi - 1; ++b) {
-            if ((double)(cum + tb.bsum[b]) >= r) break;
-            cum += tb.bsum[b];
-          }
-          s_cblock[t] = b;
-          s_cbase[t] = cum;
-        }
-      }
-    }
-    __syncthreads();
-    // ---- one wave per candidate: in-block search (np.searchsorted 'left'), then its potential ------
-    for (int t = wave; t < T; t += kInitWaves) {
-      const double r = u[t] * dpot;
-      const int b = s_cblock[t];
-      int cand;
-      if (b < 0) {
-        cand = r <= 0.0 ? 0 : n - 1;
-      } else {
-        const int i = (b << 6) + lane;
-        unsigned long long inc = i < n ? closest[i] : 0u;
-#pragma unroll
-        for (int o = 1; o < 64; o <<= 1) {
-          const unsigned long long tv = __shfl_up(inc, o, 64);
-          if (lane >= o) inc += tv;
-        }
-        const unsigned long long m = __ballot(i < n && (double)(s_cbase[t] + inc) >= r);
-        cand = m ? (b << 6) + __ffsll((long long)m) - 1 : min((b << 6) + 63, n - 1);
-      }
-      const uint32_t ck = skey[cand];
-      unsigned long long delta = visit_blocks<false>(ck, nb, 0, 64, skey, closest, tb);
-      delta = wave_sum(delta);
-      if (lane == 0) { sh.pots[t] = pot - delta; sh.cand[t] = cand; }
-    }
-    __syncthreads();
-    int best = 0;
-    unsigned long long bp = sh.pots[0];
-    for (int t = 1; t < T; ++t)
-      if (sh.pots[t] < bp) { bp = sh.pots[t]; best = t; }
-    const int bi = sh.cand[best];
-    // ---- commit the winner (all waves, disjoint block ranges) ------------------------------------------
-    visit_blocks<true>(skey[bi], nb, wave * 64, kInitWaves * 64, skey, closest, tb);
-    if (tid == 0) cho[c] = bi;
-    __syncthreads();
-  }
-  __syncthreads();
-  for (int j = tid; j < k; j += kInitThreads) {
-    const uint32_t kk = skey[cho[j]];
-    const double c0 = (double)key_r(kk), c1 = (double)key_g(kk), c2 = (double)key_b(kk);
-    double* C = centres + (P.koff + j) * 4;
-    C[0] = c0; C[1] = c1; C[2] = c2; C[3] = (c0 * c0 + c1 * c1) + c2 * c2;
+    uint32_t* g = reinterpret_cast<uint32_t*>(samp + np);
+    tb.lo = g; tb.hi = g + nb; tb.bmax = g + 2 * nb; tb.bsum = g + 3 * nb;
+    tb.sblo = g + 4 * nb; tb.sbhi = tb.sblo + nsb; tb.sbmax = tb.sbhi + nsb; tb.sbsum = tb.sbmax + nsb;
+    init_body(keys, P, init_idx, rand, centres, chosen + P.koff, samp, tb, sh, s_u, s_touch, nullptr);
   }
 }
 
@@ -698,6 +901,14 @@ static int layout_work(rhccq_ctx* ctx, const rhccq_mbk_problem* probs, int n_pro
   return 0;
 }
 
+#ifdef RHCCQ_STAMPS
+int rhccq_debug_stamps(unsigned long long* out16_host) {
+  if (hipDeviceSynchronize() != hipSuccess) return -2;
+  if (hipMemcpyFromSymbol(out16_host, HIP_SYMBOL(g_init_stamps), sizeof(unsigned long long) * 16) != hipSuccess) return -2;
+  return 0;
+}
+#endif
+
 int rhccq_mbk_init(rhccq_ctx* ctx, const uint32_t* keys, const rhccq_mbk_problem* probs, int32_t n_prob, const int32_t* init_idx,
                    const double* rand, double* centres, int32_t* chosen) {
   if (!ctx || !keys || !probs || !init_idx || !rand || !centres || !chosen || n_prob <= 0)
@@ -716,7 +927,7 @@ int rhccq_mbk_init(rhccq_ctx* ctx, const uint32_t* keys, const rhccq_mbk_problem
     hp[i] = MbkP{q.off, q.n, q.k, q.koff, q.init_off, q.init_n, q.rand_off, q.first, q.T};
     ho[i] = (long long)words;
     const size_t nb = (size_t)((q.init_n + 63) / 64);
-    words += 2 * nb * 64 + 4 * nb;
+    words += 2 * nb * 64 + 4 * nb + 4 * ((nb + 15) / 16) + 8;
     words = (words + 63) & ~(size_t)63;
   }
   const size_t head = align256(sizeof(MbkP) * n_prob) + align256(8 * (size_t)n_prob);
