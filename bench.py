@@ -56,32 +56,27 @@ def one_step(rh, enc, rgb, specs, roi_mask, block, stage_acc=None):
     return out, q
 
 
-def kernel_event_time(rh, fn, iters=5):
-    """average duration of fn() measured with HIP events on the stream the kernels run on."""
+def roofline_probe(rh, rgb, specs, iters=5):
+    """Live HIP-event timing (events recorded on the stream the kernel is launched on) of the heaviest
+    HBM-streaming kernel of the path, job_scan_kernel (K0 + K1a: one read of RGB + every class label map,
+    colour-bit set).  Every timed launch starts from cleared bitmaps / stats, as in a real frame."""
     import torch
-    fn()
-    torch.cuda.synchronize()
-    ev0, ev1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
-    ev0.record(rh.stream)
-    for _ in range(iters):
-        fn()
-    ev1.record(rh.stream)
-    torch.cuda.synchronize()
-    return ev0.elapsed_time(ev1) / iters * 1e-3
-
-
-def roofline_probe(rh, rgb, specs):
-    """Live HIP-event timing of the dominant HBM-streaming kernel of the path (job_scan_kernel: one
-    read of RGB + both label maps, K0 + K1a) and of the palette-space neighbour pass (K3/K4)."""
     H, W = int(rgb.shape[0]), int(rgb.shape[1])
     labels = [c.labels for c in specs]
     job_base = np.concatenate([[0], np.cumsum([c.n_seg for c in specs])])[:-1]
     n_jobs = sum(c.n_seg for c in specs)
-    bitmaps, stats = rh.new_job_state(n_jobs)
-
-    def scan():
+    total = 0.0
+    for it in range(iters + 1):
+        bitmaps, stats = rh.new_job_state(n_jobs)
+        torch.cuda.synchronize()
+        ev0, ev1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+        ev0.record(rh.stream)
         rh.job_scan(rgb, labels, job_base, bitmaps, stats, black_is_colour=False)
-    t = kernel_event_time(rh, scan)
+        ev1.record(rh.stream)
+        torch.cuda.synchronize()
+        if it > 0:                                  # first launch = warm-up
+            total += ev0.elapsed_time(ev1) * 1e-3
+    t = total / iters
     px = H * W
     algo_bytes = px * (3 + 4 * len(specs))          # RGB + one int32 label per class, read once
     return {"bound": "hbm", "kernel": "job_scan_kernel", "achieved": algo_bytes / t / 1e9, "peak": HBM_PEAK_GBS,

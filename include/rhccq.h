@@ -62,6 +62,13 @@ int rhccq_job_scan(rhccq_ctx* ctx, const uint8_t* rgb, int32_t H, int32_t W, int
                    const int32_t* const* labels_host /* host array of device ptrs */,
                    const int32_t* job_base_host, int32_t black_is_colour, uint32_t* bitmaps,
                    int32_t* stats);
+/* Same pass with BYTE colour flags (bytemaps: uint8[n_jobs][2^24], zero-initialised): plain idempotent
+ * stores instead of scattered device-scope atomics (which run at the memory side on MI355X).
+ * rhccq_bytemap_pack then ORs the flags into the 2 MiB bitmaps (32 bytes -> one word). */
+int rhccq_job_scan_bytes(rhccq_ctx* ctx, const uint8_t* rgb, int32_t H, int32_t W, int32_t n_class,
+                         const int32_t* const* labels_host, const int32_t* job_base_host,
+                         int32_t black_is_colour, uint8_t* bytemaps, int32_t* stats);
+int rhccq_bytemap_pack(rhccq_ctx* ctx, const uint8_t* bytemaps, int32_t n_jobs, uint32_t* bitmaps);
 /* set bit 0 (black) of the bitmaps of the jobs listed (device int32 list) */
 int rhccq_job_set_black(rhccq_ctx* ctx, uint32_t* bitmaps, const int32_t* jobs, int32_t n_jobs);
 /* popcount of every job's bitmap -> counts[n_jobs] (device) and chunk sums workspace
@@ -81,11 +88,12 @@ int rhccq_job_blackfix(rhccq_ctx* ctx, const uint8_t* rgb, int32_t H, int32_t W,
 /* per-pixel palette index (rank of the pixel's colour in its job's palette) and/or first raster
  * position of every palette entry.  fix_key[job] (device, may be NULL) = key that replaces in-mask
  * black pixels (0 = no fix).  idx_out (int32[n_class][H*W], may be NULL): -1 where the pixel has no
- * job.  first_pos (int32 at pal_off[job]+rank, may be NULL) must be initialised to INT_MAX. */
+ * job.  first_pos (may be NULL) must be initialised to INT_MAX; entry = pal_off[job]+rank, or
+ * fp_lut[pal_off[job]+rank] when fp_lut != NULL (first positions of a clustered, smaller palette). */
 int rhccq_job_index(rhccq_ctx* ctx, const uint8_t* rgb, int32_t H, int32_t W, int32_t n_class,
                     const int32_t* const* labels_host, const int32_t* job_base_host,
                     const uint32_t* bitmaps, const uint32_t* word_prefix, const int64_t* pal_off,
-                    const uint32_t* fix_key, int32_t* idx_out, int32_t* first_pos);
+                    const uint32_t* fix_key, int32_t* idx_out, int32_t* first_pos, const int32_t* fp_lut);
 
 /* ---- K3/K4: DBSCAN(min_samples=1) labels = eps-graph components (clustering.py:233-235) -------
  * problems p = 0..n_prob-1: keys[off[p] .. off[p]+n[p]); labels in sklearn order (rank of the
@@ -127,8 +135,9 @@ int rhccq_mbk_init(rhccq_ctx* ctx, const uint32_t* keys, const rhccq_mbk_problem
                    int32_t n_prob, const int32_t* init_idx, const double* rand, double* centres,
                    int32_t* chosen);
 /* run up to n_steps mini-batch steps starting at step index step0 for every problem that has not
- * converged; state: double[n_prob][8] = {ewa, ewa_min, no_improvement, since_reassign, done,
- * steps_done, have_ewa, reserved}; weights double[sum k]; seed = 42 stream of counter_hash() */
+ * converged; state: double[n_prob][16] = {ewa, ewa_min, no_improvement, since_reassign, done,
+ * steps_done, have_ewa, have_min, n_zero_weight_centres (initialise to k), reserved...}; weights
+ * double[sum k]; seed = 42 stream of counter_hash() */
 int rhccq_mbk_steps(rhccq_ctx* ctx, const uint32_t* keys, const rhccq_mbk_problem* probs_host,
                     int32_t n_prob, int64_t step0, int32_t n_steps, uint64_t seed, double* centres,
                     double* weights, double* state, void* work, int64_t work_bytes);

@@ -33,13 +33,16 @@ PROTOTYPES = {
     "rhccq_eps_threshold": (c_int32, [c_double, C.POINTER(c_int32), C.POINTER(c_int32), C.POINTER(c_double)]),
     "rhccq_job_scan": (c_int32, [c_void_p, c_void_p, c_int32, c_int32, c_int32, C.POINTER(c_void_p), C.POINTER(c_int32),
                                  c_int32, c_void_p, c_void_p]),
+    "rhccq_job_scan_bytes": (c_int32, [c_void_p, c_void_p, c_int32, c_int32, c_int32, C.POINTER(c_void_p), C.POINTER(c_int32),
+                                       c_int32, c_void_p, c_void_p]),
+    "rhccq_bytemap_pack": (c_int32, [c_void_p, c_void_p, c_int32, c_void_p]),
     "rhccq_job_set_black": (c_int32, [c_void_p, c_void_p, c_void_p, c_int32]),
     "rhccq_bitmap_count": (c_int32, [c_void_p, c_void_p, c_int32, c_void_p, c_void_p]),
     "rhccq_bitmap_emit": (c_int32, [c_void_p, c_void_p, c_int32, c_void_p, c_void_p, c_void_p, c_void_p]),
     "rhccq_job_blackfix": (c_int32, [c_void_p, c_void_p, c_int32, c_int32, c_int32, C.POINTER(c_void_p), C.POINTER(c_int32),
                                      c_void_p, c_void_p]),
     "rhccq_job_index": (c_int32, [c_void_p, c_void_p, c_int32, c_int32, c_int32, C.POINTER(c_void_p), C.POINTER(c_int32),
-                                  c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p]),
+                                  c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p]),
     "rhccq_eps_components": (c_int32, [c_void_p, c_void_p, c_void_p, c_void_p, c_int32, c_int32, c_void_p, c_void_p]),
     "rhccq_cluster_sums": (c_int32, [c_void_p, c_void_p, c_void_p, c_int64, c_void_p]),
     "rhccq_cluster_means": (c_int32, [c_void_p, c_void_p, c_int64, c_void_p]),

@@ -32,33 +32,41 @@ struct StatTable {
   unsigned cnt[kStatSlots], nblack[kStatSlots];
 };
 
-__device__ __forceinline__ void stat_add(StatTable& t, int32_t* gstats, int job, int r, int c, bool black) {
-  unsigned h = ((unsigned)job * 2654435761u) >> 26;  // 6 bits
+// a thread's running statistics of the job it is currently inside (per class); flushed to the block's
+// LDS table only when the job changes -- with large segments that is once or twice per thread
+struct RunStat {
+  int job, minr, maxr, minc, maxc;
+  unsigned cnt, nblack;
+};
+
+__device__ __forceinline__ void stat_flush(StatTable& t, int32_t* gstats, const RunStat& rs) {
+  if (rs.job < 0) return;
+  unsigned h = ((unsigned)rs.job * 2654435761u) >> 26;  // 6 bits
   for (int probe = 0; probe < kStatSlots; ++probe) {
     int s = (h + probe) & (kStatSlots - 1);
     int cur = t.job[s];
     if (cur == -1) {
-      int old = atomicCAS(&t.job[s], -1, job);
-      cur = (old == -1) ? job : old;
+      int old = atomicCAS(&t.job[s], -1, rs.job);
+      cur = (old == -1) ? rs.job : old;
     }
-    if (cur == job) {
-      atomicMin(&t.minr[s], r);
-      atomicMax(&t.maxr[s], r);
-      atomicMin(&t.minc[s], c);
-      atomicMax(&t.maxc[s], c);
-      atomicAdd(&t.cnt[s], 1u);
-      if (black) atomicAdd(&t.nblack[s], 1u);
+    if (cur == rs.job) {
+      atomicMin(&t.minr[s], rs.minr);
+      atomicMax(&t.maxr[s], rs.maxr);
+      atomicMin(&t.minc[s], rs.minc);
+      atomicMax(&t.maxc[s], rs.maxc);
+      atomicAdd(&t.cnt[s], rs.cnt);
+      if (rs.nblack) atomicAdd(&t.nblack[s], rs.nblack);
       return;
     }
   }
   // table full: straight to global memory
-  int32_t* g = gstats + (size_t)job * 6;
-  atomicMin(&g[0], r);
-  atomicMax(&g[1], r);
-  atomicMin(&g[2], c);
-  atomicMax(&g[3], c);
-  atomicAdd((unsigned*)&g[4], 1u);
-  if (black) atomicAdd((unsigned*)&g[5], 1u);
+  int32_t* g = gstats + (size_t)rs.job * 6;
+  atomicMin(&g[0], rs.minr);
+  atomicMax(&g[1], rs.maxr);
+  atomicMin(&g[2], rs.minc);
+  atomicMax(&g[3], rs.maxc);
+  atomicAdd((unsigned*)&g[4], rs.cnt);
+  if (rs.nblack) atomicAdd((unsigned*)&g[5], rs.nblack);
 }
 
 __device__ __forceinline__ void load4px(const uint8_t* rgb, int64_t p0, int64_t n_px, uint32_t key[4]) {
@@ -90,8 +98,13 @@ __device__ __forceinline__ void load4lab(const int32_t* lab, int64_t p0, int64_t
   }
 }
 
+// kBytes = true: colour flags are BYTES (one per colour, 16 MiB per job) written with plain stores --
+// idempotent, so no atomics are needed and the per-XCD L2s merge them by byte mask; bytemap_pack_kernel
+// then folds them into the 2 MiB bitmaps.  kBytes = false: bits set with test-before-atomicOr (scattered
+// device-scope atomics execute at the memory side on MI355X: use only when 16 MiB per job is too much).
+template <bool kBytes>
 __global__ __launch_bounds__(256) void job_scan_kernel(const uint8_t* __restrict__ rgb, int H, int W, ClassArgs ca,
-                                                       int black_is_colour, uint32_t* bitmaps,
+                                                       int black_is_colour, uint32_t* bitmaps, uint8_t* bytemaps,
                                                        int32_t* stats) {
   __shared__ StatTable tab;
   for (int i = threadIdx.x; i < kStatSlots; i += blockDim.x) {
@@ -106,28 +119,47 @@ __global__ __launch_bounds__(256) void job_scan_kernel(const uint8_t* __restrict
   const int64_t per_block = (n_quads + gridDim.x - 1) / gridDim.x;
   const int64_t q_begin = (int64_t)blockIdx.x * per_block;
   const int64_t q_end = min(q_begin + per_block, n_quads);
+  RunStat rs[kMaxClass];
+#pragma unroll
+  for (int c = 0; c < kMaxClass; ++c) rs[c].job = -1;
   for (int64_t q = q_begin + threadIdx.x; q < q_end; q += blockDim.x) {
     const int64_t p0 = q << 2;
     uint32_t key[4];
     load4px(rgb, p0, n_px, key);
-    for (int c = 0; c < ca.n_class; ++c) {
+    const int r0 = (int)(p0 / W), c0 = (int)(p0 - (int64_t)r0 * W);
+#pragma unroll
+    for (int c = 0; c < kMaxClass; ++c) {
+      if (c >= ca.n_class) break;
       int32_t lab[4];
       load4lab(ca.labels[c], p0, n_px, lab);
 #pragma unroll
       for (int i = 0; i < 4; ++i) {
         if (lab[i] <= 0 || p0 + i >= n_px) continue;
         const int job = ca.job_base[c] + lab[i] - 1;
-        const int r = (int)((p0 + i) / W), col = (int)((p0 + i) % W);
+        int r = r0, col = c0 + i;
+        while (col >= W) { col -= W; ++r; }                // a quad spans at most two rows when W >= 4
         const bool black = key[i] == 0u;
-        stat_add(tab, stats, job, r, col, black);
+        if (job != rs[c].job) {
+          stat_flush(tab, stats, rs[c]);
+          rs[c].job = job; rs[c].minr = r; rs[c].maxr = r; rs[c].minc = col; rs[c].maxc = col; rs[c].cnt = 0; rs[c].nblack = 0;
+        }
+        rs[c].minr = min(rs[c].minr, r); rs[c].maxr = max(rs[c].maxr, r);
+        rs[c].minc = min(rs[c].minc, col); rs[c].maxc = max(rs[c].maxc, col);
+        rs[c].cnt += 1; rs[c].nblack += black;
         if (!black || black_is_colour) {
-          uint32_t* wptr = bitmaps + (size_t)job * RHCCQ_BITMAP_WORDS + (key[i] >> 5);
-          const uint32_t bit = 1u << (key[i] & 31u);
-          if ((*wptr & bit) == 0u) atomicOr(wptr, bit);   // bits are only ever set: a stale read costs one redundant atomic
+          if (kBytes) {
+            bytemaps[((size_t)job << 24) + key[i]] = 1;
+          } else {
+            uint32_t* wptr = bitmaps + (size_t)job * RHCCQ_BITMAP_WORDS + (key[i] >> 5);
+            const uint32_t bit = 1u << (key[i] & 31u);
+            if ((*wptr & bit) == 0u) atomicOr(wptr, bit);   // bits are only ever set: a stale read costs one redundant atomic
+          }
         }
       }
     }
   }
+#pragma unroll
+  for (int c = 0; c < kMaxClass; ++c) stat_flush(tab, stats, rs[c]);
   __syncthreads();
   for (int s = threadIdx.x; s < kStatSlots; s += blockDim.x) {
     if (tab.job[s] >= 0) {
@@ -139,6 +171,22 @@ __global__ __launch_bounds__(256) void job_scan_kernel(const uint8_t* __restrict
       atomicAdd((unsigned*)&g[4], tab.cnt[s]);
       if (tab.nblack[s]) atomicAdd((unsigned*)&g[5], tab.nblack[s]);
     }
+  }
+}
+
+// 32 colour bytes -> one bitmap word (ORed into the bitmap so that job_set_black / earlier tiles survive)
+__global__ __launch_bounds__(256) void bytemap_pack_kernel(const uint8_t* __restrict__ bytemaps, uint32_t* __restrict__ bitmaps, size_t n_words) {
+  for (size_t w = (size_t)blockIdx.x * blockDim.x + threadIdx.x; w < n_words; w += (size_t)gridDim.x * blockDim.x) {
+    const uint4 a = reinterpret_cast<const uint4*>(bytemaps)[w * 2], b = reinterpret_cast<const uint4*>(bytemaps)[w * 2 + 1];
+    const uint32_t v[8] = {a.x, a.y, a.z, a.w, b.x, b.y, b.z, b.w};
+    uint32_t word = 0;
+#pragma unroll
+    for (int i = 0; i < 8; ++i) {
+      // bytes are 0 or 1: gather bit 0 of each of the 4 bytes into 4 adjacent bits
+      const uint32_t x = v[i];
+      word |= ((x & 1u) | ((x >> 7) & 2u) | ((x >> 14) & 4u) | ((x >> 21) & 8u)) << (4 * i);
+    }
+    if (word) bitmaps[w] |= word;
   }
 }
 
@@ -238,7 +286,8 @@ __device__ __forceinline__ uint32_t rank_of(const uint32_t* __restrict__ bitmaps
 __global__ __launch_bounds__(256) void job_index_kernel(const uint8_t* __restrict__ rgb, int H, int W, ClassArgs ca,
                                                         const uint32_t* __restrict__ bitmaps, const uint32_t* __restrict__ word_prefix,
                                                         const int64_t* __restrict__ pal_off, const uint32_t* __restrict__ fix_key,
-                                                        int32_t* __restrict__ idx_out, int32_t* __restrict__ first_pos) {
+                                                        int32_t* __restrict__ idx_out, int32_t* first_pos,
+                                                        const int32_t* __restrict__ fp_lut) {
   const int64_t n_px = (int64_t)H * W;
   const int64_t n_quads = (n_px + 3) >> 2;
   for (int64_t q = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; q < n_quads; q += (int64_t)gridDim.x * blockDim.x) {
@@ -259,7 +308,10 @@ __global__ __launch_bounds__(256) void job_index_kernel(const uint8_t* __restric
         const uint32_t rk = rank_of(bitmaps, word_prefix, job, k);
         res[i] = (int32_t)rk;
         if (first_pos) {
-          int32_t* fp = first_pos + pal_off[job] + rk;
+          // fp_lut (optional) maps (job, rank) to an entry of a smaller table, e.g. the level-1 clustered
+          // palette: the table then stays cache resident and almost every pixel stops at the plain compare
+          const int64_t e = pal_off[job] + rk;
+          int32_t* fp = first_pos + (fp_lut ? (int64_t)fp_lut[e] : e);
           const int32_t p = (int32_t)(p0 + i);
           if (p < *fp) atomicMin(fp, p);
         }
@@ -372,7 +424,32 @@ int rhccq_job_scan(rhccq_ctx* ctx, const uint8_t* rgb, int32_t H, int32_t W, int
   if (g64 > 2048) g64 = 2048;
   if (g64 < 1) g64 = 1;
   const int grid = (int)g64;
-  hipLaunchKernelGGL(job_scan_kernel, dim3(grid), dim3(256), 0, ctx->stream, rgb, H, W, ca, black_is_colour, bitmaps, stats);
+  hipLaunchKernelGGL(job_scan_kernel<false>, dim3(grid), dim3(256), 0, ctx->stream, rgb, H, W, ca, black_is_colour, bitmaps, (uint8_t*)nullptr, stats);
+  RHCCQ_LAUNCH_CHECK(ctx);
+  return 0;
+}
+
+int rhccq_job_scan_bytes(rhccq_ctx* ctx, const uint8_t* rgb, int32_t H, int32_t W, int32_t n_class,
+                         const int32_t* const* labels_host, const int32_t* job_base_host, int32_t black_is_colour,
+                         uint8_t* bytemaps, int32_t* stats) {
+  if (!ctx || !rgb || !bytemaps || !stats || H <= 0 || W <= 0) return rhccq_fail(ctx, RHCCQ_E_ARG, "job_scan_bytes: bad argument");
+  if (((uintptr_t)rgb & 3u) != 0) return rhccq_fail(ctx, RHCCQ_E_ARG, "job_scan_bytes: rgb must be 4-byte aligned");
+  ClassArgs ca;
+  if (int e = make_class_args(ctx, n_class, labels_host, job_base_host, &ca)) return e;
+  const int64_t quads = ((int64_t)H * W + 3) / 4;
+  int64_t g64 = (quads + 1023) / 1024;
+  if (g64 > 2048) g64 = 2048;
+  if (g64 < 1) g64 = 1;
+  hipLaunchKernelGGL(job_scan_kernel<true>, dim3((int)g64), dim3(256), 0, ctx->stream, rgb, H, W, ca, black_is_colour, (uint32_t*)nullptr, bytemaps, stats);
+  RHCCQ_LAUNCH_CHECK(ctx);
+  return 0;
+}
+
+int rhccq_bytemap_pack(rhccq_ctx* ctx, const uint8_t* bytemaps, int32_t n_jobs, uint32_t* bitmaps) {
+  if (!ctx || !bytemaps || !bitmaps || n_jobs <= 0) return rhccq_fail(ctx, RHCCQ_E_ARG, "bytemap_pack: bad argument");
+  if (((uintptr_t)bytemaps & 15u) != 0) return rhccq_fail(ctx, RHCCQ_E_ARG, "bytemap_pack: bytemaps must be 16-byte aligned");
+  const size_t n_words = (size_t)n_jobs * RHCCQ_BITMAP_WORDS;
+  hipLaunchKernelGGL(bytemap_pack_kernel, dim3(2048), dim3(256), 0, ctx->stream, bytemaps, bitmaps, n_words);
   RHCCQ_LAUNCH_CHECK(ctx);
   return 0;
 }
@@ -419,14 +496,14 @@ int rhccq_job_blackfix(rhccq_ctx* ctx, const uint8_t* rgb, int32_t H, int32_t W,
 int rhccq_job_index(rhccq_ctx* ctx, const uint8_t* rgb, int32_t H, int32_t W, int32_t n_class,
                     const int32_t* const* labels_host, const int32_t* job_base_host, const uint32_t* bitmaps,
                     const uint32_t* word_prefix, const int64_t* pal_off, const uint32_t* fix_key, int32_t* idx_out,
-                    int32_t* first_pos) {
+                    int32_t* first_pos, const int32_t* fp_lut) {
   if (!ctx || !rgb || !bitmaps || !word_prefix || !pal_off || H <= 0 || W <= 0 || (int64_t)H * W > INT32_MAX)
     return rhccq_fail(ctx, RHCCQ_E_ARG, "job_index: bad argument");
   ClassArgs ca;
   if (int e = make_class_args(ctx, n_class, labels_host, job_base_host, &ca)) return e;
   const int64_t quads = ((int64_t)H * W + 3) / 4;
   hipLaunchKernelGGL(job_index_kernel, dim3(stream_grid(quads, 256)), dim3(256), 0, ctx->stream, rgb, H, W, ca, bitmaps, word_prefix,
-                     pal_off, fix_key, idx_out, first_pos);
+                     pal_off, fix_key, idx_out, first_pos, fp_lut);
   RHCCQ_LAUNCH_CHECK(ctx);
   return 0;
 }

@@ -469,18 +469,19 @@ __global__ __launch_bounds__(kInitThreads) void mbk_init_kernel(const uint32_t* 
 // mini-batch steps
 // ------------------------------------------------------------------------------------------------
 constexpr int kBatch = 1024;        // padded batch (sklearn batch_size = 1000)
-constexpr int kTileC = 64;          // centres per workgroup in the batch E-step
+constexpr int kTileC = 512;         // centres per workgroup in the batch E-step (16 KB of LDS)
+constexpr int kPtChunks = kBatch / 256;   // a workgroup takes 256 of the batch points
 
-// state[p][8] = {ewa, ewa_min, no_improvement, since_reassign, done, steps_done, have_ewa, have_min}
+// state[p][16] = {ewa, ewa_min, no_improvement, since_reassign, done, steps_done, have_ewa, have_min, n_zero_weight, ...}
 __global__ __launch_bounds__(256) void mbk_batch_estep_kernel(const uint32_t* __restrict__ keys, const MbkP* __restrict__ probs,
                                                               const double* __restrict__ centres, const double* __restrict__ state,
                                                               long long step, unsigned long long seed, double* __restrict__ pdist,
                                                               int32_t* __restrict__ pidx, const long long* __restrict__ part_off) {
   const int p = blockIdx.y;
   const MbkP P = probs[p];
-  if (state[p * 8 + 4] != 0.0) return;
+  if (state[p * 16 + 4] != 0.0) return;
   const int n_tiles = (int)((P.k + kTileC - 1) / kTileC);
-  const int tile = blockIdx.x;
+  const int tile = blockIdx.x / kPtChunks, chunk = blockIdx.x % kPtChunks;
   if (tile >= n_tiles) return;
   const int bs = (int)min((long long)1000, P.n);
   __shared__ double sc[kTileC * 4];
@@ -492,7 +493,8 @@ __global__ __launch_bounds__(256) void mbk_batch_estep_kernel(const uint32_t* __
   __syncthreads();
   double* pd = pdist + part_off[p] + (size_t)tile * kBatch;
   int32_t* pi = pidx + part_off[p] + (size_t)tile * kBatch;
-  for (int b = threadIdx.x; b < bs; b += blockDim.x) {
+  const int b = chunk * 256 + threadIdx.x;
+  if (b < bs) {
     const unsigned long long src = bounded(counter_hash(seed, 2ull * (unsigned long long)step, (unsigned long long)b), (unsigned long long)P.n);
     const uint32_t kk = keys[P.off + src];
     const double x0 = (double)key_r(kk), x1 = (double)key_g(kk), x2 = (double)key_b(kk);
@@ -508,7 +510,10 @@ __global__ __launch_bounds__(256) void mbk_batch_estep_kernel(const uint32_t* __
 }
 
 constexpr int kUpdThreads = 1024;
+constexpr int kUpdWaves = kUpdThreads / 64;
 constexpr int kHashSlots = 2048;
+constexpr int kHistBins = 2048;
+constexpr int kStateStride = 16;    // doubles per problem, see rhccq_mbk_steps
 
 struct UpdShared {
   int lab[kBatch];
@@ -518,12 +523,12 @@ struct UpdShared {
   unsigned hsum[kHashSlots][4];
   unsigned long long hk[kBatch];   // reassignment hash keys
   int perm[kBatch];
-  double dred[16];
-  int ired[17];
-  double wmax, wmin_keep, thr_w;
-  int n_cand, n_re, flag;
+  int hist[kHistBins];
+  double dred[kUpdWaves];
+  int ired[kUpdWaves + 1];
+  int weq[kUpdWaves], wsel[kUpdWaves];
   double sel_w;
-  int sel_take;
+  int take;
 };
 
 __device__ __forceinline__ double block_max_d(double v, UpdShared& sh) {
@@ -534,7 +539,7 @@ __device__ __forceinline__ double block_max_d(double v, UpdShared& sh) {
   if (lane == 0) sh.dred[w] = v;
   __syncthreads();
   double t = sh.dred[0];
-  for (int i = 1; i < kUpdThreads / 64; ++i) t = fmax(t, sh.dred[i]);
+  for (int i = 1; i < kUpdWaves; ++i) t = fmax(t, sh.dred[i]);
   return t;
 }
 __device__ __forceinline__ double block_min_d(double v, UpdShared& sh) {
@@ -545,10 +550,18 @@ __device__ __forceinline__ double block_min_d(double v, UpdShared& sh) {
   if (lane == 0) sh.dred[w] = v;
   __syncthreads();
   double t = sh.dred[0];
-  for (int i = 1; i < kUpdThreads / 64; ++i) t = fmin(t, sh.dred[i]);
+  for (int i = 1; i < kUpdWaves; ++i) t = fmin(t, sh.dred[i]);
   return t;
 }
 __device__ __forceinline__ int block_sum_i(int v, UpdShared& sh) { return block_sum<int>(v, sh.ired); }
+
+// selection predicate of the low-count reassignment (index-ordered ties resolved by `eq_rank`)
+__device__ __forceinline__ bool reassign_sel(double w, double thr, bool capped, double sel_w, int take, int eq_rank) {
+  if (!(w < thr)) return false;
+  if (!capped) return true;
+  if (w < sel_w) return true;
+  return w == sel_w && eq_rank < take;
+}
 
 __global__ __launch_bounds__(kUpdThreads) void mbk_update_kernel(const uint32_t* __restrict__ keys, const MbkP* __restrict__ probs,
                                                                  double* __restrict__ centres, double* __restrict__ weights,
@@ -556,9 +569,9 @@ __global__ __launch_bounds__(kUpdThreads) void mbk_update_kernel(const uint32_t*
                                                                  const double* __restrict__ pdist, const int32_t* __restrict__ pidx,
                                                                  const long long* __restrict__ part_off) {
   __shared__ UpdShared sh;
-  const int p = blockIdx.x, tid = threadIdx.x;
+  const int p = blockIdx.x, tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
   const MbkP P = probs[p];
-  double* st = state + p * 8;
+  double* st = state + p * kStateStride;
   if (st[4] != 0.0) return;
   const int k = (int)P.k;
   const long long n = P.n;
@@ -571,21 +584,26 @@ __global__ __launch_bounds__(kUpdThreads) void mbk_update_kernel(const uint32_t*
   const int n_tiles = (k + kTileC - 1) / kTileC;
   double* C = centres + P.koff * 4;
   double* W = weights + P.koff;
-  // ---- reduce the per-tile partial arg-mins in tile order (first arg-min) --------------------------
   for (int i = tid; i < kHashSlots; i += kUpdThreads) {
     sh.hkey[i] = -1;
     sh.hsum[i][0] = sh.hsum[i][1] = sh.hsum[i][2] = sh.hsum[i][3] = 0;
   }
+  // ---- reduce the per-tile partial arg-mins in tile order (first arg-min) --------------------------
   double per = 0.0;
   if (tid < bs) {
     const double* pd = pdist + part_off[p] + tid;
     const int32_t* pi = pidx + part_off[p] + tid;
     double bd = pd[0];
-    int bj = pi[0];
-    for (int t = 1; t < n_tiles; ++t) {
-      const double d = pd[(size_t)t * kBatch];
-      if (d < bd) { bd = d; bj = pi[(size_t)t * kBatch]; }
+    int bt = 0;
+    for (int t0 = 1; t0 < n_tiles; t0 += 8) {            // 8 independent loads in flight, compared in tile order
+      double dv[8];
+#pragma unroll
+      for (int q = 0; q < 8; ++q) dv[q] = t0 + q < n_tiles ? pd[(size_t)(t0 + q) * kBatch] : INFINITY;
+#pragma unroll
+      for (int q = 0; q < 8; ++q)
+        if (dv[q] < bd) { bd = dv[q]; bt = t0 + q; }
     }
+    const int bj = pi[(size_t)bt * kBatch];
     const unsigned long long src = bounded(counter_hash(seed, 2ull * (unsigned long long)step, (unsigned long long)tid), (unsigned long long)n);
     const uint32_t kk = keys[P.off + src];
     sh.lab[tid] = bj;
@@ -593,14 +611,12 @@ __global__ __launch_bounds__(kUpdThreads) void mbk_update_kernel(const uint32_t*
     const double d0 = (double)key_r(kk) - C[bj * 4], d1 = (double)key_g(kk) - C[bj * 4 + 1], d2 = (double)key_b(kk) - C[bj * 4 + 2];
     per = (d0 * d0 + d1 * d1) + d2 * d2;
   }
-  if (tid < kBatch) sh.per[tid] = per;
-  // reassignment decision uses the weights BEFORE this step's update (sklearn _random_reassign)
-  int zero = 0;
-  for (int j = tid; j < k; j += kUpdThreads) zero |= W[j] == 0.0;
-  __syncthreads();
-  zero = block_sum_i(zero, sh) > 0;
+  sh.per[tid] = per;
+  // reassignment decision uses the weights BEFORE this step's update (sklearn _random_reassign):
+  // st[8] = number of zero-weight centres, maintained by the reassignment sweep (it can only be non-zero
+  // while every step reassigns)
   double since = st[3] + (double)bs;
-  const bool do_reassign = zero || since >= 10.0 * (double)k;
+  const bool do_reassign = st[8] > 0.0 || since >= 10.0 * (double)k;
   if (do_reassign) since = 0.0;
   // ---- batch inertia: fixed 1024-leaf tree ----------------------------------------------------------
   for (int s = 512; s >= 1; s >>= 1) {
@@ -642,75 +658,91 @@ __global__ __launch_bounds__(kUpdThreads) void mbk_update_kernel(const uint32_t*
     W[j] = wn;
   }
   __syncthreads();
-  // ---- low-count reassignment (sklearn _mini_batch_step) -----------------------------------------------
+  // ---- low-count reassignment (sklearn _mini_batch_step), coalesced sweeps over the weights ------------
   if (do_reassign) {
     double wm = 0.0;
+#pragma unroll 8
     for (int j = tid; j < k; j += kUpdThreads) wm = fmax(wm, W[j]);
     wm = block_max_d(wm, sh);
     const double thr = 0.01 * wm;
-    int cnt = 0;
-    for (int j = tid; j < k; j += kUpdThreads) cnt += W[j] < thr;
-    cnt = block_sum_i(cnt, sh);
     const int cap = (int)(0.5 * (double)bs);
-    // selection threshold: keep candidates with (W, index) among the `cap` smallest when cnt > cap
-    double sel_w = thr;                                 // candidates: W < sel_w, plus `take` of W == sel_w
-    int take = 0;
-    if (cnt > 0.5 * (double)bs) {
-      // weights are integer-valued: bisect the smallest integer v with #(W <= v, W < thr) >= cap
-      double lo_v = -1.0, hi_v = floor(thr);            // #(W <= lo_v) < cap <= #(W <= hi_v) (hi_v >= all candidates)
-      if (hi_v >= thr) hi_v -= 1.0;
-      while (hi_v - lo_v > 1.0) {
-        const double mid = floor((lo_v + hi_v) * 0.5);
-        int c2 = 0;
-        for (int j = tid; j < k; j += kUpdThreads) c2 += (W[j] < thr) && (W[j] <= mid);
-        c2 = block_sum_i(c2, sh);
-        if (c2 >= cap) hi_v = mid; else lo_v = mid;
+    const int nbins = (int)ceil(thr);                   // candidate weights are integers in [0, thr)
+    const bool use_hist = nbins <= kHistBins;
+    for (int i = tid; i < kHistBins; i += kUpdThreads) sh.hist[i] = 0;
+    __syncthreads();
+    int cnt = 0;
+    for (int j = tid; j < k; j += kUpdThreads) {
+      const double w = W[j];
+      if (w < thr) {
+        ++cnt;
+        if (use_hist) atomicAdd(&sh.hist[(int)w], 1);
       }
-      int below = 0;
-      for (int j = tid; j < k; j += kUpdThreads) below += (W[j] < thr) && (W[j] < hi_v);
-      below = block_sum_i(below, sh);
-      sel_w = hi_v;
-      take = cap - below;
     }
-    // rank the candidates in ascending index order: thread owns a contiguous index range
-    const int perj = (k + kUpdThreads - 1) / kUpdThreads;
-    const int jlo = min(tid * perj, k), jhi = min(jlo + perj, k);
+    cnt = block_sum_i(cnt, sh);
     const bool capped = cnt > 0.5 * (double)bs;
-    int eqc = 0;
-    if (capped)
-      for (int j = jlo; j < jhi; ++j) eqc += (W[j] < thr) && (W[j] == sel_w);
-    int eq_tot;
-    int eq_base = block_exscan<int>(eqc, sh.ired, &eq_tot);
-    int mine = 0;
-    {
-      int e = eq_base;
-      for (int j = jlo; j < jhi; ++j) {
-        const double w = W[j];
-        bool sel;
-        if (!capped) sel = w < thr;
-        else if (w < thr && w < sel_w) sel = true;
-        else if (w < thr && w == sel_w) { sel = e < take; ++e; }
-        else sel = false;
-        mine += sel;
+    double sel_w = thr;
+    int take = 0;
+    if (capped) {
+      if (use_hist) {
+        if (tid == 0) {                                 // smallest weight v with #(W <= v) >= cap
+          int below = 0, v = 0;
+          for (; v < nbins; ++v) {
+            if (below + sh.hist[v] >= cap) break;
+            below += sh.hist[v];
+          }
+          sh.sel_w = (double)v;
+          sh.take = cap - below;
+        }
+        __syncthreads();
+        sel_w = sh.sel_w;
+        take = sh.take;
+      } else {
+        double lo_v = -1.0, hi_v = floor(thr);
+        if (hi_v >= thr) hi_v -= 1.0;
+        while (hi_v - lo_v > 1.0) {
+          const double mid = floor((lo_v + hi_v) * 0.5);
+          int c2 = 0;
+          for (int j = tid; j < k; j += kUpdThreads) c2 += (W[j] < thr) && (W[j] <= mid);
+          c2 = block_sum_i(c2, sh);
+          if (c2 >= cap) hi_v = mid; else lo_v = mid;
+        }
+        int below = 0;
+        for (int j = tid; j < k; j += kUpdThreads) below += (W[j] < thr) && (W[j] < hi_v);
+        below = block_sum_i(below, sh);
+        sel_w = hi_v;
+        take = cap - below;
       }
     }
-    int n_re;
-    const int rbase = block_exscan<int>(mine, sh.ired, &n_re);
-    // min weight among the centres that are NOT reassigned (computed before any overwrite)
+    // index-ordered ranks: wave w owns the contiguous index range [w * R, (w + 1) * R), swept 64 at a time
+    const int R = (((k + kUpdWaves - 1) / kUpdWaves) + 63) & ~63;
+    const int j0 = wave * R, j1 = min(j0 + R, k);
+    int eq_base = 0;
+    if (capped) {
+      int eq = 0;
+      for (int j = j0 + lane; j < j1; j += 64) { const double w = W[j]; eq += (w < thr) && (w == sel_w); }
+      eq = (int)wave_sum((unsigned long long)eq);
+      if (lane == 0) sh.weq[wave] = eq;
+      __syncthreads();
+      for (int w = 0; w < wave; ++w) eq_base += sh.weq[w];
+    }
+    // sweep 2: selected count per wave, min weight of the centres that stay
+    int nsel = 0, eq_run = eq_base;
     double wmin = INFINITY;
-    {
-      int e = eq_base;
-      for (int j = jlo; j < jhi; ++j) {
-        const double w = W[j];
-        bool sel;
-        if (!capped) sel = w < thr;
-        else if (w < thr && w < sel_w) sel = true;
-        else if (w < thr && w == sel_w) { sel = e < take; ++e; }
-        else sel = false;
-        if (!sel) wmin = fmin(wmin, w);
-      }
+    for (int jb = j0; jb < j1; jb += 64) {
+      const int j = jb + lane;
+      const double w = j < j1 ? W[j] : INFINITY;
+      const bool is_eq = capped && (w < thr) && (w == sel_w);
+      const unsigned long long meq = __ballot(is_eq);
+      const int rank = eq_run + __popcll(meq & ((1ull << lane) - 1ull));
+      const bool sel = j < j1 && reassign_sel(w, thr, capped, sel_w, take, rank);
+      nsel += __popcll(__ballot(sel));
+      if (j < j1 && !sel) wmin = fmin(wmin, w);
+      eq_run += __popcll(meq);
     }
-    wmin = block_min_d(wmin, sh);
+    if (lane == 0) sh.wsel[wave] = nsel;
+    wmin = block_min_d(wmin, sh);                        // (two barriers: wsel is visible afterwards)
+    int rbase = 0, n_re = 0;
+    for (int w = 0; w < kUpdWaves; ++w) { if (w < wave) rbase += sh.wsel[w]; n_re += sh.wsel[w]; }
     if (n_re > 0) {
       // perm = batch positions ordered by (hash key, position)
       if (tid < bs) sh.hk[tid] = counter_hash(seed, 2ull * (unsigned long long)step + 1ull, (unsigned long long)tid);
@@ -726,25 +758,32 @@ __global__ __launch_bounds__(kUpdThreads) void mbk_update_kernel(const uint32_t*
       }
       __syncthreads();
     }
-    {
-      int e = eq_base, r = rbase;
-      for (int j = jlo; j < jhi; ++j) {
-        const double w = W[j];
-        bool sel;
-        if (!capped) sel = w < thr;
-        else if (w < thr && w < sel_w) sel = true;
-        else if (w < thr && w == sel_w) { sel = e < take; ++e; }
-        else sel = false;
-        if (sel) {
-          const uint32_t kk = sh.bkey[sh.perm[r]];
-          ++r;
-          const double c0 = (double)key_r(kk), c1 = (double)key_g(kk), c2 = (double)key_b(kk);
-          C[j * 4] = c0; C[j * 4 + 1] = c1; C[j * 4 + 2] = c2;
-          C[j * 4 + 3] = (c0 * c0 + c1 * c1) + c2 * c2;
-          W[j] = wmin;
-        }
+    // sweep 3: apply; count the centres whose weight is still zero afterwards
+    int nzero = 0, r_run = rbase;
+    eq_run = eq_base;
+    for (int jb = j0; jb < j1; jb += 64) {
+      const int j = jb + lane;
+      const double w = j < j1 ? W[j] : INFINITY;
+      const bool is_eq = capped && (w < thr) && (w == sel_w);
+      const unsigned long long meq = __ballot(is_eq);
+      const int rank = eq_run + __popcll(meq & ((1ull << lane) - 1ull));
+      const bool sel = j < j1 && reassign_sel(w, thr, capped, sel_w, take, rank);
+      const unsigned long long msel = __ballot(sel);
+      double wf = w;
+      if (sel) {
+        const uint32_t kk = sh.bkey[sh.perm[r_run + __popcll(msel & ((1ull << lane) - 1ull))]];
+        const double c0 = (double)key_r(kk), c1 = (double)key_g(kk), c2 = (double)key_b(kk);
+        C[j * 4] = c0; C[j * 4 + 1] = c1; C[j * 4 + 2] = c2;
+        C[j * 4 + 3] = (c0 * c0 + c1 * c1) + c2 * c2;
+        W[j] = wmin;
+        wf = wmin;
       }
+      nzero += (j < j1) && (wf == 0.0);
+      eq_run += __popcll(meq);
+      r_run += __popcll(msel);
     }
+    nzero = block_sum_i(nzero, sh);
+    if (tid == 0) st[8] = (double)nzero;
   }
   // ---- sklearn _mini_batch_convergence (EWA early stopping) -------------------------------------------
   if (tid == 0) {
@@ -954,7 +993,7 @@ int rhccq_mbk_steps(rhccq_ctx* ctx, const uint32_t* keys, const rhccq_mbk_proble
   if (int e = layout_work(ctx, probs, n_prob, work, work_bytes, &v, &blocks, &max_tiles)) return e;
   for (int s = 0; s < n_steps; ++s) {
     const long long step = step0 + s;
-    hipLaunchKernelGGL(mbk_batch_estep_kernel, dim3(max_tiles, n_prob), dim3(256), 0, ctx->stream, keys, v.probs, centres, state, step,
+    hipLaunchKernelGGL(mbk_batch_estep_kernel, dim3(max_tiles * kPtChunks, n_prob), dim3(256), 0, ctx->stream, keys, v.probs, centres, state, step,
                        (unsigned long long)seed, v.pdist, v.pidx, v.part_off);
     hipLaunchKernelGGL(mbk_update_kernel, dim3(n_prob), dim3(kUpdThreads), 0, ctx->stream, keys, v.probs, centres, weights, state, step,
                        (unsigned long long)seed, v.pdist, v.pidx, v.part_off);

@@ -106,9 +106,14 @@ class FrameEncoder:
             torch.cuda.synchronize()
         self.timings[name] = self.timings.get(name, 0.0) + (time.perf_counter() - t0)
 
-    def reduce_first_positions(self, arrays):
-        """hook of the tiled (multi-GPU) encoder; a single GPU sees the whole frame"""
-        return arrays
+    def first_positions(self, S, fp_lut, n_entries):
+        """int64[n_entries]: first frame-raster position of every entry fp_lut maps (job, rank) to
+        (INT_MAX where an entry has no pixel).  The tiled (multi-GPU) encoder overrides this."""
+        rh = self.rh
+        fp = torch.full((max(n_entries, 1),), INT_MAX, dtype=torch.int32, device=rh.device)
+        rh.job_index(S["rgb"], S["labels"], S["job_base"][:-1], S["bitmaps"], S["prefix"], S["d_pal_off"], S["fix_key"],
+                     want_idx=False, first_pos=fp, fp_lut=rh.dev(fp_lut))
+        return fp[:n_entries].cpu().numpy().astype(np.int64)
 
     # ------------------------------------------------------------------------------------------
     def prepare(self, rgb, classes):
@@ -158,14 +163,11 @@ class FrameEncoder:
         d_pal_off = rh.dev(pal_off[:-1].copy())
         total = int(pal_off[-1])
         prefix, keys_dev = rh.bitmap_emit(bitmaps, chunk, d_pal_off, total)
-        first_pos = torch.full((max(total, 1),), INT_MAX, dtype=torch.int32, device=rh.device)
-        rh.job_index(rgb, labels, job_base[:-1], bitmaps, prefix, d_pal_off, fix_key, want_idx=False, first_pos=first_pos)
         keys_all = keys_dev[:total].cpu().numpy().view(np.uint32)
-        fp_all = first_pos[:total].cpu().numpy().astype(np.int64)
         self._t("unique", t0)
         return {"H": H, "W": W, "rgb": rgb, "classes": classes, "labels": labels, "job_base": job_base, "n_jobs": n_jobs,
                 "bitmaps": bitmaps, "prefix": prefix, "pal_off": pal_off, "d_pal_off": d_pal_off, "fix_key": fix_key,
-                "keys_all": keys_all, "fp_all": fp_all, "P": P, "present": present, "job_class": job_class,
+                "keys_all": keys_all, "P": P, "present": present, "job_class": job_class,
                 "job_region": job_region, "crop": (r0, r1, c0, c1), "total": total}
 
     def level1(self, S):
@@ -184,12 +186,17 @@ class FrameEncoder:
         res = cluster_palettes(rh, jobs)
         self._t("level1_cluster", t0)
         t0 = time.perf_counter()
+        # first raster position of every CLUSTERED palette entry (fixes the first-seen order of the merges,
+        # merging.py:77-79): one streaming pass whose atomicMin table is only sum(K_j) entries
         seg_comp = {}
-        fps = self.reduce_first_positions([_scatter_min(len(nk), mp, S["fp_all"][pal_off[j]:pal_off[j + 1]])
-                                           for j, (nk, mp, info) in zip(job_ids, res)])
-        for j, (nk, mp, info), fp_new in zip(job_ids, res, fps):
-            seg_comp[j] = _Comp(nk, fp_new, (int(r0[j]), int(c0[j])), (int(r1[j] - r0[j] + 1), int(c1[j] - c0[j] + 1)),
-                                {int(j): mp.astype(np.int32)}, False)
+        new_off = np.concatenate([[0], np.cumsum([len(nk) for nk, _, _ in res])]).astype(np.int64)
+        fp_lut = np.zeros(max(S["total"], 1), np.int32)
+        for i, (j, (nk, mp, info)) in enumerate(zip(job_ids, res)):
+            fp_lut[pal_off[j]:pal_off[j + 1]] = new_off[i] + mp
+        fp_new_all = self.first_positions(S, fp_lut, int(new_off[-1]))
+        for i, (j, (nk, mp, info)) in enumerate(zip(job_ids, res)):
+            seg_comp[j] = _Comp(nk, fp_new_all[new_off[i]:new_off[i + 1]], (int(r0[j]), int(c0[j])),
+                                (int(r1[j] - r0[j] + 1), int(c1[j] - c0[j] + 1)), {int(j): mp.astype(np.int32)}, False)
         per_class = []
         for ci, cls in enumerate(classes):
             regs = []

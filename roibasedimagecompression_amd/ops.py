@@ -173,11 +173,23 @@ class Rhccq:
         stats = torch.tensor([INT_MAX, -1, INT_MAX, -1, 0, 0], dtype=torch.int32, device=self.device).repeat(n_jobs, 1).contiguous()
         return bitmaps, stats
 
-    def job_scan(self, rgb, labels, job_base, bitmaps, stats, black_is_colour):
+    BYTEMAP_MAX_JOBS = 64        # 16 MiB of byte flags per job: up to 1 GiB of the 288 GB
+
+    def job_scan(self, rgb, labels, job_base, bitmaps, stats, black_is_colour, bytemaps=None):
+        """K0 + K1a.  With few jobs the colour flags go through byte maps (plain stores) and are packed into
+        the bitmaps; with many jobs bits are set directly with atomics."""
         H, W = rgb.shape[0], rgb.shape[1]
         n, ptrs, bases = self._class_args(labels, job_base)
-        self._check(self.lib.rhccq_job_scan(self.ctx, self._p(rgb), H, W, n, ptrs, bases, int(black_is_colour),
-                                            self._p(bitmaps), self._p(stats)), "job_scan")
+        n_jobs = bitmaps.shape[0]
+        if bytemaps is None and n_jobs <= self.BYTEMAP_MAX_JOBS:
+            bytemaps = self.zeros((n_jobs, 1 << 24), torch.uint8)
+        if bytemaps is not None:
+            self._check(self.lib.rhccq_job_scan_bytes(self.ctx, self._p(rgb), H, W, n, ptrs, bases, int(black_is_colour),
+                                                      self._p(bytemaps), self._p(stats)), "job_scan_bytes")
+            self._check(self.lib.rhccq_bytemap_pack(self.ctx, self._p(bytemaps), n_jobs, self._p(bitmaps)), "bytemap_pack")
+        else:
+            self._check(self.lib.rhccq_job_scan(self.ctx, self._p(rgb), H, W, n, ptrs, bases, int(black_is_colour),
+                                                self._p(bitmaps), self._p(stats)), "job_scan")
 
     def job_set_black(self, bitmaps, jobs):
         if len(jobs) == 0:
@@ -206,12 +218,13 @@ class Rhccq:
         self._check(self.lib.rhccq_job_blackfix(self.ctx, self._p(rgb), H, W, n, ptrs, bases, self._p(needs_fix), self._p(best)),
                     "job_blackfix")
 
-    def job_index(self, rgb, labels, job_base, bitmaps, prefix, pal_off, fix_key=None, want_idx=True, first_pos=None):
+    def job_index(self, rgb, labels, job_base, bitmaps, prefix, pal_off, fix_key=None, want_idx=True, first_pos=None, fp_lut=None):
         H, W = rgb.shape[0], rgb.shape[1]
         n, ptrs, bases = self._class_args(labels, job_base)
         idx = self.empty((n, H * W), torch.int32) if want_idx else None
         self._check(self.lib.rhccq_job_index(self.ctx, self._p(rgb), H, W, n, ptrs, bases, self._p(bitmaps), self._p(prefix),
-                                             self._p(pal_off), self._p(fix_key), self._p(idx), self._p(first_pos)), "job_index")
+                                             self._p(pal_off), self._p(fix_key), self._p(idx), self._p(first_pos), self._p(fp_lut)),
+                    "job_index")
         return idx
 
     def frame_remap(self, rgb, labels, job_base, bitmaps, prefix, pal_off, fix_key, lut, default_index, out_dtype):
@@ -348,7 +361,9 @@ class Rhccq:
         self._check(self.lib.rhccq_mbk_init(self.ctx, self._p(keys), probs, n_prob, self._p(d_init), self._p(d_rand),
                                             self._p(centres), self._p(chosen)), "mbk_init")
         weights = self.zeros((K,), torch.float64)
-        state = self.zeros((n_prob, 8), torch.float64)
+        st0 = np.zeros((n_prob, 16))
+        st0[:, 8] = k_list                                   # every centre starts with zero weight
+        state = self.dev(st0)
         wbytes = int(self.lib.rhccq_mbk_work_bytes(probs, n_prob))
         work = self.empty((max(wbytes, 8),), torch.uint8)
         step = 0

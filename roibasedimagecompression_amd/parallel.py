@@ -154,30 +154,18 @@ class TiledFrameEncoder(FrameEncoder):
         d_pal_off = rh.dev(pal_off[:-1].copy())
         total = int(pal_off[-1])
         prefix, keys_dev = rh.bitmap_emit(bitmaps, chunk, d_pal_off, total)
-        first_pos = torch.full((max(total, 1),), INT_MAX, dtype=torch.int32, device=rh.device)
-        rh.job_index(rgb, labels, job_base[:-1], bitmaps, prefix, d_pal_off, fix_key, want_idx=False, first_pos=first_pos)
         keys_all = keys_dev[:total].cpu().numpy().view(np.uint32)
-        # tile-local raster positions -> frame raster positions; the MIN over ranks happens after the
-        # level-1 mapping (reduce_first_positions), on arrays the size of the clustered palettes
-        fp_all = self._global_pos(first_pos[:total].cpu().numpy())
         return {"H": H, "W": W, "rgb": rgb, "classes": classes, "labels": labels, "job_base": job_base, "n_jobs": n_jobs,
                 "bitmaps": bitmaps, "prefix": prefix, "pal_off": pal_off, "d_pal_off": d_pal_off, "fix_key": fix_key,
-                "keys_all": keys_all, "fp_all": fp_all, "P": P, "present": present, "job_class": job_class,
+                "keys_all": keys_all, "P": P, "present": present, "job_class": job_class,
                 "job_region": job_region, "crop": (r0, r1, c0, c1), "total": total}
 
-    def reduce_first_positions(self, arrays):
-        """MIN over ranks of the first-seen positions of the level-1 (clustered) palette entries: the only
-        other exchange of the tiled path, palette-sized (a few 10^4 int64 per segment at 4K)."""
-        if dist.get_world_size(self.group) == 1 or not arrays:
-            return arrays
-        sizes = [len(a) for a in arrays]
-        t = torch.from_numpy(np.concatenate(arrays)).to(self.rh.device)
-        t = all_reduce_min_(t, self.group).cpu().numpy()
-        out, o = [], 0
-        for n in sizes:
-            out.append(t[o:o + n])
-            o += n
-        return out
+    def first_positions(self, S, fp_lut, n_entries):
+        """tile-local first positions -> frame raster positions -> MIN over ranks: the only other exchange of
+        the tiled path, the size of the clustered palettes (a few 10^4 int64 per segment at 4K)."""
+        local = super().first_positions(S, fp_lut, n_entries)
+        t = torch.from_numpy(self._global_pos(local)).to(self.rh.device)
+        return all_reduce_min_(t, self.group).cpu().numpy().astype(np.int64)
 
     @property
     def tile_origins(self):
