@@ -151,13 +151,14 @@ int rhccq_mbk_assign(rhccq_ctx* ctx, const uint32_t* keys, const rhccq_mbk_probl
 /* ---- K6: index remap gather (clustering.py:373-377) ------------------------------------------ */
 int rhccq_remap(rhccq_ctx* ctx, const int32_t* idx, int64_t n, const int32_t* lut, int64_t lut_n,
                 int32_t* out);
-/* fused final remap of a frame: class precedence = class order; lut values < 0 are transparent;
- * out_elem_bytes in {1,2,4} */
+/* fused final remap of a frame: class precedence = class order; value = lut[pal_off[job]+rank], then
+ * lut2[value] when lut2 != NULL (lut = level-1 mapping, lut2 = the composed levels 2-3 over the clustered
+ * palettes); values < 0 are transparent; out_elem_bytes in {1,2,4} */
 int rhccq_frame_remap(rhccq_ctx* ctx, const uint8_t* rgb, int32_t H, int32_t W, int32_t n_class,
                       const int32_t* const* labels_host, const int32_t* job_base_host,
                       const uint32_t* bitmaps, const uint32_t* word_prefix, const int64_t* pal_off,
-                      const uint32_t* fix_key, const int32_t* lut, int32_t default_index, void* out,
-                      int32_t out_elem_bytes);
+                      const uint32_t* fix_key, const int32_t* lut, const int32_t* lut2, int32_t default_index,
+                      void* out, int32_t out_elem_bytes);
 
 /* ---- K5: merge_region_components_simple (encoder/compression/merging.py:8-120) ---------------
  * one component at a time (the host assigns first-seen global indices between the two calls):

@@ -54,7 +54,7 @@ PROTOTYPES = {
     "rhccq_mbk_assign": (c_int32, [c_void_p, c_void_p, C.POINTER(MbkProblem), c_int32, c_void_p, c_void_p, c_int64, c_void_p]),
     "rhccq_remap": (c_int32, [c_void_p, c_void_p, c_int64, c_void_p, c_int64, c_void_p]),
     "rhccq_frame_remap": (c_int32, [c_void_p, c_void_p, c_int32, c_int32, c_int32, C.POINTER(c_void_p), C.POINTER(c_int32),
-                                    c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_int32, c_void_p, c_int32]),
+                                    c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_int32, c_void_p, c_int32]),
     "rhccq_merge_firstpos": (c_int32, [c_void_p, c_void_p, c_int32, c_int32, c_int32, c_int32, c_int32, c_int32, c_int32, c_void_p]),
     "rhccq_merge_paint": (c_int32, [c_void_p, c_void_p, c_int32, c_int32, c_int32, c_int32, c_int32, c_int32, c_void_p, c_int32, c_void_p]),
     "rhccq_decode": (c_int32, [c_void_p, c_void_p, c_int32, c_int64, c_void_p, c_int64, c_void_p]),

@@ -332,7 +332,8 @@ template <typename OutT>
 __global__ __launch_bounds__(256) void frame_remap_kernel(const uint8_t* __restrict__ rgb, int H, int W, ClassArgs ca,
                                                           const uint32_t* __restrict__ bitmaps, const uint32_t* __restrict__ word_prefix,
                                                           const int64_t* __restrict__ pal_off, const uint32_t* __restrict__ fix_key,
-                                                          const int32_t* __restrict__ lut, int32_t default_index, OutT* __restrict__ out) {
+                                                          const int32_t* __restrict__ lut, const int32_t* __restrict__ lut2,
+                                                          int32_t default_index, OutT* __restrict__ out) {
   const int64_t n_px = (int64_t)H * W;
   const int64_t n_quads = (n_px + 3) >> 2;
   for (int64_t q = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; q < n_quads; q += (int64_t)gridDim.x * blockDim.x) {
@@ -350,7 +351,9 @@ __global__ __launch_bounds__(256) void frame_remap_kernel(const uint8_t* __restr
         const int job = ca.job_base[c] + lab[i] - 1;
         uint32_t k = key[i];
         if (k == 0u && fix_key) k = fix_key[job];
-        res[i] = lut[pal_off[job] + rank_of(bitmaps, word_prefix, job, k)];
+        int32_t v = lut[pal_off[job] + rank_of(bitmaps, word_prefix, job, k)];
+        if (lut2) v = lut2[v];                          // level-1 index -> composed levels 2/3 (small, cache resident)
+        res[i] = v;
       }
     }
 #pragma unroll
@@ -511,7 +514,7 @@ int rhccq_job_index(rhccq_ctx* ctx, const uint8_t* rgb, int32_t H, int32_t W, in
 int rhccq_frame_remap(rhccq_ctx* ctx, const uint8_t* rgb, int32_t H, int32_t W, int32_t n_class,
                       const int32_t* const* labels_host, const int32_t* job_base_host, const uint32_t* bitmaps,
                       const uint32_t* word_prefix, const int64_t* pal_off, const uint32_t* fix_key, const int32_t* lut,
-                      int32_t default_index, void* out, int32_t out_elem_bytes) {
+                      const int32_t* lut2, int32_t default_index, void* out, int32_t out_elem_bytes) {
   if (!ctx || !rgb || !bitmaps || !word_prefix || !pal_off || !lut || !out || H <= 0 || W <= 0)
     return rhccq_fail(ctx, RHCCQ_E_ARG, "frame_remap: bad argument");
   ClassArgs ca;
@@ -519,9 +522,9 @@ int rhccq_frame_remap(rhccq_ctx* ctx, const uint8_t* rgb, int32_t H, int32_t W, 
   const int64_t quads = ((int64_t)H * W + 3) / 4;
   const dim3 grid(stream_grid(quads, 256)), block(256);
   switch (out_elem_bytes) {
-    case 1: hipLaunchKernelGGL(frame_remap_kernel<uint8_t>, grid, block, 0, ctx->stream, rgb, H, W, ca, bitmaps, word_prefix, pal_off, fix_key, lut, default_index, (uint8_t*)out); break;
-    case 2: hipLaunchKernelGGL(frame_remap_kernel<uint16_t>, grid, block, 0, ctx->stream, rgb, H, W, ca, bitmaps, word_prefix, pal_off, fix_key, lut, default_index, (uint16_t*)out); break;
-    case 4: hipLaunchKernelGGL(frame_remap_kernel<int32_t>, grid, block, 0, ctx->stream, rgb, H, W, ca, bitmaps, word_prefix, pal_off, fix_key, lut, default_index, (int32_t*)out); break;
+    case 1: hipLaunchKernelGGL(frame_remap_kernel<uint8_t>, grid, block, 0, ctx->stream, rgb, H, W, ca, bitmaps, word_prefix, pal_off, fix_key, lut, lut2, default_index, (uint8_t*)out); break;
+    case 2: hipLaunchKernelGGL(frame_remap_kernel<uint16_t>, grid, block, 0, ctx->stream, rgb, H, W, ca, bitmaps, word_prefix, pal_off, fix_key, lut, lut2, default_index, (uint16_t*)out); break;
+    case 4: hipLaunchKernelGGL(frame_remap_kernel<int32_t>, grid, block, 0, ctx->stream, rgb, H, W, ca, bitmaps, word_prefix, pal_off, fix_key, lut, lut2, default_index, (int32_t*)out); break;
     default: return rhccq_fail(ctx, RHCCQ_E_ARG, "frame_remap: out_elem_bytes must be 1, 2 or 4");
   }
   RHCCQ_LAUNCH_CHECK(ctx);

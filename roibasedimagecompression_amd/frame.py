@@ -56,7 +56,7 @@ class _Comp:
         self.fp = fp              # int64[K] first absolute raster position showing the entry
         self.top_left = top_left
         self.shape = shape
-        self.maps = maps          # {job: int32[P_job]} level-1 palette index -> index into keys
+        self.maps = maps          # {job: int32[K1_job]} index in the job's CLUSTERED level-1 palette -> index into keys
         self.merged = merged      # True: canvas semantics (index 0 = black = uncovered)
 
 
@@ -112,7 +112,7 @@ class FrameEncoder:
         rh = self.rh
         fp = torch.full((max(n_entries, 1),), INT_MAX, dtype=torch.int32, device=rh.device)
         rh.job_index(S["rgb"], S["labels"], S["job_base"][:-1], S["bitmaps"], S["prefix"], S["d_pal_off"], S["fix_key"],
-                     want_idx=False, first_pos=fp, fp_lut=rh.dev(fp_lut))
+                     want_idx=False, first_pos=fp, fp_lut=fp_lut)
         return fp[:n_entries].cpu().numpy().astype(np.int64)
 
     # ------------------------------------------------------------------------------------------
@@ -193,10 +193,13 @@ class FrameEncoder:
         fp_lut = np.zeros(max(S["total"], 1), np.int32)
         for i, (j, (nk, mp, info)) in enumerate(zip(job_ids, res)):
             fp_lut[pal_off[j]:pal_off[j + 1]] = new_off[i] + mp
-        fp_new_all = self.first_positions(S, fp_lut, int(new_off[-1]))
+        S["lut1"] = rh.dev(fp_lut)                                         # (job, rank) -> global clustered-palette entry
+        S["k1_off"] = {int(j): (int(new_off[i]), int(new_off[i + 1])) for i, j in enumerate(job_ids)}
+        S["k1_total"] = int(new_off[-1])
+        fp_new_all = self.first_positions(S, S["lut1"], int(new_off[-1]))
         for i, (j, (nk, mp, info)) in enumerate(zip(job_ids, res)):
             seg_comp[j] = _Comp(nk, fp_new_all[new_off[i]:new_off[i + 1]], (int(r0[j]), int(c0[j])),
-                                (int(r1[j] - r0[j] + 1), int(c1[j] - c0[j] + 1)), {int(j): mp.astype(np.int32)}, False)
+                                (int(r1[j] - r0[j] + 1), int(c1[j] - c0[j] + 1)), {int(j): np.arange(len(nk), dtype=np.int32)}, False)
         per_class = []
         for ci, cls in enumerate(classes):
             regs = []
@@ -254,8 +257,9 @@ class FrameEncoder:
         (fk3, mp3, info3), = cluster_palettes(rh, [{"keys": m3c.keys, "quality": q3, "eps": eps, "mc": mc}])
         self._t("level3", t0)
         t0 = time.perf_counter()
-        # ---- compose the three levels into one LUT per (segment, level-1 index) ---------------------
-        lut = np.full(max(total, 1), -1, np.int32)
+        # ---- compose levels 2-3 into one LUT over the clustered level-1 palettes (lut2); the per-pixel pass
+        # chains it behind the level-1 mapping (lut1) -------------------------------------------------------
+        lut2 = np.full(max(S["k1_total"], 1), -1, np.int32)
         for c2 in comps3:
             for job, m in c2.maps.items():
                 if multi:
@@ -263,20 +267,21 @@ class FrameEncoder:
                     v = np.where(painted, mp3[m3c.maps[job]], -1)
                 else:
                     v = mp3[m]
-                lut[pal_off[job]:pal_off[job + 1]] = v
+                a, b = S["k1_off"][job]
+                lut2[a:b] = v
         if multi:
             default_index = int(mp3[0])
         else:
             blk = np.nonzero(fk3 == 0)[0]
             default_index = int(blk[0]) if len(blk) else 0
-        max_index = int(max(lut.max(initial=0), default_index))
+        max_index = int(max(lut2.max(initial=0), default_index))
         out_dtype = torch.uint8 if max_index < 256 else (torch.int16 if max_index < 65536 else torch.int32)
         dtype_name = "uint8" if max_index < 256 else ("uint16" if max_index < 65536 else "uint32")
-        d_lut = rh.dev(lut)
+        d_lut2 = rh.dev(lut2)
         self._t("compose", t0)
         t0 = time.perf_counter()
-        out = rh.frame_remap(rgb, S["labels"], S["job_base"][:-1], S["bitmaps"], S["prefix"], S["d_pal_off"], S["fix_key"], d_lut,
-                             default_index, out_dtype)
+        out = rh.frame_remap(rgb, S["labels"], S["job_base"][:-1], S["bitmaps"], S["prefix"], S["d_pal_off"], S["fix_key"], S["lut1"],
+                             default_index, out_dtype, lut2=d_lut2)
         self._t("remap", t0, sync=profile)
         result = {"palette": unpack_rgb(fk3), "indices": out, "indices_dtype": dtype_name,
                   "shape": (H, W) if multi else tuple(m3c.shape), "top_left": (0, 0) if multi else tuple(m3c.top_left),
@@ -292,16 +297,16 @@ class FrameEncoder:
         return it: canvas semantics for merged components (uncovered = 0 = black), crop semantics for a
         single segment (background = the palette's black entry)."""
         rh = self.rh
-        pal_off = S["pal_off"]
-        lut = np.full(max(int(pal_off[-1]), 1), -1, np.int32)
+        lut2 = np.full(max(S["k1_total"], 1), -1, np.int32)
         for job, m in comp.maps.items():
-            lut[pal_off[job]:pal_off[job + 1]] = m
+            a, b = S["k1_off"][job]
+            lut2[a:b] = m
         default = 0
         if not comp.merged:
             blk = np.nonzero(comp.keys == 0)[0]
             default = int(blk[0]) if len(blk) else 0
         full = rh.frame_remap(S["rgb"], S["labels"], S["job_base"][:-1], S["bitmaps"], S["prefix"], S["d_pal_off"], S["fix_key"],
-                              rh.dev(lut), default, torch.int32)
+                              S["lut1"], default, torch.int32, lut2=rh.dev(lut2))
         r, c = comp.top_left
         h, w = comp.shape
         return full[r:r + h, c:c + w].contiguous()

@@ -227,13 +227,13 @@ class Rhccq:
                     "job_index")
         return idx
 
-    def frame_remap(self, rgb, labels, job_base, bitmaps, prefix, pal_off, fix_key, lut, default_index, out_dtype):
+    def frame_remap(self, rgb, labels, job_base, bitmaps, prefix, pal_off, fix_key, lut, default_index, out_dtype, lut2=None):
         H, W = rgb.shape[0], rgb.shape[1]
         n, ptrs, bases = self._class_args(labels, job_base)
         out = self.empty((H, W), out_dtype)
         self._check(self.lib.rhccq_frame_remap(self.ctx, self._p(rgb), H, W, n, ptrs, bases, self._p(bitmaps), self._p(prefix),
-                                               self._p(pal_off), self._p(fix_key), self._p(lut), int(default_index), self._p(out),
-                                               out.element_size()), "frame_remap")
+                                               self._p(pal_off), self._p(fix_key), self._p(lut), self._p(lut2), int(default_index),
+                                               self._p(out), out.element_size()), "frame_remap")
         return out
 
     def unique_colors(self, rgb):
