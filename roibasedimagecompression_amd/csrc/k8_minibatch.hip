@@ -50,7 +50,7 @@ struct InitShared {
   uint32_t ckey[kTMaxI];
   unsigned long long delta[kTMaxI];
   unsigned long long pot;
-  int n_touch, n_items, overflow;
+  int n_touch2[2], n_items, overflow;
 };
 
 __device__ __forceinline__ unsigned long long init_exscan64(unsigned long long v, InitShared& sh, unsigned long long* total) {
@@ -174,10 +174,11 @@ __device__ __forceinline__ void enumerate_hits(uint32_t ck, int nb, int nsb, con
   }
 }
 
-// lower closest[] of block b against centre ck; refresh bmax / bsum / sbsum; note the super-block as touched
-__device__ __forceinline__ void commit_block(int b, uint32_t ck, uint2* samp, const InitTables& tb, int* touch, int* n_touch, int touch_cap) {
+// lower closest[] of block b against centre ck (samples already in `sv`); refresh bmax / bsum / sbsum; note
+// the super-block as touched
+__device__ __forceinline__ void commit_block(int b, uint32_t ck, uint2 sv, uint2* samp, const InitTables& tb, int* touch, int* n_touch,
+                                             int touch_cap) {
   const int lane = threadIdx.x & 63;
-  const uint2 sv = samp[(b << 6) + lane];
   const unsigned d = (unsigned)dist2_keys(ck, sv.x);
   unsigned c2 = sv.y;
   if (d < c2) { c2 = d; samp[(b << 6) + lane].y = d; }
@@ -245,7 +246,7 @@ __device__ __forceinline__ void init_body(const uint32_t* __restrict__ keys, con
     psum += sum;
   }
   psum = block_sum<unsigned long long>(psum, sh.red64);
-  if (tid == 0) { cho[0] = P.first; sh.n_touch = 0; sh.pot = psum; sh.n_items = 0; sh.overflow = 0; }
+  if (tid == 0) { cho[0] = P.first; sh.n_touch2[0] = 0; sh.n_touch2[1] = 0; sh.pot = psum; sh.n_items = 0; sh.overflow = 0; }
   if (tid < kTMaxI) sh.delta[tid] = 0;
   if (tid < T && k > 1) s_u[T + tid] = rand[P.rand_off + tid];         // uniforms of step 1 -> buffer 1
   __syncthreads();
@@ -260,7 +261,8 @@ __device__ __forceinline__ void init_body(const uint32_t* __restrict__ keys, con
     double u_next = 0.0;
     if (tid < T && c + 1 < k) u_next = rand[P.rand_off + (size_t)c * T + tid];
     const unsigned long long pot = sh.pot;
-    const int n_touched = min(sh.n_touch, kMaxTouch);
+    const int* touch_r = s_touch + (((c - 1) & 1) ? kMaxTouch : 0);   // list written by the previous step's commit
+    const int n_touched = min(sh.n_touch2[(c - 1) & 1], kMaxTouch);
     // ================= phase 1: waves t < T -- pick candidate t, list the blocks it can improve ===========
     if (wave < T) {
       const int t = wave;
@@ -328,7 +330,7 @@ __device__ __forceinline__ void init_body(const uint32_t* __restrict__ keys, con
       // idle waves refresh the super-block maxima the previous winner touched (a stale, larger sbmax is
       // conservative, so the candidate waves may read either value)
       for (int i = (tid - T * 64); i < n_touched * 16; i += kInitThreads - T * 64) {
-        const int sb = s_touch[i >> 4], b = sb * 16 + (i & 15);
+        const int sb = touch_r[i >> 4], b = sb * 16 + (i & 15);
         unsigned m = b < nb ? tb.bmax[b] : 0u;
 #pragma unroll
         for (int o = 8; o > 0; o >>= 1) m = max(m, (unsigned)__shfl_xor((int)m, o, 64));
@@ -339,24 +341,24 @@ __device__ __forceinline__ void init_body(const uint32_t* __restrict__ keys, con
     STAMP(2);
     const bool use_list = s_items != nullptr && sh.overflow == 0;
     const int n_items = sh.n_items;
+    int* touch_w = s_touch + ((c & 1) ? kMaxTouch : 0);      // list written by this step's commit
+    int* n_touch_w = &sh.n_touch2[c & 1];
     // ================= phase 2: potentials ==================================================================
+    // all waves share the (candidate, block) items evenly, 8 items (8 x 512 B of samples) in flight per wave
     if (use_list) {
-      // all waves share the (candidate, block) items evenly; 8 items (8 x 512 B of samples) in flight per wave
       for (int i0 = wave * 8; i0 < n_items; i0 += kInitWaves * 8) {
         uint32_t it[8];
         uint2 sv[8];
 #pragma unroll
-        for (int q = 0; q < 8; ++q) {
-          it[q] = i0 + q < n_items ? s_items[i0 + q] : 0xffffffffu;
-          sv[q] = samp[((it[q] == 0xffffffffu ? 0u : (it[q] & 0xffffffu)) << 6) + lane];
-        }
+        for (int q = 0; q < 8; ++q) it[q] = i0 + q < n_items ? s_items[i0 + q] : 0xffffffffu;
+#pragma unroll
+        for (int q = 0; q < 8; ++q) sv[q] = samp[((it[q] == 0xffffffffu ? 0u : (it[q] & 0xffffffu)) << 6) + lane];
 #pragma unroll
         for (int q = 0; q < 8; ++q) {
           if (it[q] == 0xffffffffu) continue;
-          const int t = it[q] >> 24;
-          const unsigned d = (unsigned)dist2_keys(sh.ckey[t], sv[q].x);
-          const unsigned s = wave_sum_u32(sv[q].y > d ? sv[q].y - d : 0u);
-          if (lane == 0 && s) atomicAdd(&sh.delta[t], (unsigned long long)s);
+          const unsigned d = (unsigned)dist2_keys(sh.ckey[it[q] >> 24], sv[q].x);
+          const unsigned sdel = wave_sum_u32(sv[q].y > d ? sv[q].y - d : 0u);
+          if (lane == 0 && sdel) atomicAdd(&sh.delta[it[q] >> 24], (unsigned long long)sdel);
         }
       }
     } else {
@@ -368,9 +370,9 @@ __device__ __forceinline__ void init_body(const uint32_t* __restrict__ keys, con
             const int p = __ffsll((long long)mb) - 1;
             mb &= mb - 1;
             const int bb = __shfl(b, p, 64);
-            const uint2 sv = samp[(bb << 6) + lane];
-            const unsigned d = (unsigned)dist2_keys(ck, sv.x);
-            delta += sv.y > d ? sv.y - d : 0u;
+            const uint2 s2 = samp[(bb << 6) + lane];
+            const unsigned d = (unsigned)dist2_keys(ck, s2.x);
+            delta += s2.y > d ? s2.y - d : 0u;
           }
         });
         delta = wave_sum(delta);
@@ -385,12 +387,14 @@ __device__ __forceinline__ void init_body(const uint32_t* __restrict__ keys, con
     for (int t = 1; t < T; ++t)
       if (sh.delta[t] > bd) { bd = sh.delta[t]; best = t; }
     const uint32_t kb = sh.ckey[best];
-    if (tid == 0) sh.n_touch = 0;
-    __syncthreads();
-    if (use_list) {
+    if (false) {
+    } else if (use_list) {
       for (int i = wave; i < n_items; i += kInitWaves) {
-        const uint32_t it = s_items[i];
-        if ((int)(it >> 24) == best) commit_block((int)(it & 0xffffffu), kb, samp, tb, s_touch, &sh.n_touch, kMaxTouch);
+        const uint32_t itx = s_items[i];
+        if ((int)(itx >> 24) == best) {
+          const int b = (int)(itx & 0xffffffu);
+          commit_block(b, kb, samp[(b << 6) + lane], samp, tb, touch_w, n_touch_w, kMaxTouch);
+        }
       }
     } else {
       // wave w owns super-blocks sb = w (mod 16)
@@ -399,31 +403,33 @@ __device__ __forceinline__ void init_body(const uint32_t* __restrict__ keys, con
         const bool hsb = sb < nsb && (unsigned)box_dist2(kb, tb.sblo[sb], tb.sbhi[sb]) < tb.sbmax[sb];
         unsigned long long msb = __ballot(hsb);
         while (msb) {
-          const int s = (base + __ffsll((long long)msb) - 1) * kInitWaves + wave;
+          const int sx = (base + __ffsll((long long)msb) - 1) * kInitWaves + wave;
           msb &= msb - 1;
-          const int b = s * 16 + (lane & 15);
+          const int b = sx * 16 + (lane & 15);
           const bool hb = lane < 16 && b < nb && (unsigned)box_dist2(kb, tb.lo[b], tb.hi[b]) < tb.bmax[b];
           unsigned long long mb = __ballot(hb);
           while (mb) {
             const int p = __ffsll((long long)mb) - 1;
             mb &= mb - 1;
-            commit_block(s * 16 + p, kb, samp, tb, s_touch, &sh.n_touch, kMaxTouch);
+            const int bb = sx * 16 + p;
+            commit_block(bb, kb, samp[(bb << 6) + lane], samp, tb, touch_w, n_touch_w, kMaxTouch);
           }
         }
       }
     }
-    if (tid == 0) { cho[c] = sh.cand[best]; sh.pot = pot - bd; sh.n_items = 0; sh.overflow = 0; }
+    if (tid == 0) { cho[c] = sh.cand[best]; sh.pot = pot - bd; sh.n_items = 0; sh.overflow = 0; sh.n_touch2[(c + 1) & 1] = 0; }
     if (tid < T) { s_u[((c + 1) & 1) * T + tid] = u_next; sh.delta[tid] = 0; }
     __syncthreads();
     STAMP(4);
     // more touched super-blocks than the list holds (only in the first steps): refresh all of them
-    if (sh.n_touch > kMaxTouch) {
+    if (sh.n_touch2[c & 1] > kMaxTouch) {
       for (int sb = tid; sb < nsb; sb += kInitThreads) {
         unsigned m = 0;
         for (int b = sb * 16; b < min(sb * 16 + 16, nb); ++b) m = max(m, tb.bmax[b]);
         tb.sbmax[sb] = m;
       }
-      if (tid == 0) sh.n_touch = 0;
+      __syncthreads();
+      if (tid == 0) sh.n_touch2[c & 1] = 0;
       __syncthreads();
     }
   }
@@ -447,7 +453,7 @@ __global__ __launch_bounds__(kInitThreads) void mbk_init_kernel(const uint32_t* 
   __shared__ uint32_t s_tab[4 * kInitLdsBlocks + 4 * kInitLdsSuper];
   __shared__ uint32_t s_items[kMaxItems];
   __shared__ double s_u[2 * kTMaxI];
-  __shared__ int s_touch[kMaxTouch];
+  __shared__ int s_touch[2 * kMaxTouch];
   const MbkP P = probs[blockIdx.x];
   const int nb = ((int)P.init_n + 63) >> 6, np = nb << 6, nsb = (nb + 15) >> 4;
   uint2* samp = reinterpret_cast<uint2*>(scratch + scratch_off[blockIdx.x]);
@@ -810,51 +816,99 @@ __global__ __launch_bounds__(kUpdThreads) void mbk_update_kernel(const uint32_t*
 // ------------------------------------------------------------------------------------------------
 // final E-step over all points
 // ------------------------------------------------------------------------------------------------
-constexpr int kAsgThreads = 256;
-constexpr int kAsgPts = 4;
-constexpr int kAsgTile = 512;       // centres per LDS tile (16 KB)
+// ---- exact pruning of the final E-step: uniform 32^3 grid over the centres --------------------------
+// A point searches the cells around its own in growing Chebyshev rings and stops once its best true
+// distance is below the distance to anything outside the searched cube; every centre it skips is provably
+// farther than the winner by a margin far above float64 rounding, so the result equals the brute-force
+// first arg-min of csq_j + (-2 * dot) (ties between equal distances go to the smaller j explicitly).
+constexpr int kGridG = 32, kGridCells = kGridG * kGridG * kGridG, kCellSide = 8;
 
-__global__ __launch_bounds__(kAsgThreads) void mbk_assign_kernel(const uint32_t* __restrict__ keys, const MbkP* __restrict__ probs,
-                                                                 const double* __restrict__ centres, int32_t* __restrict__ labels,
-                                                                 const long long* __restrict__ blk_off) {
-  // blockIdx.x -> (problem, chunk of 1024 points) through the prefix blk_off[n_prob+1]
-  __shared__ double sc[kAsgTile * 4];
+__device__ __forceinline__ int grid_axis(double v) { return min(kGridG - 1, max(0, (int)(v * (1.0 / kCellSide)))); }
+
+__global__ __launch_bounds__(256) void grid_count_kernel(const MbkP* __restrict__ probs, const double* __restrict__ centres,
+                                                         uint32_t* __restrict__ cell_cnt /* [n_prob][cells+1] */) {
+  const MbkP P = probs[blockIdx.y];
+  const long long j = (long long)blockIdx.x * blockDim.x + threadIdx.x;
+  if (j >= P.k) return;
+  const double* c = centres + (P.koff + j) * 4;
+  const int cell = (grid_axis(c[0]) * kGridG + grid_axis(c[1])) * kGridG + grid_axis(c[2]);
+  atomicAdd(&cell_cnt[(size_t)blockIdx.y * (kGridCells + 1) + cell + 1], 1u);
+}
+
+__global__ __launch_bounds__(1024) void grid_scan_kernel(uint32_t* __restrict__ cell_cnt, uint32_t* __restrict__ cursor) {
+  __shared__ unsigned red[17];
+  uint32_t* cs = cell_cnt + (size_t)blockIdx.x * (kGridCells + 1);
+  uint32_t* cur = cursor + (size_t)blockIdx.x * kGridCells;
+  constexpr int per = kGridCells / 1024;               // 32 consecutive cells per thread
+  unsigned loc[per];
+  unsigned sum = 0;
+  for (int i = 0; i < per; ++i) { loc[i] = cs[1 + threadIdx.x * per + i]; sum += loc[i]; }
+  unsigned tot;
+  unsigned base = block_exscan<unsigned>(sum, red, &tot);
+  for (int i = 0; i < per; ++i) {
+    cur[threadIdx.x * per + i] = base;                   // fill cursor = start of the cell
+    base += loc[i];
+    cs[1 + threadIdx.x * per + i] = base;                // cs[c + 1] = end of cell c (cs[0] stays 0)
+  }
+}
+
+__global__ __launch_bounds__(256) void grid_fill_kernel(const MbkP* __restrict__ probs, const double* __restrict__ centres,
+                                                        uint32_t* __restrict__ cursor, uint32_t* __restrict__ order) {
+  const MbkP P = probs[blockIdx.y];
+  const long long j = (long long)blockIdx.x * blockDim.x + threadIdx.x;
+  if (j >= P.k) return;
+  const double* c = centres + (P.koff + j) * 4;
+  const int cell = (grid_axis(c[0]) * kGridG + grid_axis(c[1])) * kGridG + grid_axis(c[2]);
+  const unsigned pos = atomicAdd(&cursor[(size_t)blockIdx.y * kGridCells + cell], 1u);
+  order[P.koff + pos] = (uint32_t)j;
+}
+
+__global__ __launch_bounds__(256) void mbk_assign_grid_kernel(const uint32_t* __restrict__ keys, const MbkP* __restrict__ probs,
+                                                              const double* __restrict__ centres, const uint32_t* __restrict__ cell_start,
+                                                              const uint32_t* __restrict__ order, int32_t* __restrict__ labels,
+                                                              const long long* __restrict__ blk_off) {
   int p = 0;
   while (blockIdx.x >= blk_off[p + 1]) ++p;
   const MbkP P = probs[p];
-  const long long i0 = ((long long)blockIdx.x - blk_off[p]) * (kAsgThreads * kAsgPts) + threadIdx.x;
-  double x0[kAsgPts], x1[kAsgPts], x2[kAsgPts], bd[kAsgPts];
-  int bj[kAsgPts];
-#pragma unroll
-  for (int q = 0; q < kAsgPts; ++q) {
-    const long long i = i0 + (long long)q * kAsgThreads;
-    const uint32_t kk = i < P.n ? keys[P.off + i] : 0u;
-    x0[q] = (double)key_r(kk); x1[q] = (double)key_g(kk); x2[q] = (double)key_b(kk);
-    bd[q] = INFINITY; bj[q] = 0;
-  }
-  const int k = (int)P.k;
-  for (int j0 = 0; j0 < k; j0 += kAsgTile) {
-    const int nj = min(kAsgTile, k - j0);
-    __syncthreads();
-    for (int i = threadIdx.x; i < nj * 4; i += kAsgThreads) {
-      const double v = centres[(P.koff + j0) * 4 + i];
-      sc[i] = (i & 3) == 3 ? v : -2.0 * v;
+  const long long i = ((long long)blockIdx.x - blk_off[p]) * 256 + threadIdx.x;
+  if (i >= P.n) return;
+  const uint32_t kk = keys[P.off + i];
+  const double x0 = (double)key_r(kk), x1 = (double)key_g(kk), x2 = (double)key_b(kk);
+  const double xsq = (x0 * x0 + x1 * x1) + x2 * x2;
+  const int cx = (int)key_r(kk) / kCellSide, cy = (int)key_g(kk) / kCellSide, cz = (int)key_b(kk) / kCellSide;
+  const uint32_t* cs = cell_start + (size_t)p * (kGridCells + 1);
+  const uint32_t* ord = order + P.koff;
+  const double* C = centres + P.koff * 4;
+  double bd = INFINITY;
+  int bj = 0x7fffffff;
+  for (int r = 0; r < kGridG; ++r) {
+    // everything outside the cube of rings <= r-1 is at least (r-1)*8 + (distance to the own cell's wall) >=
+    // (r - 1) * 8 away (r >= 1); 1e-6 dwarfs the float64 error of bd + xsq (values <= 4e5)
+    if (r >= 2) {
+      const double lb = (double)((r - 1) * kCellSide);
+      if (bd + xsq <= lb * lb - 1e-6) break;
     }
-    __syncthreads();
-    for (int j = 0; j < nj; ++j) {
-      const double c0 = sc[j * 4], c1 = sc[j * 4 + 1], c2 = sc[j * 4 + 2], cs = sc[j * 4 + 3];
-#pragma unroll
-      for (int q = 0; q < kAsgPts; ++q) {
-        const double d = cs + ((x0[q] * c0 + x1[q] * c1) + x2[q] * c2);
-        if (d < bd[q]) { bd[q] = d; bj[q] = j0 + j; }
+    const int zlo = max(cz - r, 0), zhi = min(cz + r, kGridG - 1);
+    for (int ix = max(cx - r, 0); ix <= min(cx + r, kGridG - 1); ++ix) {
+      const int ax = abs(ix - cx);
+      for (int iy = max(cy - r, 0); iy <= min(cy + r, kGridG - 1); ++iy) {
+        const bool shell_xy = ax == r || abs(iy - cy) == r;
+        // on the shell in x or y: the whole z range of the ring; otherwise only its two z faces
+        for (int iz = zlo; iz <= zhi; iz += (shell_xy ? 1 : max(zhi - zlo, 1))) {
+          if (!shell_xy && abs(iz - cz) != r) continue;
+          const int cell = (ix * kGridG + iy) * kGridG + iz;
+          const uint32_t e0 = cs[cell], e1 = cs[cell + 1];
+          for (uint32_t e = e0; e < e1; ++e) {
+            const int j = (int)ord[e];
+            const double* c = C + (size_t)j * 4;
+            const double d = c[3] + (-2.0 * ((x0 * c[0] + x1 * c[1]) + x2 * c[2]));
+            if (d < bd || (d == bd && j < bj)) { bd = d; bj = j; }
+          }
+        }
       }
     }
   }
-#pragma unroll
-  for (int q = 0; q < kAsgPts; ++q) {
-    const long long i = i0 + (long long)q * kAsgThreads;
-    if (i < P.n) labels[P.off + i] = bj[q];
-  }
+  labels[P.off + i] = bj;
 }
 
 static int ensure_scratch(rhccq_ctx* ctx, size_t bytes) {
@@ -890,6 +944,9 @@ int64_t rhccq_mbk_work_bytes(const rhccq_mbk_problem* probs, int32_t n_prob) {
   for (int i = 0; i < n_prob; ++i) part += (size_t)((probs[i].k + kTileC - 1) / kTileC) * kBatch;
   size_t bytes = align256(sizeof(MbkP) * n_prob) + align256(8 * (size_t)n_prob) + align256(8 * (size_t)(n_prob + 1));
   bytes += align256(part * 8) + align256(part * 4);
+  size_t ksum = 0;
+  for (int i = 0; i < n_prob; ++i) ksum += (size_t)probs[i].k;
+  bytes += align256((size_t)n_prob * (kGridCells + 1) * 4) + align256((size_t)n_prob * kGridCells * 4) + align256(ksum * 4);
   return (int64_t)bytes;
 }
 
@@ -899,6 +956,10 @@ struct WorkView {
   long long* blk_off;
   double* pdist;
   int32_t* pidx;
+  uint32_t* cell_start;   // [n_prob][cells + 1]
+  uint32_t* cursor;       // [n_prob][cells]
+  uint32_t* order;        // [sum k] centre indices grouped by cell (problem-relative)
+  long long max_k;
 };
 
 static int layout_work(rhccq_ctx* ctx, const rhccq_mbk_problem* probs, int n_prob, void* work, int64_t work_bytes, WorkView* v,
@@ -925,11 +986,16 @@ static int layout_work(rhccq_ctx* ctx, const rhccq_mbk_problem* probs, int n_pro
     mt = tiles > mt ? tiles : mt;
     part += (size_t)tiles * kBatch;
     hbo[i] = blocks;
-    blocks += (q.n + kAsgThreads * kAsgPts - 1) / (kAsgThreads * kAsgPts);
+    blocks += (q.n + 255) / 256;
   }
   hbo[n_prob] = blocks;
   v->pdist = (double*)base; base += align256(part * 8);
-  v->pidx = (int32_t*)base;
+  v->pidx = (int32_t*)base; base += align256(part * 4);
+  v->cell_start = (uint32_t*)base; base += align256((size_t)n_prob * (kGridCells + 1) * 4);
+  v->cursor = (uint32_t*)base; base += align256((size_t)n_prob * kGridCells * 4);
+  v->order = (uint32_t*)base;
+  v->max_k = 0;
+  for (int i = 0; i < n_prob; ++i) v->max_k = probs[i].k > v->max_k ? probs[i].k : v->max_k;
   if (int e = put(ctx, v->probs, hp, sizeof(MbkP) * n_prob)) return e;
   if (int e = put(ctx, v->part_off, hpo, 8 * (size_t)n_prob)) return e;
   if (int e = put(ctx, v->blk_off, hbo, 8 * (size_t)(n_prob + 1))) return e;
@@ -1010,7 +1076,13 @@ int rhccq_mbk_assign(rhccq_ctx* ctx, const uint32_t* keys, const rhccq_mbk_probl
   int max_tiles;
   if (int e = layout_work(ctx, probs, n_prob, work, work_bytes, &v, &blocks, &max_tiles)) return e;
   if (blocks > 0x7fffffffll) return rhccq_fail(ctx, RHCCQ_E_LIMIT, "mbk_assign: too many points");
-  hipLaunchKernelGGL(mbk_assign_kernel, dim3((unsigned)blocks), dim3(kAsgThreads), 0, ctx->stream, keys, v.probs, centres, labels_out, v.blk_off);
+  RHCCQ_HIP(ctx, hipMemsetAsync(v.cell_start, 0, (size_t)n_prob * (kGridCells + 1) * 4, ctx->stream));
+  const dim3 gk((unsigned)((v.max_k + 255) / 256), n_prob);
+  hipLaunchKernelGGL(grid_count_kernel, gk, dim3(256), 0, ctx->stream, v.probs, centres, v.cell_start);
+  hipLaunchKernelGGL(grid_scan_kernel, dim3(n_prob), dim3(1024), 0, ctx->stream, v.cell_start, v.cursor);
+  hipLaunchKernelGGL(grid_fill_kernel, gk, dim3(256), 0, ctx->stream, v.probs, centres, v.cursor, v.order);
+  hipLaunchKernelGGL(mbk_assign_grid_kernel, dim3((unsigned)blocks), dim3(256), 0, ctx->stream, keys, v.probs, centres, v.cell_start, v.order,
+                     labels_out, v.blk_off);
   RHCCQ_LAUNCH_CHECK(ctx);
   return 0;
 }

@@ -52,12 +52,15 @@ __device__ __forceinline__ uint32_t key_r(uint32_t k) { return (k >> 16) & 255u;
 __device__ __forceinline__ uint32_t key_g(uint32_t k) { return (k >> 8) & 255u; }
 __device__ __forceinline__ uint32_t key_b(uint32_t k) { return k & 255u; }
 
-// exact integer squared distance between two packed colours
+// exact integer squared distance between two packed colours (top byte 0): |a|^2 + |b|^2 - 2 a.b with the
+// packed 4 x u8 dot product of gfx950 (v_dot4_u32_u8): 3 instructions + 2 instead of unpack / sub / mul chains
+__device__ __forceinline__ unsigned norm2_key(uint32_t a) { return __builtin_amdgcn_udot4(a, a, 0u, false); }
 __device__ __forceinline__ int dist2_keys(uint32_t a, uint32_t b) {
-  int dr = (int)key_r(a) - (int)key_r(b);
-  int dg = (int)key_g(a) - (int)key_g(b);
-  int db = (int)key_b(a) - (int)key_b(b);
-  return __mul24(dr, dr) + __mul24(dg, dg) + __mul24(db, db);
+  return (int)(norm2_key(a) + norm2_key(b) - 2u * __builtin_amdgcn_udot4(a, b, 0u, false));
+}
+// same with the centre's norm precomputed (wave-uniform candidates)
+__device__ __forceinline__ unsigned dist2_keys_n(uint32_t a, unsigned na, uint32_t b) {
+  return na + norm2_key(b) - 2u * __builtin_amdgcn_udot4(a, b, 0u, false);
 }
 
 template <typename T>
