@@ -68,10 +68,12 @@ def roofline_probe(rh, rgb, specs, iters=5):
     total = 0.0
     for it in range(iters + 1):
         bitmaps, stats = rh.new_job_state(n_jobs)
+        bytemaps = rh.zeros((n_jobs, 1 << 24), torch.uint8)      # byte colour flags, cleared like in a real frame
         torch.cuda.synchronize()
         ev0, ev1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+        n, ptrs, bases = rh._class_args(labels, job_base)
         ev0.record(rh.stream)
-        rh.job_scan(rgb, labels, job_base, bitmaps, stats, black_is_colour=False)
+        rh._check(rh.lib.rhccq_job_scan_bytes(rh.ctx, rh._p(rgb), H, W, n, ptrs, bases, 0, rh._p(bytemaps), rh._p(stats)), "job_scan_bytes")
         ev1.record(rh.stream)
         torch.cuda.synchronize()
         if it > 0:                                  # first launch = warm-up
@@ -79,9 +81,18 @@ def roofline_probe(rh, rgb, specs, iters=5):
     t = total / iters
     px = H * W
     algo_bytes = px * (3 + 4 * len(specs))          # RGB + one int32 label per class, read once
-    return {"bound": "hbm", "kernel": "job_scan_kernel", "achieved": algo_bytes / t / 1e9, "peak": HBM_PEAK_GBS,
-            "unit": "GB/s", "frac": algo_bytes / t / 1e9 / HBM_PEAK_GBS, "traffic": None,
-            "algorithmic_bytes_per_launch": algo_bytes, "avg_launch_s": t}
+    # HBM traffic per launch from the PMC passes kept under profiles/ (separate FETCH_SIZE / WRITE_SIZE runs of
+    # this command; FETCH_SIZE doubled as MI355X_MICROARCH.md prescribes for wide coalesced reads on gfx950)
+    traffic = None
+    pmc = os.path.join(ROOT, "profiles", "r01_pmc_fetch_write_kb.json")
+    if os.path.exists(pmc):
+        rec = json.load(open(pmc)).get("void rhccq::job_scan_kernel<true>")
+        if rec and H * W == 3840 * 2160:
+            traffic = (2 * rec["FETCH_SIZE"]["mean"] + rec["WRITE_SIZE"]["mean"]) * 1024
+    return {"bound": "hbm", "kernel": "job_scan_kernel<true>", "achieved": algo_bytes / t / 1e9, "peak": HBM_PEAK_GBS,
+            "unit": "GB/s", "frac": algo_bytes / t / 1e9 / HBM_PEAK_GBS, "traffic": traffic,
+            "algorithmic_bytes_per_launch": algo_bytes, "avg_launch_s": t,
+            "note": "per-pixel passes are < 0.3 % of the step; the step is bound by the sequential k-means++ chain (mbk_init_kernel)"}
 
 
 def neighbour_probe(rh):
@@ -135,7 +146,7 @@ def main():
     ap.add_argument("--quality", type=int, default=20, help="one ROI quality tier (configs[1])")
     ap.add_argument("--sigma", type=float, default=2.0, help="sensor-noise sigma of the synthetic photo")
     ap.add_argument("--block", type=int, default=8)
-    ap.add_argument("--cpu-sample", type=int, default=320, help="edge of the CPU-baseline crop (0 = skip)")
+    ap.add_argument("--cpu-sample", type=int, default=640, help="edge of the CPU-baseline crop (0 = skip)")
     ap.add_argument("--no-probes", action="store_true")
     args = ap.parse_args()
 

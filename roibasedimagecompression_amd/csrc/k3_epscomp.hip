@@ -40,6 +40,15 @@ __device__ __forceinline__ uint32_t uf_find(uint32_t* parent, uint32_t i) {
   }
 }
 
+// read-only root lookup (labelling phase: no thread may write parent[] while others still walk it)
+__device__ __forceinline__ uint32_t uf_root(const uint32_t* parent, uint32_t i) {
+  while (true) {
+    const uint32_t p = parent[i];
+    if (p == i) return i;
+    i = p;
+  }
+}
+
 __device__ __forceinline__ void uf_union(uint32_t* parent, uint32_t a, uint32_t b) {
   while (true) {
     a = uf_find(parent, a);
@@ -202,12 +211,13 @@ __device__ void eps_components_body(const uint32_t* __restrict__ gkeys, int n, i
   }
   __syncthreads();
   // K4 labelling: root = smallest member index; label = rank of the root among roots
-  for (int i = tid; i < n; i += blockDim.x) A.perm[i] = 0;
+  // roots first into perm[] (read-only walk), then parent[] = root, perm[] = is_root
+  for (int i = tid; i < n; i += blockDim.x) A.perm[i] = uf_root(A.parent, i);
   __syncthreads();
   for (int i = tid; i < n; i += blockDim.x) {
-    const uint32_t r = uf_find(A.parent, i);
-    A.parent[i] = r;                                    // full compression (own entry only)
-    if (r == (uint32_t)i) A.perm[i] = 1;
+    const uint32_t r = A.perm[i];
+    A.parent[i] = r;
+    A.perm[i] = r == (uint32_t)i ? 1u : 0u;
   }
   __syncthreads();
   {
@@ -228,13 +238,190 @@ __device__ void eps_components_body(const uint32_t* __restrict__ gkeys, int n, i
   for (int i = tid; i < n; i += blockDim.x) labels_out[i] = (int32_t)A.perm[A.parent[i]];
 }
 
+// ---- fast path: the whole problem in LDS, up to 30^3 cells held as packed u16 pairs ------------------
+constexpr int kFastG = 30;
+constexpr int kFastCells = kFastG * kFastG * kFastG;      // 27000
+constexpr int kFastWords = (kFastCells + 2 + 1) / 2;      // u16 cell table (cells + sentinel) as u32 words
+
+__device__ __forceinline__ unsigned cell16(const uint32_t* tab, int c) { return (tab[c >> 1] >> ((c & 1) * 16)) & 0xffffu; }
+
+__global__ __launch_bounds__(kEpsThreads) void eps_components_lds_kernel(const uint32_t* __restrict__ keys, const int32_t* __restrict__ desc,
+                                                                          const double* __restrict__ r2v, int32_t* __restrict__ labels_out,
+                                                                          int32_t* __restrict__ ncomp_out) {
+  __shared__ uint32_t s_keys[RHCCQ_EPS_LDS_MAX];
+  __shared__ uint32_t s_parent[RHCCQ_EPS_LDS_MAX];
+  __shared__ unsigned short s_perm[RHCCQ_EPS_LDS_MAX];
+  __shared__ uint32_t s_cell[kFastWords];
+  __shared__ unsigned s_red[16];
+  const int p = blockIdx.x, tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, n_waves = kEpsThreads / 64;
+  const int off = desc[p * 4 + 0], n = desc[p * 4 + 1], thr = desc[p * 4 + 2], boundary = desc[p * 4 + 3];
+  if (n <= 0) {
+    if (tid == 0) ncomp_out[p] = 0;
+    return;
+  }
+  if (n > RHCCQ_EPS_LDS_MAX) return;                    // handled by eps_components_kernel
+  const double r2 = r2v[p];
+  const int reach2 = boundary >= 0 ? boundary : thr;
+  // cell side: the clique side (3 (s-1)^2 <= thr) when the grid then fits, else the smallest side that fits
+  int s = 1;
+  while (3 * s * s <= thr) ++s;
+  const int s_min = (255 / kFastG) + 1;                 // 9
+  const bool clique = s >= s_min;
+  if (!clique) s = s_min;
+  const int G = (255 / s) + 1, n_cells = G * G * G;
+  auto cell_of = [&](uint32_t k) { return ((int)key_r(k) / s * G + (int)key_g(k) / s) * G + (int)key_b(k) / s; };
+  for (int i = tid; i < n; i += kEpsThreads) { s_keys[i] = keys[off + i]; s_parent[i] = i; }
+  for (int w = tid; w < kFastWords; w += kEpsThreads) s_cell[w] = 0;
+  __syncthreads();
+  // histogram into entry cell+0 (packed u16), inclusive scan -> ends, scatter by decrementing ends -> starts
+  for (int i = tid; i < n; i += kEpsThreads) {
+    const int c = cell_of(s_keys[i]);
+    atomicAdd(&s_cell[c >> 1], 1u << ((c & 1) * 16));
+  }
+  __syncthreads();
+  {
+    const int per = (n_cells + kEpsThreads - 1) / kEpsThreads;
+    const int lo = min(tid * per, n_cells), hi = min(lo + per, n_cells);
+    unsigned sum = 0;
+    for (int c = lo; c < hi; ++c) sum += cell16(s_cell, c);
+    unsigned tot;
+    unsigned base = block_exscan<unsigned>(sum, s_red, &tot);
+    __syncthreads();
+    // two neighbouring threads may share a u32 word: write through 16-bit stores
+    unsigned short* c16 = reinterpret_cast<unsigned short*>(s_cell);
+    for (int c = lo; c < hi; ++c) {
+      base += c16[c];
+      c16[c] = (unsigned short)base;                    // end of cell c
+    }
+    if (tid == 0) c16[n_cells] = (unsigned short)n;    // sentinel
+  }
+  __syncthreads();
+  for (int i = tid; i < n; i += kEpsThreads) {
+    const int c = cell_of(s_keys[i]);
+    const unsigned old = atomicSub(&s_cell[c >> 1], 1u << ((c & 1) * 16));
+    const unsigned pos = ((old >> ((c & 1) * 16)) & 0xffffu) - 1u;
+    s_perm[pos] = (unsigned short)i;
+  }
+  __syncthreads();
+  // now cell16(c) = start of cell c, cell16(c+1) = its end (the next start / the sentinel)
+  if (clique) {
+    for (int q = tid; q < n; q += kEpsThreads) {
+      const uint32_t i = s_perm[q];
+      const uint32_t rep = s_perm[cell16(s_cell, cell_of(s_keys[i]))];
+      if (rep != i) uf_union(s_parent, i, rep);
+    }
+    __syncthreads();
+  }
+  int R = 0;
+  while ((long long)(R * s) * (R * s) <= reach2 + 0ll && R < G) ++R;
+  const int span = 2 * R + 1, n_off = span * span * span;
+  // one wave per non-empty cell A (found as the heads of the cell-sorted point list); its lanes test the
+  // neighbour offsets 64 at a time, then the wave searches each surviving cell pair
+  for (int q0 = wave * 64; q0 < n; q0 += n_waves * 64) {
+    const int q = q0 + lane;
+    int ca = -1;
+    if (q < n) {
+      const int c = cell_of(s_keys[s_perm[q]]);
+      if ((int)cell16(s_cell, c) == q) ca = c;          // q is the first point of its cell
+    }
+    unsigned long long heads = __ballot(ca >= 0);
+    while (heads) {
+      const int hl = __ffsll((long long)heads) - 1;
+      heads &= heads - 1;
+      const int A = __shfl(ca, hl, 64);
+      const unsigned a0 = cell16(s_cell, A), na = cell16(s_cell, A + 1) - a0;
+      const int ax = A / (G * G), ay = (A / G) % G, az = A % G;
+      const uint32_t repa = s_perm[a0];
+      for (int ob = 0; ob < n_off; ob += 64) {
+        const int o = ob + lane;
+        int B = -1;
+        if (o < n_off) {
+          const int dz = o % span - R, dy = (o / span) % span - R, dx = o / (span * span) - R;
+          const bool fwd = dx > 0 || (dx == 0 && (dy > 0 || (dy == 0 && dz >= 0)));
+          const bool same = dx == 0 && dy == 0 && dz == 0;
+          const int bx = ax + dx, by = ay + dy, bz = az + dz;
+          if (fwd && !(same && clique) && bx >= 0 && bx < G && by >= 0 && by < G && bz >= 0 && bz < G) {
+            const int gx = dx ? (abs(dx) - 1) * s + 1 : 0, gy = dy ? (abs(dy) - 1) * s + 1 : 0, gz = dz ? (abs(dz) - 1) * s + 1 : 0;
+            const int cb = (bx * G + by) * G + bz;
+            if (gx * gx + gy * gy + gz * gz <= reach2 && cell16(s_cell, cb + 1) > cell16(s_cell, cb)) B = cb;
+          }
+        }
+        unsigned long long mb = __ballot(B >= 0);
+        while (mb) {
+          const int bl = __ffsll((long long)mb) - 1;
+          mb &= mb - 1;
+          const int cb = __shfl(B, bl, 64);
+          const unsigned b0 = cell16(s_cell, cb), nbp = cell16(s_cell, cb + 1) - b0;
+          const unsigned total = na * nbp;
+          if (clique) {
+            const uint32_t repb = s_perm[b0];
+            if (uf_find(s_parent, repa) == uf_find(s_parent, repb)) continue;
+            for (unsigned base = 0; base < total; base += 64) {
+              const unsigned pp = base + lane;
+              bool hit = false;
+              if (pp < total) hit = is_neighbor(s_keys[s_perm[a0 + pp / nbp]], s_keys[s_perm[b0 + pp % nbp]], thr, boundary, r2);
+              if (__any(hit)) {
+                if (lane == 0) uf_union(s_parent, repa, repb);
+                break;
+              }
+            }
+          } else {
+            const bool same = cb == A;
+            for (unsigned base = 0; base < total; base += 64) {
+              const unsigned pp = base + lane;
+              if (pp < total) {
+                const unsigned ia = pp / nbp, ib = pp % nbp;
+                if (!same || ia < ib) {
+                  const uint32_t i = s_perm[a0 + ia], j = s_perm[b0 + ib];
+                  if (is_neighbor(s_keys[i], s_keys[j], thr, boundary, r2)) uf_union(s_parent, i, j);
+                }
+              }
+            }
+          }
+        }
+      }
+    }
+  }
+  __syncthreads();
+  // K4 labelling: root = smallest member index; label = rank of the root among roots
+  {
+    constexpr int kPer = (RHCCQ_EPS_LDS_MAX + kEpsThreads - 1) / kEpsThreads;   // 20 points per thread
+    uint32_t root[kPer];
+#pragma unroll
+    for (int j = 0; j < kPer; ++j) {
+      const int i = tid + j * kEpsThreads;
+      root[j] = i < n ? uf_root(s_parent, i) : 0u;     // nobody writes parent[] here
+    }
+    __syncthreads();
+#pragma unroll
+    for (int j = 0; j < kPer; ++j) {
+      const int i = tid + j * kEpsThreads;
+      if (i < n) { s_parent[i] = root[j]; s_perm[i] = root[j] == (uint32_t)i ? 1 : 0; }
+    }
+  }
+  __syncthreads();
+  {
+    const int per = (n + kEpsThreads - 1) / kEpsThreads;
+    const int lo = min(tid * per, n), hi = min(lo + per, n);
+    unsigned sum = 0;
+    for (int i = lo; i < hi; ++i) sum += s_perm[i];
+    unsigned tot;
+    unsigned base = block_exscan<unsigned>(sum, s_red, &tot);
+    for (int i = lo; i < hi; ++i) {
+      const unsigned f = s_perm[i];
+      s_perm[i] = (unsigned short)base;
+      base += f;
+    }
+    if (tid == 0) ncomp_out[p] = (int32_t)tot;
+  }
+  __syncthreads();
+  for (int i = tid; i < n; i += kEpsThreads) labels_out[off + i] = (int32_t)s_perm[s_parent[i]];
+}
+
 __global__ __launch_bounds__(kEpsThreads) void eps_components_kernel(const uint32_t* __restrict__ keys, const int32_t* __restrict__ desc,
                                                                       const double* __restrict__ r2, int32_t* __restrict__ labels_out,
                                                                       int32_t* __restrict__ ncomp_out, uint32_t* __restrict__ gwork,
                                                                       int work_stride) {
-  __shared__ uint32_t s_keys[RHCCQ_EPS_LDS_MAX];
-  __shared__ uint32_t s_parent[RHCCQ_EPS_LDS_MAX];
-  __shared__ uint32_t s_perm[RHCCQ_EPS_LDS_MAX];
   __shared__ unsigned s_cell_start[kMaxCells + 1];
   __shared__ unsigned s_cell_fill[kMaxCells];
   __shared__ unsigned s_red[16];
@@ -246,8 +433,7 @@ __global__ __launch_bounds__(kEpsThreads) void eps_components_kernel(const uint3
   }
   EpsArrays A;
   if (n <= RHCCQ_EPS_LDS_MAX) {
-    A.keys = s_keys; A.parent = s_parent; A.perm = s_perm;
-    eps_components_body<true>(keys + off, n, thr, boundary, r2[p], labels_out + off, ncomp_out + p, A, s_cell_start, s_cell_fill, s_red);
+    return;                                             // handled by eps_components_lds_kernel
   } else {
     uint32_t* w = gwork + (size_t)p * 3 * work_stride;
     A.keys = w; A.parent = w + work_stride; A.perm = w + 2 * (size_t)work_stride;
@@ -278,7 +464,9 @@ extern "C" int rhccq_eps_components(rhccq_ctx* ctx, const uint32_t* keys, const 
     }
     gwork = (uint32_t*)ctx->scratch;
   }
-  hipLaunchKernelGGL(eps_components_kernel, dim3(n_prob), dim3(kEpsThreads), 0, ctx->stream, keys, desc, r2, labels_out, ncomp_out, gwork, stride);
+  hipLaunchKernelGGL(eps_components_lds_kernel, dim3(n_prob), dim3(kEpsThreads), 0, ctx->stream, keys, desc, r2, labels_out, ncomp_out);
+  if (max_n > RHCCQ_EPS_LDS_MAX)
+    hipLaunchKernelGGL(eps_components_kernel, dim3(n_prob), dim3(kEpsThreads), 0, ctx->stream, keys, desc, r2, labels_out, ncomp_out, gwork, stride);
   RHCCQ_LAUNCH_CHECK(ctx);
   return 0;
 }
