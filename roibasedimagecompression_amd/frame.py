@@ -163,11 +163,10 @@ class FrameEncoder:
         d_pal_off = rh.dev(pal_off[:-1].copy())
         total = int(pal_off[-1])
         prefix, keys_dev = rh.bitmap_emit(bitmaps, chunk, d_pal_off, total)
-        keys_all = keys_dev[:total].cpu().numpy().view(np.uint32)
         self._t("unique", t0)
         return {"H": H, "W": W, "rgb": rgb, "classes": classes, "labels": labels, "job_base": job_base, "n_jobs": n_jobs,
                 "bitmaps": bitmaps, "prefix": prefix, "pal_off": pal_off, "d_pal_off": d_pal_off, "fix_key": fix_key,
-                "keys_all": keys_all, "P": P, "present": present, "job_class": job_class,
+                "keys_dev": keys_dev, "has_black": has_bg | all_black, "P": P, "present": present, "job_class": job_class,
                 "job_region": job_region, "crop": (r0, r1, c0, c1), "total": total}
 
     def level1(self, S):
@@ -181,7 +180,9 @@ class FrameEncoder:
         for j in np.nonzero(S["present"])[0]:
             q = classes[S["job_class"][j]].quality
             eps, _, mc = clustering_params(int(S["P"][j]), q)
-            jobs.append({"keys": S["keys_all"][pal_off[j]:pal_off[j + 1]], "quality": q, "eps": eps, "mc": mc})
+            # the sorted palette stays in HBM; small palettes are copied to the host inside cluster_palettes
+            jobs.append({"keys_dev": S["keys_dev"][pal_off[j]:pal_off[j + 1]], "has_black": bool(S["has_black"][j]),
+                         "quality": q, "eps": eps, "mc": mc})
             job_ids.append(j)
         res = cluster_palettes(rh, jobs)
         self._t("level1_cluster", t0)
@@ -190,16 +191,28 @@ class FrameEncoder:
         # merging.py:77-79): one streaming pass whose atomicMin table is only sum(K_j) entries
         seg_comp = {}
         new_off = np.concatenate([[0], np.cumsum([len(nk) for nk, _, _ in res])]).astype(np.int64)
-        fp_lut = np.zeros(max(S["total"], 1), np.int32)
+        lut1 = torch.zeros((max(S["total"], 1),), dtype=torch.int32, device=rh.device)
+        host_parts, host_slices = [], []
         for i, (j, (nk, mp, info)) in enumerate(zip(job_ids, res)):
-            fp_lut[pal_off[j]:pal_off[j + 1]] = new_off[i] + mp
-        S["lut1"] = rh.dev(fp_lut)                                         # (job, rank) -> global clustered-palette entry
+            if mp is None:                                                  # mapping resident on the device
+                lut1[pal_off[j]:pal_off[j + 1]] = info["mapping_dev"] + int(new_off[i])
+            else:
+                host_parts.append((new_off[i] + mp).astype(np.int32))
+                host_slices.append((int(pal_off[j]), int(pal_off[j + 1])))
+        if host_parts:
+            flat = rh.dev(np.concatenate(host_parts))
+            o = 0
+            for a, b in host_slices:
+                lut1[a:b] = flat[o:o + (b - a)]
+                o += b - a
+        S["lut1"] = lut1                                                   # (job, rank) -> global clustered-palette entry
         S["k1_off"] = {int(j): (int(new_off[i]), int(new_off[i + 1])) for i, j in enumerate(job_ids)}
         S["k1_total"] = int(new_off[-1])
         fp_new_all = self.first_positions(S, S["lut1"], int(new_off[-1]))
         for i, (j, (nk, mp, info)) in enumerate(zip(job_ids, res)):
             seg_comp[j] = _Comp(nk, fp_new_all[new_off[i]:new_off[i + 1]], (int(r0[j]), int(c0[j])),
                                 (int(r1[j] - r0[j] + 1), int(c1[j] - c0[j] + 1)), {int(j): np.arange(len(nk), dtype=np.int32)}, False)
+
         per_class = []
         for ci, cls in enumerate(classes):
             regs = []

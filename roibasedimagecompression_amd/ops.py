@@ -316,16 +316,20 @@ class Rhccq:
         return out[:k], sums[:k]
 
     # -- K8 -----------------------------------------------------------------------------------------
-    def minibatch_kmeans(self, key_list, k_list, return_info=False, poll_steps=64):
+    def minibatch_kmeans(self, key_list, k_list, return_info=False, poll_steps=64, return_device=False):
         """Batched MiniBatchKMeans(k, batch_size=1000, random_state=42).fit_predict labels in the
-        canonical arithmetic of oracle.minibatch_kmeans_labels.  numpy in / numpy out."""
+        canonical arithmetic of oracle.minibatch_kmeans_labels.  key_list items are numpy arrays or
+        device int32 tensors (kept resident); labels come back as numpy arrays, or as device tensors
+        with return_device=True."""
         n_prob = len(key_list)
         if n_prob == 0:
             return ([], []) if return_info else []
         probs = (MbkProblem * n_prob)()
-        sizes = [len(k) for k in key_list]
+        sizes = [int(k.numel()) if torch.is_tensor(k) else len(k) for k in key_list]
         offs = np.concatenate([[0], np.cumsum(sizes)]).astype(np.int64)
         koff = np.concatenate([[0], np.cumsum(k_list)]).astype(np.int64)
+        parts = [k if torch.is_tensor(k) else self.dev(np.ascontiguousarray(np.asarray(k)).astype(np.uint32).view(np.int32)) for k in key_list]
+        keys = parts[0] if n_prob == 1 else torch.cat(parts)
         init_list, rand_list = [], []
         ioff = roff = 0
         max_steps = 0
@@ -340,7 +344,11 @@ class Rhccq:
             init_idx = rs.randint(0, n, init_size) if init_size < n else np.arange(n)
             # canonical sample order: (Morton code of the colour, index): 64 consecutive samples form a
             # compact box, which is what the exact block pruning of mbk_init_kernel relies on
-            init_idx = init_idx[np.lexsort((init_idx, morton3(np.asarray(key_list[i])[init_idx])))]
+            if torch.is_tensor(key_list[i]):
+                skeys = key_list[i][torch.from_numpy(init_idx).to(self.device)].cpu().numpy().view(np.uint32)
+            else:
+                skeys = np.asarray(key_list[i])[init_idx]
+            init_idx = init_idx[np.lexsort((init_idx, morton3(skeys)))]
             T = 2 + int(math.log(k))
             first = first_centre_index(init_size, rs.random_sample())
             u = rs.uniform(size=max((k - 1) * T, 1))
@@ -352,7 +360,6 @@ class Rhccq:
             ioff += init_size
             roff += len(u)
             max_steps = max(max_steps, (100 * n) // bs)
-        keys = self.dev(np.concatenate([np.asarray(k).astype(np.int64) for k in key_list]).astype(np.int32))
         d_init = self.dev(np.concatenate(init_list))
         d_rand = self.dev(np.concatenate(rand_list))
         K = int(koff[-1])
@@ -378,8 +385,11 @@ class Rhccq:
         labels = self.empty((int(offs[-1]),), torch.int32)
         self._check(self.lib.rhccq_mbk_assign(self.ctx, self._p(keys), probs, n_prob, self._p(centres), self._p(work), wbytes,
                                               self._p(labels)), "mbk_assign")
-        lab = labels.cpu().numpy()
-        out = [lab[offs[i]:offs[i + 1]] for i in range(n_prob)]
+        if return_device:
+            out = [labels[offs[i]:offs[i + 1]] for i in range(n_prob)]
+        else:
+            lab = labels.cpu().numpy()
+            out = [lab[offs[i]:offs[i + 1]] for i in range(n_prob)]
         if return_info:
             return out, {"state": state.cpu().numpy(), "centres": centres.cpu().numpy(), "chosen": chosen.cpu().numpy(),
                          "koff": koff, "weights": weights.cpu().numpy()}

@@ -37,18 +37,70 @@ def _n_splits(n, mc):
     return ns
 
 
+def _cluster_resident(rh, jobs, idxs, results):
+    """MiniBatch-branch jobs whose sorted palette is resident on the device (`keys_dev`, black only at
+    index 0): labels, member sums and the palette -> new-palette mapping stay in HBM; only k-sized
+    tables cross PCIe.  Jobs that turn out to have an oversize cluster fall back to the host path."""
+    fallback = []
+    ks, parts = [], []
+    for s in idxs:
+        jb = jobs[s]
+        nbk = jb["keys_dev"][1:] if jb["has_black"] else jb["keys_dev"]
+        parts.append(nbk)
+        ks.append(math.ceil(int(nbk.numel()) * (jb["quality"] / 100) / 10))
+    labs = rh.minibatch_kmeans(parts, ks, return_device=True)
+    for s, nbk, k, lab in zip(idxs, parts, ks, labs):
+        jb = jobs[s]
+        _, sums = rh.cluster_means(nbk, lab, k)
+        sums = sums.cpu().numpy().astype(np.int64)
+        cnt = sums[:, 3]
+        if (cnt > jb["mc"]).any():                         # needs k-means splitting: host path
+            jb["keys"] = jb["keys_dev"].cpu().numpy().view(np.uint32)
+            jb["_labels"] = lab.cpu().numpy()
+            fallback.append(s)
+            continue
+        present = cnt > 0
+        nblack = 1 if jb["has_black"] else 0
+        leaf = np.full(k, 0, np.int64)
+        leaf[present] = np.arange(int(present.sum()))
+        c = np.maximum(cnt[present], 1)
+        means = ((sums[present, 0] // c) << 16) | ((sums[present, 1] // c) << 8) | (sums[present, 2] // c)
+        new_keys = np.concatenate([np.zeros(nblack, np.uint32), means.astype(np.uint32)])
+        lut = ((nblack + leaf) & 0xFFFF).astype(np.int32)   # uint16 mapping_array (clustering.py:373)
+        mapped = rh.remap(lab, rh.dev(lut))
+        mapping_dev = torch.cat([torch.zeros(1, dtype=torch.int32, device=rh.device), mapped]) if nblack else mapped
+        results[s] = (new_keys, None, {"branch": "minibatch", "n_clusters": int(present.sum()), "n_large": 0,
+                                       "mapping_dev": mapping_dev})
+    return fallback
+
+
 def cluster_palettes(rh, jobs):
-    """jobs: list of dicts {keys: uint32[P] palette keys in palette order, quality, eps, mc}.
-    Returns per job (new_keys uint32[K], mapping uint16-valued int32[P], info dict)."""
+    """jobs: list of dicts {keys: uint32[P] palette keys in palette order, quality, eps, mc}; a job may
+    instead carry {keys_dev: device int32[P] sorted keys, has_black} (then its mapping comes back as a
+    device tensor in info["mapping_dev"] and the host mapping is None).
+    Returns per job (new_keys uint32[K], mapping uint16-valued int32[P] or None, info dict)."""
     S = len(jobs)
+    pre = {}
+    resident = [s for s, jb in enumerate(jobs) if "keys_dev" in jb and
+                int(jb["keys_dev"].numel()) - (1 if jb["has_black"] else 0) >= MINIBATCH_THRESHOLD]
+    if resident:
+        _cluster_resident(rh, jobs, resident, pre)
+    for s, jb in enumerate(jobs):
+        if "keys" not in jb and s not in pre:
+            jb["keys"] = jb["keys_dev"].cpu().numpy().view(np.uint32)
     nb_idx, labels = [None] * S, [None] * S
     db_jobs, mb_jobs = [], []
     for s, jb in enumerate(jobs):
+        if s in pre:
+            continue
         keys = np.asarray(jb["keys"]).astype(np.uint32)
         jb["keys"] = keys
         nb_idx[s] = np.nonzero(keys != 0)[0]
         n = len(nb_idx[s])
         if n == 0:
+            continue
+        if "_labels" in jb:                                # resident job that fell back: labels already known
+            labels[s] = jb.pop("_labels")
             continue
         (mb_jobs if n >= MINIBATCH_THRESHOLD else db_jobs).append(s)
     if db_jobs:
@@ -107,6 +159,9 @@ def cluster_palettes(rh, jobs):
     leaf_base = 0
     plan = []
     for s in range(S):
+        if s in pre:
+            plan.append("resident")
+            continue
         keys = jobs[s]["keys"]
         black = np.nonzero(keys == 0)[0]
         if labels[s] is None:
@@ -136,6 +191,9 @@ def cluster_palettes(rh, jobs):
         dl = torch.from_numpy(np.concatenate(all_leaf)).to(rh.device)
         means = rh.cluster_means(dk, dl, leaf_base)[0].cpu().numpy().view(np.uint32)
     for s in range(S):
+        if s in pre:
+            results.append(pre[s])
+            continue
         keys = jobs[s]["keys"]
         P = len(keys)
         if plan[s] is None:                                # only black: returned unchanged (clustering.py:197-199)

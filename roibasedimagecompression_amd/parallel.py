@@ -154,10 +154,9 @@ class TiledFrameEncoder(FrameEncoder):
         d_pal_off = rh.dev(pal_off[:-1].copy())
         total = int(pal_off[-1])
         prefix, keys_dev = rh.bitmap_emit(bitmaps, chunk, d_pal_off, total)
-        keys_all = keys_dev[:total].cpu().numpy().view(np.uint32)
         return {"H": H, "W": W, "rgb": rgb, "classes": classes, "labels": labels, "job_base": job_base, "n_jobs": n_jobs,
                 "bitmaps": bitmaps, "prefix": prefix, "pal_off": pal_off, "d_pal_off": d_pal_off, "fix_key": fix_key,
-                "keys_all": keys_all, "P": P, "present": present, "job_class": job_class,
+                "keys_dev": keys_dev, "has_black": has_bg | all_black, "P": P, "present": present, "job_class": job_class,
                 "job_region": job_region, "crop": (r0, r1, c0, c1), "total": total}
 
     def first_positions(self, S, fp_lut, n_entries):
