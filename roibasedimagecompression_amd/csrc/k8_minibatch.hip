@@ -353,12 +353,28 @@ __device__ __forceinline__ void init_body(const uint32_t* __restrict__ keys, con
         for (int q = 0; q < 8; ++q) it[q] = i0 + q < n_items ? s_items[i0 + q] : 0xffffffffu;
 #pragma unroll
         for (int q = 0; q < 8; ++q) sv[q] = samp[((it[q] == 0xffffffffu ? 0u : (it[q] & 0xffffffu)) << 6) + lane];
+        // consecutive items mostly belong to one candidate (a candidate appends its blocks in runs): keep a
+        // per-lane partial sum while the candidate does not change, reduce across the wave only on a change
+        int cur_t = -1;
+        unsigned acc = 0;                                // <= 8 items * 195075 per lane
 #pragma unroll
         for (int q = 0; q < 8; ++q) {
           if (it[q] == 0xffffffffu) continue;
-          const unsigned d = (unsigned)dist2_keys(sh.ckey[it[q] >> 24], sv[q].x);
-          const unsigned sdel = wave_sum_u32(sv[q].y > d ? sv[q].y - d : 0u);
-          if (lane == 0 && sdel) atomicAdd(&sh.delta[it[q] >> 24], (unsigned long long)sdel);
+          const int t = (int)(it[q] >> 24);
+          if (t != cur_t) {
+            if (cur_t >= 0) {
+              const unsigned sdel = wave_sum_u32(acc);
+              if (lane == 0 && sdel) atomicAdd(&sh.delta[cur_t], (unsigned long long)sdel);
+            }
+            cur_t = t;
+            acc = 0;
+          }
+          const unsigned d = (unsigned)dist2_keys(sh.ckey[t], sv[q].x);
+          acc += sv[q].y > d ? sv[q].y - d : 0u;
+        }
+        if (cur_t >= 0) {
+          const unsigned sdel = wave_sum_u32(acc);
+          if (lane == 0 && sdel) atomicAdd(&sh.delta[cur_t], (unsigned long long)sdel);
         }
       }
     } else {

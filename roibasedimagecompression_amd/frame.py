@@ -177,12 +177,27 @@ class FrameEncoder:
         r0, r1, c0, c1 = S["crop"]
         t0 = time.perf_counter()
         jobs, job_ids = [], []
+        # palettes of >= 10 000 colours stay in HBM (MiniBatch branch); the small ones (DBSCAN branch) are
+        # brought to the host in ONE copy
+        nblk = S["has_black"].astype(np.int64)
+        big = S["present"] & (S["P"] - nblk >= 10000)
+        small_ids = np.nonzero(S["present"] & ~big)[0]
+        host_keys = {}
+        if len(small_ids):
+            lo, hi = int(pal_off[small_ids[0]]), int(pal_off[small_ids[-1] + 1])
+            chunk = S["keys_dev"][lo:hi].cpu().numpy().view(np.uint32)
+            for j in small_ids:
+                host_keys[int(j)] = chunk[pal_off[j] - lo:pal_off[j + 1] - lo]
         for j in np.nonzero(S["present"])[0]:
             q = classes[S["job_class"][j]].quality
             eps, _, mc = clustering_params(int(S["P"][j]), q)
-            # the sorted palette stays in HBM; small palettes are copied to the host inside cluster_palettes
-            jobs.append({"keys_dev": S["keys_dev"][pal_off[j]:pal_off[j + 1]], "has_black": bool(S["has_black"][j]),
-                         "quality": q, "eps": eps, "mc": mc})
+            jb = {"quality": q, "eps": eps, "mc": mc}
+            if big[j]:
+                jb["keys_dev"] = S["keys_dev"][pal_off[j]:pal_off[j + 1]]
+                jb["has_black"] = bool(S["has_black"][j])
+            else:
+                jb["keys"] = host_keys[int(j)]
+            jobs.append(jb)
             job_ids.append(j)
         res = cluster_palettes(rh, jobs)
         self._t("level1_cluster", t0)
@@ -191,20 +206,19 @@ class FrameEncoder:
         # merging.py:77-79): one streaming pass whose atomicMin table is only sum(K_j) entries
         seg_comp = {}
         new_off = np.concatenate([[0], np.cumsum([len(nk) for nk, _, _ in res])]).astype(np.int64)
-        lut1 = torch.zeros((max(S["total"], 1),), dtype=torch.int32, device=rh.device)
-        host_parts, host_slices = [], []
-        for i, (j, (nk, mp, info)) in enumerate(zip(job_ids, res)):
-            if mp is None:                                                  # mapping resident on the device
-                lut1[pal_off[j]:pal_off[j + 1]] = info["mapping_dev"] + int(new_off[i])
-            else:
-                host_parts.append((new_off[i] + mp).astype(np.int32))
-                host_slices.append((int(pal_off[j]), int(pal_off[j + 1])))
-        if host_parts:
-            flat = rh.dev(np.concatenate(host_parts))
-            o = 0
-            for a, b in host_slices:
-                lut1[a:b] = flat[o:o + (b - a)]
-                o += b - a
+        any_resident = any(mp is None for _, mp, _ in res)
+        if not any_resident:                                                # all mappings on the host: one upload
+            lut1_host = np.zeros(max(S["total"], 1), np.int32)
+            for i, (j, (nk, mp, info)) in enumerate(zip(job_ids, res)):
+                lut1_host[pal_off[j]:pal_off[j + 1]] = new_off[i] + mp
+            lut1 = rh.dev(lut1_host)
+        else:
+            lut1 = torch.zeros((max(S["total"], 1),), dtype=torch.int32, device=rh.device)
+            for i, (j, (nk, mp, info)) in enumerate(zip(job_ids, res)):
+                if mp is None:                                              # mapping resident on the device
+                    lut1[pal_off[j]:pal_off[j + 1]] = info["mapping_dev"] + int(new_off[i])
+                else:
+                    lut1[pal_off[j]:pal_off[j + 1]] = rh.dev((new_off[i] + mp).astype(np.int32))
         S["lut1"] = lut1                                                   # (job, rank) -> global clustered-palette entry
         S["k1_off"] = {int(j): (int(new_off[i]), int(new_off[i + 1])) for i, j in enumerate(job_ids)}
         S["k1_total"] = int(new_off[-1])
