@@ -146,7 +146,7 @@ def main():
     ap.add_argument("--quality", type=int, default=20, help="one ROI quality tier (configs[1])")
     ap.add_argument("--sigma", type=float, default=2.0, help="sensor-noise sigma of the synthetic photo")
     ap.add_argument("--block", type=int, default=8)
-    ap.add_argument("--cpu-sample", type=int, default=640, help="edge of the CPU-baseline crop (0 = skip)")
+    ap.add_argument("--cpu-sample", type=int, default=576, help="edge of the CPU-baseline crop (0 = skip)")
     ap.add_argument("--no-probes", action="store_true")
     args = ap.parse_args()
 

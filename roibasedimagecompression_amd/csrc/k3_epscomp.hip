@@ -315,9 +315,35 @@ __global__ __launch_bounds__(kEpsThreads) void eps_components_lds_kernel(const u
   int R = 0;
   while ((long long)(R * s) * (R * s) <= reach2 + 0ll && R < G) ++R;
   const int span = 2 * R + 1, n_off = span * span * span;
+  // sparse palettes (about one point per occupied cell, e.g. already-quantised level-2/3 palettes): one
+  // THREAD per point walks the neighbouring cells and unions with every later-listed neighbour in range;
+  // dense palettes: one WAVE per occupied cell pair (below)
+  int n_heads = 0;
+  for (int q = tid; q < n; q += kEpsThreads) n_heads += (int)cell16(s_cell, cell_of(s_keys[s_perm[q]])) == q;
+  n_heads = block_sum<int>(n_heads, reinterpret_cast<int*>(s_red));
+  const bool point_mode = n < 3 * n_heads;
+  if (point_mode) {
+    for (int q = tid; q < n; q += kEpsThreads) {
+      const uint32_t i = s_perm[q];
+      const uint32_t ki = s_keys[i];
+      const int A = cell_of(ki);
+      const int ax = A / (G * G), ay = (A / G) % G, az = A % G;
+      for (int bx = max(ax - R, 0); bx <= min(ax + R, G - 1); ++bx)
+        for (int by = max(ay - R, 0); by <= min(ay + R, G - 1); ++by)
+          for (int bz = max(az - R, 0); bz <= min(az + R, G - 1); ++bz) {
+            const int cb = (bx * G + by) * G + bz;
+            const unsigned b0 = cell16(s_cell, cb), b1 = cell16(s_cell, cb + 1);
+            for (unsigned e = b0; e < b1; ++e) {
+              if ((int)e <= q) continue;                 // each unordered pair once (by position in the cell order)
+              const uint32_t j = s_perm[e];
+              if (is_neighbor(ki, s_keys[j], thr, boundary, r2)) uf_union(s_parent, i, j);
+            }
+          }
+    }
+  }
   // one wave per non-empty cell A (found as the heads of the cell-sorted point list); its lanes test the
   // neighbour offsets 64 at a time, then the wave searches each surviving cell pair
-  for (int q0 = wave * 64; q0 < n; q0 += n_waves * 64) {
+  for (int q0 = wave * 64; q0 < n && !point_mode; q0 += n_waves * 64) {
     const int q = q0 + lane;
     int ca = -1;
     if (q < n) {
