@@ -137,6 +137,23 @@ __device__ __forceinline__ unsigned wave_max_u32(unsigned v) {
   return max(max((unsigned)__builtin_amdgcn_readlane((int)v, 0), (unsigned)__builtin_amdgcn_readlane((int)v, 16)),
              max((unsigned)__builtin_amdgcn_readlane((int)v, 32), (unsigned)__builtin_amdgcn_readlane((int)v, 48)));
 }
+// inclusive scan of one u32 per lane over the wave on DPP (gfx9 row_shr / row_bcast forms): 6 shifted adds on
+// the VALU instead of 6 LDS-crossbar permutes.  The wave total must fit 32 bits.
+__device__ __forceinline__ unsigned wave_incscan_u32(unsigned v) {
+  v += (unsigned)__builtin_amdgcn_update_dpp(0, (int)v, 0x111, 0xF, 0xF, true);   // row_shr:1
+  v += (unsigned)__builtin_amdgcn_update_dpp(0, (int)v, 0x112, 0xF, 0xF, true);   // row_shr:2
+  v += (unsigned)__builtin_amdgcn_update_dpp(0, (int)v, 0x114, 0xF, 0xF, true);   // row_shr:4
+  v += (unsigned)__builtin_amdgcn_update_dpp(0, (int)v, 0x118, 0xF, 0xF, true);   // row_shr:8  -> scan inside each row of 16
+  v += (unsigned)__builtin_amdgcn_update_dpp(0, (int)v, 0x142, 0xA, 0xF, false);  // row_bcast:15 into rows 1 and 3
+  v += (unsigned)__builtin_amdgcn_update_dpp(0, (int)v, 0x143, 0xC, 0xF, false);  // row_bcast:31 into rows 2 and 3
+  return v;
+}
+// exact u64 inclusive scan of values < 2^32 from two u32 scans of 16-bit limbs (limb totals < 2^32)
+__device__ __forceinline__ unsigned long long wave_incscan_limbs(unsigned v) {
+  const unsigned hi = wave_incscan_u32(v >> 16), lo = wave_incscan_u32(v & 0xffffu);
+  return ((unsigned long long)hi << 16) + lo;
+}
+
 __device__ __forceinline__ unsigned long long wave_incscan_u64(unsigned long long v) {
   const int lane = threadIdx.x & 63;
 #pragma unroll
@@ -261,6 +278,10 @@ __device__ __forceinline__ void init_body(const uint32_t* __restrict__ keys, con
     double u_next = 0.0;
     if (tid < T && c + 1 < k) u_next = rand[P.rand_off + (size_t)c * T + tid];
     const unsigned long long pot = sh.pot;
+    // the reductions of this step start from zero; reset here (between the previous step's closing barrier and
+    // this step's first one) -- NOT at the end of the previous step, where slower waves may still be reading
+    // them for the arg-max
+    if (tid < T) sh.delta[tid] = 0;
     const int* touch_r = s_touch + (((c - 1) & 1) ? kMaxTouch : 0);   // list written by the previous step's commit
     const int n_touched = min(sh.n_touch2[(c - 1) & 1], kMaxTouch);
     // ================= phase 1: waves t < T -- pick candidate t, list the blocks it can improve ===========
@@ -275,7 +296,8 @@ __device__ __forceinline__ void init_body(const uint32_t* __restrict__ keys, con
         unsigned long long loc = 0;
         const int s0 = lane * persb;
         for (int i = 0; i < persb; ++i) loc += (s0 + i < nsb) ? tb.sbsum[s0 + i] : 0u;
-        const unsigned long long inc = wave_incscan_u64(loc);
+        // persb <= 21 super-blocks of < 2e8 each keep a lane's sum below 2^32 (kInitLdsSuper / 64 = 4 in LDS)
+        const unsigned long long inc = loc < 0x100000000ull && persb <= 21 ? wave_incscan_limbs((unsigned)loc) : wave_incscan_u64(loc);
         const unsigned long long exc = inc - loc;
         const unsigned long long m1 = __ballot(loc > 0 && (double)exc < r && r <= (double)inc);
         if (m1) {
@@ -293,7 +315,7 @@ __device__ __forceinline__ void init_body(const uint32_t* __restrict__ keys, con
           // level 2: the 16 blocks of the super-block
           const int b2 = sb * 16 + (lane & 15);
           const unsigned long long v2 = (lane < 16 && b2 < nb) ? tb.bsum[b2] : 0u;
-          const unsigned long long inc2 = wave_incscan_u64(v2);
+          const unsigned long long inc2 = wave_incscan_u32((unsigned)v2);     // 16 blocks x < 1.25e7 fits 32 bits
           const unsigned long long m2 = __ballot(lane < 16 && v2 > 0 && (double)(cum + inc2 - v2) < r && r <= (double)(cum + inc2));
           if (m2) {
             const int l2 = __ffsll((long long)m2) - 1;
@@ -302,7 +324,7 @@ __device__ __forceinline__ void init_body(const uint32_t* __restrict__ keys, con
             // level 3: the 64 samples of the block
             const int i = (b << 6) + lane;
             const uint2 sv = samp[i];
-            const unsigned long long inc3 = wave_incscan_u64(i < n ? sv.y : 0u);
+            const unsigned long long inc3 = wave_incscan_u32(i < n ? sv.y : 0u);   // 64 x 195075 fits 32 bits
             const unsigned long long m3 = __ballot(i < n && (double)(cum2 + inc3) >= r);
             const int l3 = m3 ? __ffsll((long long)m3) - 1 : min(63, n - 1 - (b << 6));
             cand = (b << 6) + l3;
@@ -405,10 +427,16 @@ __device__ __forceinline__ void init_body(const uint32_t* __restrict__ keys, con
     const uint32_t kb = sh.ckey[best];
     if (false) {
     } else if (use_list) {
-      for (int i = wave; i < n_items; i += kInitWaves) {
-        const uint32_t itx = s_items[i];
-        if ((int)(itx >> 24) == best) {
-          const int b = (int)(itx & 0xffffffu);
+      // lane l of wave w looks at item w + 16 l (one LDS read covers 1024 items); the wave then commits the
+      // winner's blocks among them one after the other
+      for (int i0 = 0; i0 < n_items; i0 += kInitWaves * 64) {
+        const int i = i0 + wave + kInitWaves * lane;
+        const uint32_t itx = i < n_items ? s_items[i] : 0xffffffffu;
+        unsigned long long m = __ballot(itx != 0xffffffffu && (int)(itx >> 24) == best);
+        while (m) {
+          const int l = __ffsll((long long)m) - 1;
+          m &= m - 1;
+          const int b = (int)((uint32_t)__shfl((int)itx, l, 64) & 0xffffffu);
           commit_block(b, kb, samp[(b << 6) + lane], samp, tb, touch_w, n_touch_w, kMaxTouch);
         }
       }
@@ -434,7 +462,7 @@ __device__ __forceinline__ void init_body(const uint32_t* __restrict__ keys, con
       }
     }
     if (tid == 0) { cho[c] = sh.cand[best]; sh.pot = pot - bd; sh.n_items = 0; sh.overflow = 0; sh.n_touch2[(c + 1) & 1] = 0; }
-    if (tid < T) { s_u[((c + 1) & 1) * T + tid] = u_next; sh.delta[tid] = 0; }
+    if (tid < T) s_u[((c + 1) & 1) * T + tid] = u_next;
     __syncthreads();
     STAMP(4);
     // more touched super-blocks than the list holds (only in the first steps): refresh all of them

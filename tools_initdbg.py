@@ -1,0 +1,18 @@
+import numpy as np, math
+from roibasedimagecompression_amd.ops import Rhccq, morton3
+from oracle import rhccq_oracle as O
+rh = Rhccq(0)
+rng = np.random.default_rng(2)
+P2 = np.unique(rng.integers(0, 256, (30000, 3)).astype(np.uint8), axis=0)
+k = 450
+labs, info = rh.minibatch_kmeans([O.pack_rgb(P2)], [k], return_info=True)
+n = len(P2)
+rs = np.random.RandomState(42)
+init_size = min(max(3000, 3 * k), n)
+rs.randint(0, n, init_size)
+ii = rs.randint(0, n, init_size)
+ii = ii[np.lexsort((ii, O.morton3(O.pack_rgb(P2[ii]))))]
+cidx = O.kmeanspp_int(P2[ii].astype(np.int64), k, rs)
+ch = info["chosen"][:k]
+bad = np.nonzero(ch != cidx)[0]
+print("first divergence at step", bad[:5], "of", k, "gpu", ch[bad[:5]], "oracle", cidx[bad[:5]])
