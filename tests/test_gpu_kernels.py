@@ -176,3 +176,28 @@ def test_dct_quant_extension(rh, O, block):
     oc, oq = O.dct_quant_blocks(want_luma, block, want_q.astype(np.float64))
     assert np.abs(coef.cpu().numpy() - oc).max() <= 1e-5 * 255 * block
     assert np.array_equal(q.cpu().numpy(), oq)
+
+
+def test_minibatch_init_chain_many_cases(rh, O):
+    """The k-means++ chain of mbk_init_kernel (work list, lazy super-block maxima, hierarchical search) against
+    the oracle's exact-integer k-means++ on the same Morton-ordered sample, for several shapes -- every pick
+    must be identical (this is the kernel where a reduction race once hid behind lucky timing)."""
+    import math
+    rng = np.random.default_rng(123)
+    cases = []
+    for n, hi, k in ((12000, 256, 130), (30000, 256, 900), (45000, 96, 2500), (20000, 40, 400), (70000, 256, 4200)):
+        P = np.unique(rng.integers(0, hi, (n, 3)).astype(np.uint8), axis=0)
+        if len(P) >= 10000:
+            cases.append((P, k))
+    labs, info = rh.minibatch_kmeans([O.pack_rgb(P) for P, _ in cases], [k for _, k in cases], return_info=True)
+    for i, (P, k) in enumerate(cases):
+        n = len(P)
+        rs = np.random.RandomState(42)
+        init_size = 3000 if 3000 >= k else 3 * k          # sklearn: 3 * batch_size, or 3 * k when that is < k
+        init_size = min(init_size, n)
+        rs.randint(0, n, init_size)
+        ii = rs.randint(0, n, init_size) if init_size < n else np.arange(n)
+        ii = ii[np.lexsort((ii, O.morton3(O.pack_rgb(P[ii]))))]
+        want = O.kmeanspp_int(P[ii].astype(np.int64), k, rs)
+        got = info["chosen"][info["koff"][i]:info["koff"][i + 1]]
+        assert np.array_equal(got, want), (i, n, k, int(np.argmax(got != want)))

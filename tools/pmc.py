@@ -1,3 +1,5 @@
+import os, sys
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 import csv, glob, sys, json, collections
 out = {}
 for name in ("FETCH_SIZE", "WRITE_SIZE"):

@@ -1,3 +1,5 @@
+import os, sys
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 import csv, glob, sys
 d = sys.argv[1]
 f = glob.glob(d + "/*/*_kernel_stats.csv")[0]

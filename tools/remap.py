@@ -1,3 +1,5 @@
+import os, sys
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 import time, numpy as np, torch
 from roibasedimagecompression_amd.ops import Rhccq
 from roibasedimagecompression_amd.frame import FrameEncoder

@@ -1,3 +1,5 @@
+import os, sys
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 """diagnostic only: per-phase cycle shares of mbk_init_kernel (build with -DRHCCQ_STAMPS into dbg_build/)."""
 import ctypes, sys, time, math
 import numpy as np
