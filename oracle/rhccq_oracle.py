@@ -31,8 +31,11 @@ Canonical k-means arithmetic "KM64" (shared with csrc/):
     sklearn consumes it (choice(p=uniform) for the first centre, uniform(size=T)
     per further centre, T = 2 + int(ln k));
   * Lloyd (KMeans): x = p - m with m = sum(p)/n (exact integer sum, one IEEE
-    division); dist(i,j) = csq_j + (-2 * ((x0*c0 + x1*c1) + x2*c2)) with
-    csq_j = (c0*c0 + c1*c1) + c2*c2, every operation individually rounded (no FMA);
+    division); dist(i,j) = csq_j + (-2 * fma(x2, c2, fma(x1, c1, x0*c0))) with
+    csq_j = (c0*c0 + c2*c2) + c1*c1 -- bit for bit what sklearn's E-step evaluates
+    (OpenBLAS dgemm FMA chain over k, numpy-einsum two-lane row norms): on integer
+    colour lattices exact real-arithmetic ties are common and these roundings decide
+    them (oracle/km64_estep.c); every other operation is individually rounded;
     label = first arg-min; new centre = (exact integer sum of member p)/count - m;
     convergence exactly as sklearn._kmeans_single_lloyd (labels unchanged, or
     sum_j |dc_j|^2 <= tol with tol = 1e-4 * mean(var)), max_iter = 300.
@@ -61,6 +64,41 @@ __all__ = [
 ]
 
 MINIBATCH_THRESHOLD = 10000  # clustering.py:205
+
+_KM64 = None
+
+
+def _km64_lib():
+    """oracle/km64_estep.c built in place with gcc (the E-step needs a correctly rounded fma, which numpy
+    does not expose)."""
+    global _KM64
+    if _KM64 is not None:
+        return _KM64
+    import ctypes
+    import os
+    import subprocess
+    here = os.path.dirname(os.path.abspath(__file__))
+    src = os.path.join(here, "km64_estep.c")
+    out = os.path.join(here, "_build", "libkm64.so")
+    if not os.path.exists(out) or os.path.getmtime(out) < os.path.getmtime(src):
+        os.makedirs(os.path.dirname(out), exist_ok=True)
+        subprocess.check_call(["gcc", "-O2", "-ffp-contract=off", "-shared", "-fPIC", "-o", out, src, "-lm"])
+    lib = ctypes.CDLL(out)
+    lib.km64_estep.argtypes = [ctypes.c_void_p, ctypes.c_int64, ctypes.c_void_p, ctypes.c_int64, ctypes.c_void_p, ctypes.c_void_p]
+    lib.km64_estep.restype = None
+    _KM64 = lib
+    return lib
+
+
+def km64_estep(X, C, want_dist=False):
+    """first arg-min_j of ||c_j||^2 + (-2) fma(x2,c2,fma(x1,c1,x0*c0)), ||c||^2 = (c0^2+c2^2)+c1^2."""
+    X = np.ascontiguousarray(X, dtype=np.float64).reshape(-1, 3)
+    C = np.ascontiguousarray(C, dtype=np.float64).reshape(-1, 3)
+    lab = np.empty(len(X), np.int32)
+    dist = np.empty(len(X), np.float64) if want_dist else None
+    _km64_lib().km64_estep(X.ctypes.data, len(X), C.ctypes.data, len(C), lab.ctypes.data, dist.ctypes.data if want_dist else None)
+    return (lab, dist) if want_dist else lab
+
 
 
 # --------------------------------------------------------------------------------------
@@ -243,8 +281,7 @@ def kmeans_labels(points, k, seed=42, max_iter=300, return_info=False):
     relocated = 0
     for it in range(max_iter):
         n_iter = it + 1
-        D = _km64_dist(X, C)
-        labels = _argmin_first(D)
+        labels = km64_estep(X, C)
         cnt = np.bincount(labels, minlength=k).astype(np.int64)
         Sj = np.zeros((k, 3), np.int64)
         np.add.at(Sj, labels, P)
@@ -279,7 +316,7 @@ def kmeans_labels(points, k, seed=42, max_iter=300, return_info=False):
             break
         labels_old = labels
     if not strict:
-        labels = _argmin_first(_km64_dist(X, C))
+        labels = km64_estep(X, C)
     if return_info:
         return labels, {"n_iter": n_iter, "strict": strict, "relocated": relocated, "init_idx": init_idx}
     return labels
@@ -375,7 +412,7 @@ def minibatch_kmeans_labels(points, k, seed=42, batch_size=1000, max_iter=100,
         consecutive samples a compact box, which is what lets the GPU prune exactly -- and greedy
         k-means++ runs on it in exact integers;
       * step s draws its batch as idx_b = bounded(counter_hash(seed, 2*s, b), n), b < batch;
-      * E-step distance dist = csq_j + (-2 * dot) on raw 0..255 coordinates, first arg-min;
+      * E-step distance as in KMeans (csq_j + (-2 * fma-chain dot)) on raw 0..255 coordinates, first arg-min;
       * centre update c = (c*w + S_int) * (1/(w+cnt)) with S_int the exact integer sum of the
         batch members (order independent);
       * reassignment (sklearn _mini_batch_step): candidates w < ratio*max(w); if more than
@@ -415,8 +452,7 @@ def minibatch_kmeans_labels(points, k, seed=42, batch_size=1000, max_iter=100,
         do_reassign = bool((W == 0).any() or since >= 10 * k)
         if do_reassign:
             since = 0
-        D = _mb_dist(Xb, C)
-        lab = _argmin_first(D)
+        lab = km64_estep(Xb, C)
         dd = Xb - C[lab]
         per = (dd[:, 0] * dd[:, 0] + dd[:, 1] * dd[:, 1]) + dd[:, 2] * dd[:, 2]
         inertia = tree_sum_1024(per)                    # fixed binary tree, GPU-reproducible
@@ -460,9 +496,7 @@ def minibatch_kmeans_labels(points, k, seed=42, batch_size=1000, max_iter=100,
         if no_impr >= max_no_improvement:
             break
     if assign is None:
-        labels = np.empty(n, np.int32)
-        for s0 in range(0, n, 4096):
-            labels[s0:s0 + 4096] = _argmin_first(_mb_dist(X[s0:s0 + 4096], C))
+        labels = km64_estep(X, C)
     else:
         labels = assign(X, C)
     if return_info:

@@ -4,8 +4,8 @@
 // Canonical arithmetic "KM64" (see oracle/rhccq_oracle.py): greedy k-means++ on EXACT integer
 // squared distances (cumulative sums / potentials are order independent), MT19937 uniforms supplied
 // by the host exactly as numpy's RandomState(42) emits them; Lloyd in float64 on mean-centred
-// coordinates with every operation individually rounded (this file is built with
-// -ffp-contract=off), centres from exact integer member sums, sklearn's convergence rules.
+// coordinates, E-step distance csq + (-2 * fma-chain dot) exactly as sklearn's dgemm / einsum evaluate it
+// (rhccq_common.h; the file is built with -ffp-contract=off, the only fused operations are explicit), centres from exact integer member sums, sklearn's convergence rules.
 //
 // MI355X design: one 1024-thread workgroup per split problem (problems of a frame are batched in one
 // launch, grid = #problems); points, labels, centres and integer accumulators live in LDS
@@ -54,10 +54,9 @@ __device__ __forceinline__ unsigned long long block_exscan64(unsigned long long 
   return base + inc - v;
 }
 
-// KM64 distance: csq + (-2 * ((x0*c0 + x1*c1) + x2*c2))
+// KM64 distance: csq + (-2 * fma(x2, c2, fma(x1, c1, x0*c0)))   (rhccq_common.h)
 __device__ __forceinline__ double km64_dist(double x0, double x1, double x2, const double* c) {
-  const double dot = (x0 * c[0] + x1 * c[1]) + x2 * c[2];
-  return c[3] + (-2.0 * dot);
+  return c[3] + (-2.0 * km64_dot(x0, x1, x2, c[0], c[1], c[2]));
 }
 
 __global__ __launch_bounds__(kKmThreads) void kmeans_kernel(const uint32_t* __restrict__ keys, const int32_t* __restrict__ desc,
@@ -195,7 +194,7 @@ __global__ __launch_bounds__(kKmThreads) void kmeans_kernel(const uint32_t* __re
     const uint32_t kk = P[chosen[j]];
     const double c0 = (double)key_r(kk) - m0, c1 = (double)key_g(kk) - m1, c2 = (double)key_b(kk) - m2;
     C[j * 4 + 0] = c0; C[j * 4 + 1] = c1; C[j * 4 + 2] = c2;
-    C[j * 4 + 3] = (c0 * c0 + c1 * c1) + c2 * c2;
+    C[j * 4 + 3] = km64_csq(c0, c1, c2);
   }
   for (int i = tid; i < n; i += kKmThreads) aux[i] = 0x7fffffffu;   // labels_old = -1
   __syncthreads();
@@ -331,7 +330,7 @@ __global__ __launch_bounds__(kKmThreads) void kmeans_kernel(const uint32_t* __re
       const double d0 = c0 - C[j * 4 + 0], d1 = c1 - C[j * 4 + 1], d2 = c2 - C[j * 4 + 2];
       shift[j] = (d0 * d0 + d1 * d1) + d2 * d2;
       C[j * 4 + 0] = c0; C[j * 4 + 1] = c1; C[j * 4 + 2] = c2;
-      C[j * 4 + 3] = (c0 * c0 + c1 * c1) + c2 * c2;
+      C[j * 4 + 3] = km64_csq(c0, c1, c2);
     }
     __threadfence_block();
     __syncthreads();

@@ -485,7 +485,7 @@ __device__ __forceinline__ void init_body(const uint32_t* __restrict__ keys, con
     const uint32_t kk = samp[cho[j]].x;
     const double c0 = (double)key_r(kk), c1 = (double)key_g(kk), c2 = (double)key_b(kk);
     double* C = centres + (P.koff + j) * 4;
-    C[0] = c0; C[1] = c1; C[2] = c2; C[3] = (c0 * c0 + c1 * c1) + c2 * c2;
+    C[0] = c0; C[1] = c1; C[2] = c2; C[3] = km64_csq(c0, c1, c2);
   }
 }
 
@@ -548,10 +548,10 @@ __global__ __launch_bounds__(256) void mbk_batch_estep_kernel(const uint32_t* __
     const unsigned long long src = bounded(counter_hash(seed, 2ull * (unsigned long long)step, (unsigned long long)b), (unsigned long long)P.n);
     const uint32_t kk = keys[P.off + src];
     const double x0 = (double)key_r(kk), x1 = (double)key_g(kk), x2 = (double)key_b(kk);
-    double bd = sc[3] + ((x0 * sc[0] + x1 * sc[1]) + x2 * sc[2]);
+    double bd = sc[3] + km64_dot(x0, x1, x2, sc[0], sc[1], sc[2]);
     int bj = 0;
     for (int j = 1; j < nj; ++j) {
-      const double d = sc[j * 4 + 3] + ((x0 * sc[j * 4] + x1 * sc[j * 4 + 1]) + x2 * sc[j * 4 + 2]);
+      const double d = sc[j * 4 + 3] + km64_dot(x0, x1, x2, sc[j * 4], sc[j * 4 + 1], sc[j * 4 + 2]);
       if (d < bd) { bd = d; bj = j; }
     }
     pd[b] = bd;
@@ -704,7 +704,7 @@ __global__ __launch_bounds__(kUpdThreads) void mbk_update_kernel(const uint32_t*
     const double c1 = (C[j * 4 + 1] * w + (double)sh.hsum[h][1]) * alpha;
     const double c2 = (C[j * 4 + 2] * w + (double)sh.hsum[h][2]) * alpha;
     C[j * 4] = c0; C[j * 4 + 1] = c1; C[j * 4 + 2] = c2;
-    C[j * 4 + 3] = (c0 * c0 + c1 * c1) + c2 * c2;
+    C[j * 4 + 3] = km64_csq(c0, c1, c2);
     W[j] = wn;
   }
   __syncthreads();
@@ -824,7 +824,7 @@ __global__ __launch_bounds__(kUpdThreads) void mbk_update_kernel(const uint32_t*
         const uint32_t kk = sh.bkey[sh.perm[r_run + __popcll(msel & ((1ull << lane) - 1ull))]];
         const double c0 = (double)key_r(kk), c1 = (double)key_g(kk), c2 = (double)key_b(kk);
         C[j * 4] = c0; C[j * 4 + 1] = c1; C[j * 4 + 2] = c2;
-        C[j * 4 + 3] = (c0 * c0 + c1 * c1) + c2 * c2;
+        C[j * 4 + 3] = km64_csq(c0, c1, c2);
         W[j] = wmin;
         wf = wmin;
       }
@@ -945,7 +945,7 @@ __global__ __launch_bounds__(256) void mbk_assign_grid_kernel(const uint32_t* __
           for (uint32_t e = e0; e < e1; ++e) {
             const int j = (int)ord[e];
             const double* c = C + (size_t)j * 4;
-            const double d = c[3] + (-2.0 * ((x0 * c[0] + x1 * c[1]) + x2 * c[2]));
+            const double d = c[3] + (-2.0 * km64_dot(x0, x1, x2, c[0], c[1], c[2]));
             if (d < bd || (d == bd && j < bj)) { bd = d; bj = j; }
           }
         }

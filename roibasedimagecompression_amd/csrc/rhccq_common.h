@@ -63,6 +63,17 @@ __device__ __forceinline__ unsigned dist2_keys_n(uint32_t a, unsigned na, uint32
   return na + norm2_key(b) - 2u * __builtin_amdgcn_udot4(a, b, 0u, false);
 }
 
+// ---- KM64 float64 arithmetic shared by K7 / K8 (this library is built with -ffp-contract=off: the only
+// fused operations are the explicit fma() calls below) --------------------------------------------------
+// sklearn's Lloyd E-step evaluates ||c||^2 + (-2) <x, c> with <x, c> from an OpenBLAS dgemm (FMA chain over
+// k = 0,1,2 starting from the rounded product x0*c0) and ||c||^2 from numpy's einsum (two-lane SSE2
+// accumulation: (c0^2 + c2^2) + c1^2).  Exact real-arithmetic ties are common on integer colour lattices,
+// so these roundings decide labels; oracle/km64_estep.c restates the same expression with libm's fma.
+__device__ __forceinline__ double km64_csq(double c0, double c1, double c2) { return (c0 * c0 + c2 * c2) + c1 * c1; }
+__device__ __forceinline__ double km64_dot(double x0, double x1, double x2, double c0, double c1, double c2) {
+  return fma(x2, c2, fma(x1, c1, x0 * c0));
+}
+
 template <typename T>
 __device__ __forceinline__ T wave_sum(T v) {
 #pragma unroll

@@ -60,9 +60,18 @@ class _Comp:
         self.merged = merged      # True: canvas semantics (index 0 = black = uncovered)
 
 
-def _scatter_min(n, idx, val):
-    out = np.full(n, _FP_NONE, np.int64)
-    np.minimum.at(out, idx, val)
+def _scatter_min(n, idx, val, out=None):
+    """out[idx[i]] = min(out[idx[i]], val[i]) without ufunc.at (sort + reduceat: ~20x faster at 10^5 entries)."""
+    if out is None:
+        out = np.full(n, _FP_NONE, np.int64)
+    idx = np.asarray(idx)
+    if len(idx) == 0:
+        return out
+    order = np.argsort(idx)                              # min is order independent: no stable sort needed
+    si, sv = idx[order], np.asarray(val)[order]
+    starts = np.flatnonzero(np.r_[True, si[1:] != si[:-1]])
+    tgt = si[starts]
+    out[tgt] = np.minimum(out[tgt], np.minimum.reduceat(sv, starts))
     return out
 
 
@@ -75,7 +84,7 @@ def _merge(comps, bbox):
     seqs = []
     for c in reversed(comps):
         valid = np.nonzero((c.keys != 0) & (c.fp < _FP_NONE))[0]
-        seqs.append(c.keys[valid[np.argsort(c.fp[valid], kind="stable")]])
+        seqs.append(c.keys[valid[np.argsort(c.fp[valid])]])   # first positions of distinct entries are distinct
     allk = np.concatenate(seqs) if seqs else np.zeros(0, np.uint32)
     u, first = np.unique(allk, return_index=True)
     order = np.argsort(first, kind="stable")
@@ -89,7 +98,7 @@ def _merge(comps, bbox):
         lut = np.zeros(len(c.keys), np.int32)                  # black / unused -> canvas 0
         pos = np.searchsorted(u, c.keys[valid])
         lut[valid] = rank[pos]
-        np.minimum.at(gfp, lut[valid], c.fp[valid])
+        _scatter_min(len(gfp), lut[valid], c.fp[valid], out=gfp)
         for job, m in c.maps.items():
             maps[job] = lut[m]
     minr, minc, maxr, maxc = bbox
