@@ -42,12 +42,21 @@ def build_inputs(rh, H, W, seed, tiles, q_roi, q_non, sigma):
     return img, rgb, specs, roi_mask, (lr, ln, br, bn)
 
 
-def one_step(rh, enc, rgb, specs, roi_mask, block, stage_acc=None):
+def one_step(rh, enc, rgb, specs, roi_mask, block, stage_acc=None, extra=()):
+    """one pass of the hot path over one batch: the frame (plus `extra` further frames when the step is a
+    batch, --frames-per-step) and the DCT/quantisation extension of every frame"""
     import torch
-    out = enc.encode(rgb, specs)
+    if extra:
+        outs = enc.encode_batch([(rgb, specs)] + [(r, sp) for r, sp, _ in extra])
+        out = outs[0]
+    else:
+        out = enc.encode(rgb, specs)
     t0 = time.perf_counter()
     luma, qstep = rh.luma_qstep(rgb, roi_mask, block, 4.0, 16.0)
     coef, q = rh.dct_quant(luma, block, qstep, want_coef=False)
+    for r, sp, m in extra:
+        l2, q2 = rh.luma_qstep(r, m, block, 4.0, 16.0)
+        rh.dct_quant(l2, block, q2, want_coef=False)
     if stage_acc is not None:
         torch.cuda.synchronize()
         for k, v in enc.timings.items():
@@ -148,6 +157,9 @@ def main():
     ap.add_argument("--block", type=int, default=8)
     ap.add_argument("--cpu-sample", type=int, default=576, help="edge of the CPU-baseline crop (0 = skip)")
     ap.add_argument("--no-probes", action="store_true")
+    ap.add_argument("--frames-per-step", type=int, default=1,
+                    help="frames encoded together per step (default 1 = BASELINE configs[1], a single frame; > 1 is the "
+                         "stream / batch regime of configs[2] and [4]: one batched clustering launch per level)")
     args = ap.parse_args()
 
     import torch
@@ -165,7 +177,12 @@ def main():
     enc = FrameEncoder(rh)
     H, W = args.height, args.width
     # at >= 4K the reference's SLIC scaling yields <= 2 segments per region (SURVEY.md 8a preface)
-    img, rgb, specs, roi_mask, (lr, ln, br, bn) = build_inputs(rh, H, W, 1234 + rank, (2, 1), args.quality, args.quality, args.sigma)
+    B = max(1, args.frames_per_step)
+    img, rgb, specs, roi_mask, (lr, ln, br, bn) = build_inputs(rh, H, W, 1234 + rank * B, (2, 1), args.quality, args.quality, args.sigma)
+    extra = []
+    for i in range(1, B):
+        _, r_i, sp_i, m_i, _ = build_inputs(rh, H, W, 1234 + rank * B + i, (2, 1), args.quality, args.quality, args.sigma)
+        extra.append((r_i, sp_i, m_i))
 
     def barrier():
         if world > 1:
@@ -173,12 +190,12 @@ def main():
         torch.cuda.synchronize()
 
     for _ in range(args.warmup):
-        one_step(rh, enc, rgb, specs, roi_mask, args.block)
+        one_step(rh, enc, rgb, specs, roi_mask, args.block, extra=extra)
     barrier()
     t0 = time.perf_counter()
     out = None
     for _ in range(args.steps):
-        out, q = one_step(rh, enc, rgb, specs, roi_mask, args.block)
+        out, q = one_step(rh, enc, rgb, specs, roi_mask, args.block, extra=extra)
     barrier()
     dt = time.perf_counter() - t0
     if world > 1:
@@ -187,18 +204,19 @@ def main():
         dt = float(t.item())
     stages = {}
     if rank == 0:
-        one_step(rh, enc, rgb, specs, roi_mask, args.block, stage_acc=stages)
-    px = H * W * args.steps * world
+        one_step(rh, enc, rgb, specs, roi_mask, args.block, stage_acc=stages, extra=extra)
+    px = H * W * args.steps * world * B
     line = {
         "metric": "Mpixels/s encoded (ROI cluster + DCT/quant) at 4K RGB",
         "value": px / dt / 1e6, "unit": "Mpixels/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
         "ms_per_step": dt / args.steps * 1e3, "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
         "dtype": "u8 keys / int32 exact k-means++ / f64 Lloyd+mini-batch", "data": "synthetic",
-        "config": {"workload": f"configs[1]: single {W}x{H} RGB synthetic 'photo' frame per GPU (seed 1234+rank, sigma={args.sigma}), "
-                               f"one quality tier q={args.quality} (levels {args.quality}/{min(2*args.quality,100)}/{min(4*args.quality,100)}), "
+        "config": {"workload": (f"configs[1]: single {W}x{H} RGB synthetic 'photo' frame per GPU (seed 1234+rank, sigma={args.sigma}), " if B == 1 else
+                                f"batch of {B} {W}x{H} RGB synthetic 'photo' frames per GPU per step (seeds 1234+rank*{B}+i, sigma={args.sigma}), ")
+                               + f"one quality tier q={args.quality} (levels {args.quality}/{min(2*args.quality,100)}/{min(4*args.quality,100)}), "
                                "2 segments per class, ROI ellipse 35 % + 3 px overlap; "
                                f"{args.block}x{args.block} DCT + two-tier quantisation extension in the timed region",
-                   "frames_per_step_per_gpu": 1, "parallelism": f"frame-parallel x{world}"},
+                   "frames_per_step_per_gpu": B, "parallelism": f"frame-parallel x{world}"},
     }
     if rank == 0:
         line["stages_ms"] = {k: round(v * 1e3, 3) for k, v in stages.items()}
@@ -209,6 +227,23 @@ def main():
             line["neighbour_pass"] = neighbour_probe(rh)
         else:
             line["roofline"] = roofline_probe(rh, rgb, specs)
+        if not args.no_probes and world == 1 and B == 1:
+            # the same path in the stream regime (configs[4]: many 4K frames in flight): 8 frames per step share
+            # one batched clustering launch per level, so the sequential k-means++ chains run side by side
+            nb = 8
+            more = []
+            for i in range(1, nb):
+                _, r_i, sp_i, m_i, _ = build_inputs(rh, H, W, 1234 + i, (2, 1), args.quality, args.quality, args.sigma)
+                more.append((r_i, sp_i, m_i))
+            one_step(rh, enc, rgb, specs, roi_mask, args.block, extra=more)
+            torch.cuda.synchronize()
+            t1 = time.perf_counter()
+            one_step(rh, enc, rgb, specs, roi_mask, args.block, extra=more)
+            torch.cuda.synchronize()
+            d1 = time.perf_counter() - t1
+            line["stream_regime"] = {"frames_per_step": nb, "value": nb * H * W / d1 / 1e6, "unit": "Mpixels/s", "ms_per_step": d1 * 1e3,
+                                     "note": "python bench.py --frames-per-step 8 times this regime as the main value"}
+            del more
         if args.cpu_sample and world == 1:
             line["cpu_baseline"] = cpu_baseline(img, lr, ln, args.cpu_sample, args.quality)
         else:

@@ -178,13 +178,11 @@ class FrameEncoder:
                 "keys_dev": keys_dev, "has_black": has_bg | all_black, "P": P, "present": present, "job_class": job_class,
                 "job_region": job_region, "crop": (r0, r1, c0, c1), "total": total}
 
-    def level1(self, S):
-        """Cluster every segment palette (subregions.py:426-449) and merge per region
-        (subregions.py:634-679).  Returns per class the list of region components."""
-        rh = self.rh
-        classes, pal_off, job_base = S["classes"], S["pal_off"], S["job_base"]
-        r0, r1, c0, c1 = S["crop"]
-        t0 = time.perf_counter()
+    # ---- the three levels as (collect jobs) / (apply results) pairs, so that the palettes of several frames
+    # can share one batched clustering launch per level (encode_batch) ---------------------------------------
+    def level1_jobs(self, S):
+        """Clustering jobs of every segment palette of the frame (subregions.py:426-449)."""
+        classes, pal_off = S["classes"], S["pal_off"]
         jobs, job_ids = [], []
         # palettes of >= 10 000 colours stay in HBM (MiniBatch branch); the small ones (DBSCAN branch) are
         # brought to the host in ONE copy
@@ -208,9 +206,14 @@ class FrameEncoder:
                 jb["keys"] = host_keys[int(j)]
             jobs.append(jb)
             job_ids.append(j)
-        res = cluster_palettes(rh, jobs)
-        self._t("level1_cluster", t0)
-        t0 = time.perf_counter()
+        return jobs, job_ids
+
+    def level1_finish(self, S, job_ids, res):
+        """lut1, first positions of the clustered entries, merge per region (subregions.py:634-679).
+        Returns per class the list of region components."""
+        rh = self.rh
+        classes, pal_off, job_base = S["classes"], S["pal_off"], S["job_base"]
+        r0, r1, c0, c1 = S["crop"]
         # first raster position of every CLUSTERED palette entry (fixes the first-seen order of the merges,
         # merging.py:77-79): one streaming pass whose atomicMin table is only sum(K_j) entries
         seg_comp = {}
@@ -235,7 +238,6 @@ class FrameEncoder:
         for i, (j, (nk, mp, info)) in enumerate(zip(job_ids, res)):
             seg_comp[j] = _Comp(nk, fp_new_all[new_off[i]:new_off[i + 1]], (int(r0[j]), int(c0[j])),
                                 (int(r1[j] - r0[j] + 1), int(c1[j] - c0[j] + 1)), {int(j): np.arange(len(nk), dtype=np.int32)}, False)
-
         per_class = []
         for ci, cls in enumerate(classes):
             regs = []
@@ -244,57 +246,59 @@ class FrameEncoder:
                 # subregions.py:637-679: > 1 components are merged on the region canvas, one is kept as is
                 regs.append(_merge(segs, tuple(int(v) for v in cls.region_bbox[r])) if segs else None)
             per_class.append(regs)
+        return per_class
+
+    def level1(self, S):
+        t0 = time.perf_counter()
+        jobs, job_ids = self.level1_jobs(S)
+        res = cluster_palettes(self.rh, jobs)
+        self._t("level1_cluster", t0)
+        t0 = time.perf_counter()
+        per_class = self.level1_finish(S, job_ids, res)
         self._t("merge1", t0)
         return per_class
 
-    def encode(self, rgb, classes, want_levels=False, profile=False):
-        """rgb: uint8[H,W,3] device tensor; classes: [ClassSpec] in precedence order (ROI first).
-        Returns dict(palette uint8[K,3], indices (device tensor [H,W], dtype by max index),
-        indices_dtype, shape, top_left, levels (optional))."""
-        rh = self.rh
-        self.timings = {}
-        S = self.prepare(rgb, classes)
-        H, W, pal_off, total = S["H"], S["W"], S["pal_off"], S["total"]
-        per_class = self.level1(S)
-        t0 = time.perf_counter()
-        levels = {"level1": per_class, "level2": []} if want_levels else None
+    def level2_jobs(self, S, per_class):
+        """merge per class on the frame canvas (regions.py:34-46) -> one clustering job per class."""
+        H, W = S["H"], S["W"]
         lvl2, q2s = [], []
-        for ci, cls in enumerate(classes):
+        for ci, cls in enumerate(S["classes"]):
             regs = [r for r in per_class[ci] if r is not None]
             q2 = min(cls.quality * 2, 100)
             q2s.append(q2)
             if not regs:
                 continue                                                                  # rhccq.ipynb:1009-1013
             lvl2.append((ci, _merge(regs, (0, 0, H, W)), q2))
-        self._t("merge2", t0)
-        t0 = time.perf_counter()
-        # ---- level 2: cluster each class palette (regions.py:52-68) ---------------------------------
         jobs2 = []
         for ci, comp, q2 in lvl2:
             eps, _, mc = clustering_params(len(comp.keys), q2)
             jobs2.append({"keys": comp.keys, "quality": q2, "eps": eps, "mc": mc})
-        res2 = cluster_palettes(rh, jobs2)
+        return lvl2, q2s, jobs2
+
+    @staticmethod
+    def level2_finish(lvl2, res2):
         comps3 = []
         for (ci, comp, q2), (nk, mp, info) in zip(lvl2, res2):
             fp_new = _scatter_min(len(nk), mp, comp.fp)
-            c2 = _Comp(nk, fp_new, comp.top_left, comp.shape, {job: mp[m] for job, m in comp.maps.items()}, comp.merged)
-            comps3.append(c2)
-        if want_levels:
-            levels["level2"] = comps3
-        self._t("level2", t0)
-        t0 = time.perf_counter()
-        # ---- level 3: merge classes, cluster (image.py:246-280) -------------------------------------
+            comps3.append(_Comp(nk, fp_new, comp.top_left, comp.shape, {job: mp[m] for job, m in comp.maps.items()}, comp.merged))
+        return comps3
+
+    def level3_job(self, S, comps3, q2s):
+        """merge ROI + non-ROI (image.py:246-256) -> the level-3 clustering job."""
         if not comps3:
             raise IndexError("no components")
         q3 = min(sum(q2s), 100)
-        multi = len(comps3) > 1
-        m3c = _merge(comps3, (0, 0, H, W))
+        m3c = _merge(comps3, (0, 0, S["H"], S["W"]))
         eps, _, mc = clustering_params(len(m3c.keys), q3)
-        (fk3, mp3, info3), = cluster_palettes(rh, [{"keys": m3c.keys, "quality": q3, "eps": eps, "mc": mc}])
-        self._t("level3", t0)
+        return m3c, q3, {"keys": m3c.keys, "quality": q3, "eps": eps, "mc": mc}
+
+    def finish(self, S, comps3, m3c, q3, res3, want_levels=False, levels=None, profile=False):
+        """compose levels 2-3 into lut2 and run the final per-pixel remap."""
+        rh = self.rh
+        H, W = S["H"], S["W"]
+        fk3, mp3, info3 = res3
+        multi = len(comps3) > 1
         t0 = time.perf_counter()
-        # ---- compose levels 2-3 into one LUT over the clustered level-1 palettes (lut2); the per-pixel pass
-        # chains it behind the level-1 mapping (lut1) -------------------------------------------------------
         lut2 = np.full(max(S["k1_total"], 1), -1, np.int32)
         for c2 in comps3:
             for job, m in c2.maps.items():
@@ -316,7 +320,7 @@ class FrameEncoder:
         d_lut2 = rh.dev(lut2)
         self._t("compose", t0)
         t0 = time.perf_counter()
-        out = rh.frame_remap(rgb, S["labels"], S["job_base"][:-1], S["bitmaps"], S["prefix"], S["d_pal_off"], S["fix_key"], S["lut1"],
+        out = rh.frame_remap(S["rgb"], S["labels"], S["job_base"][:-1], S["bitmaps"], S["prefix"], S["d_pal_off"], S["fix_key"], S["lut1"],
                              default_index, out_dtype, lut2=d_lut2)
         self._t("remap", t0, sync=profile)
         result = {"palette": unpack_rgb(fk3), "indices": out, "indices_dtype": dtype_name,
@@ -327,7 +331,57 @@ class FrameEncoder:
             result["levels"] = levels
         return result
 
-    # ------------------------------------------------------------------------------------------
+    def encode(self, rgb, classes, want_levels=False, profile=False):
+        """rgb: uint8[H,W,3] device tensor; classes: [ClassSpec] in precedence order (ROI first).
+        Returns dict(palette uint8[K,3], indices (device tensor [H,W], dtype by max index),
+        indices_dtype, shape, top_left, levels (optional))."""
+        rh = self.rh
+        self.timings = {}
+        S = self.prepare(rgb, classes)
+        per_class = self.level1(S)
+        t0 = time.perf_counter()
+        lvl2, q2s, jobs2 = self.level2_jobs(S, per_class)
+        self._t("merge2", t0)
+        t0 = time.perf_counter()
+        comps3 = self.level2_finish(lvl2, cluster_palettes(rh, jobs2))
+        levels = {"level1": per_class, "level2": comps3} if want_levels else None
+        self._t("level2", t0)
+        t0 = time.perf_counter()
+        m3c, q3, job3 = self.level3_job(S, comps3, q2s)
+        (res3,) = cluster_palettes(rh, [job3])
+        self._t("level3", t0)
+        return self.finish(S, comps3, m3c, q3, res3, want_levels, levels, profile)
+
+    def encode_batch(self, frames):
+        """frames: [(rgb, classes)].  Same results as encode() frame by frame, but the palettes of all frames
+        go through ONE batched clustering call per level: the sequential k-means++ chains of all segments of
+        all frames run side by side (one workgroup each) instead of leaving 250 CUs idle."""
+        rh = self.rh
+        self.timings = {}
+        t0 = time.perf_counter()
+        states = [self.prepare(rgb, classes) for rgb, classes in frames]
+        l1 = [self.level1_jobs(S) for S in states]
+        flat = [jb for jobs, _ in l1 for jb in jobs]
+        res = cluster_palettes(rh, flat)
+        self._t("level1_cluster", t0)
+        t0 = time.perf_counter()
+        per_class, o = [], 0
+        for S, (jobs, job_ids) in zip(states, l1):
+            per_class.append(self.level1_finish(S, job_ids, res[o:o + len(jobs)]))
+            o += len(jobs)
+        l2 = [self.level2_jobs(S, pc) for S, pc in zip(states, per_class)]
+        res2 = cluster_palettes(rh, [jb for _, _, jobs2 in l2 for jb in jobs2])
+        comps3, o = [], 0
+        for lvl2, q2s, jobs2 in l2:
+            comps3.append(self.level2_finish(lvl2, res2[o:o + len(jobs2)]))
+            o += len(jobs2)
+        self._t("level2", t0)
+        t0 = time.perf_counter()
+        l3 = [self.level3_job(S, c3, q2s) for S, c3, (_, q2s, _) in zip(states, comps3, l2)]
+        res3 = cluster_palettes(rh, [job for _, _, job in l3])
+        self._t("level3", t0)
+        return [self.finish(S, c3, m3c, q3, r3) for S, c3, (m3c, q3, _), r3 in zip(states, comps3, l3, res3)]
+
     def render_component(self, S, comp):
         """Index map (device int32 [h,w]) of one level-1/level-2 component as the reference would
         return it: canvas semantics for merged components (uncovered = 0 = black), crop semantics for a
