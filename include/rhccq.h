@@ -129,6 +129,14 @@ typedef struct rhccq_mbk_problem {
   int32_t first;      /* first centre (index into the init sample) */
   int32_t T;          /* n_local_trials */
 } rhccq_mbk_problem;
+/* canonical order of the init samples (oracle.minibatch_kmeans_labels: "(Morton code, index)"): init_idx
+ * (device; problem i's sample indices in RandomState draw order at [init_off, init_off + init_n), the
+ * problems back to back) is re-ordered in place.  Replaces nothing in the reference -- sklearn's sample order
+ * is the draw order (clustering.py:211-218 -> MiniBatchKMeans._init_centroids); the canonical order exists so
+ * that 64 consecutive samples form a compact colour box.  tmp: rhccq_mbk_order_bytes(sum init_n) bytes. */
+int64_t rhccq_mbk_order_bytes(int64_t total_samples);
+int rhccq_mbk_order(rhccq_ctx* ctx, const uint32_t* keys, const rhccq_mbk_problem* probs_host,
+                    int32_t n_prob, int32_t* init_idx, void* tmp, int64_t tmp_bytes);
 /* greedy k-means++ on the init sample in exact integers; writes centres[(koff+j)*4 + {0,1,2}]
  * (doubles, raw 0..255 coordinates) and chosen[koff+j] (index into the init sample) */
 int rhccq_mbk_init(rhccq_ctx* ctx, const uint32_t* keys, const rhccq_mbk_problem* probs_host,

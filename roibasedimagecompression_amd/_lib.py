@@ -51,6 +51,8 @@ PROTOTYPES = {
     "rhccq_mbk_steps": (c_int32, [c_void_p, c_void_p, C.POINTER(MbkProblem), c_int32, c_int64, c_int32, c_uint64, c_void_p,
                                   c_void_p, c_void_p, c_void_p, c_int64]),
     "rhccq_mbk_work_bytes": (c_int64, [C.POINTER(MbkProblem), c_int32]),
+    "rhccq_mbk_order_bytes": (c_int64, [c_int64]),
+    "rhccq_mbk_order": (c_int32, [c_void_p, c_void_p, C.POINTER(MbkProblem), c_int32, c_void_p, c_void_p, c_int64]),
     "rhccq_mbk_assign": (c_int32, [c_void_p, c_void_p, C.POINTER(MbkProblem), c_int32, c_void_p, c_void_p, c_int64, c_void_p]),
     "rhccq_remap": (c_int32, [c_void_p, c_void_p, c_int64, c_void_p, c_int64, c_void_p]),
     "rhccq_frame_remap": (c_int32, [c_void_p, c_void_p, c_int32, c_int32, c_int32, C.POINTER(c_void_p), C.POINTER(c_int32),

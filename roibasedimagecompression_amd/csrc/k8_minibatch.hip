@@ -18,6 +18,10 @@
 //          learning-rate update, the low-count reassignment and sklearn's EWA early-stopping rule.
 //   assign final E-step over all N points, brute force, 4 points per thread, centres (pre-scaled by -2,
 //          exact) tiled through LDS; float64 VALU bound (K = 3 is not an MFMA shape).
+#include <stdlib.h>
+
+#include <hipcub/hipcub.hpp>
+
 #include "rhccq_common.h"
 
 namespace rhccq {
@@ -617,7 +621,7 @@ __global__ __launch_bounds__(kUpdThreads) void mbk_update_kernel(const uint32_t*
                                                                  double* __restrict__ centres, double* __restrict__ weights,
                                                                  double* __restrict__ state, long long step, unsigned long long seed,
                                                                  const double* __restrict__ pdist, const int32_t* __restrict__ pidx,
-                                                                 const long long* __restrict__ part_off) {
+                                                                 const long long* __restrict__ part_off, int single_tile) {
   __shared__ UpdShared sh;
   const int p = blockIdx.x, tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
   const MbkP P = probs[p];
@@ -631,7 +635,7 @@ __global__ __launch_bounds__(kUpdThreads) void mbk_update_kernel(const uint32_t*
     if (tid == 0) st[4] = 2.0;                           // ran out of steps
     return;
   }
-  const int n_tiles = (k + kTileC - 1) / kTileC;
+  const int n_tiles = single_tile ? 1 : (k + kTileC - 1) / kTileC;
   double* C = centres + P.koff * 4;
   double* W = weights + P.koff;
   for (int i = tid; i < kHashSlots; i += kUpdThreads) {
@@ -869,60 +873,88 @@ constexpr int kGridG = 32, kGridCells = kGridG * kGridG * kGridG, kCellSide = 8;
 
 __device__ __forceinline__ int grid_axis(double v) { return min(kGridG - 1, max(0, (int)(v * (1.0 / kCellSide)))); }
 
-__global__ __launch_bounds__(256) void grid_count_kernel(const MbkP* __restrict__ probs, const double* __restrict__ centres,
-                                                         uint32_t* __restrict__ cell_cnt /* [n_prob][cells+1] */) {
-  const MbkP P = probs[blockIdx.y];
-  const long long j = (long long)blockIdx.x * blockDim.x + threadIdx.x;
-  if (j >= P.k) return;
-  const double* c = centres + (P.koff + j) * 4;
-  const int cell = (grid_axis(c[0]) * kGridG + grid_axis(c[1])) * kGridG + grid_axis(c[2]);
-  atomicAdd(&cell_cnt[(size_t)blockIdx.y * (kGridCells + 1) + cell + 1], 1u);
-}
-
-__global__ __launch_bounds__(1024) void grid_scan_kernel(uint32_t* __restrict__ cell_cnt, uint32_t* __restrict__ cursor) {
+// One 1024-thread workgroup bins all centres of one problem with LDS atomics only (scattered device-scope
+// atomics run at the memory side on this part and cost ~1 ms per step for 32 problems): count per cell, scan,
+// fill.  The order inside a cell depends on scheduling; grid_nearest() breaks distance ties by centre index,
+// so its result does not.
+__global__ __launch_bounds__(1024) void grid_build_kernel(const MbkP* __restrict__ probs, const double* __restrict__ centres,
+                                                          uint32_t* __restrict__ cell_start /* [n_prob][cells+1] */,
+                                                          uint32_t* __restrict__ order, const double* __restrict__ state) {
+  __shared__ uint32_t cnt[kGridCells];                   // counters, then fill cursors (128 KiB)
   __shared__ unsigned red[17];
-  uint32_t* cs = cell_cnt + (size_t)blockIdx.x * (kGridCells + 1);
-  uint32_t* cur = cursor + (size_t)blockIdx.x * kGridCells;
-  constexpr int per = kGridCells / 1024;               // 32 consecutive cells per thread
-  unsigned loc[per];
+  const int p = blockIdx.x;
+  if (state && state[p * 16 + 4] != 0.0) return;
+  const MbkP P = probs[p];
+  const double* C = centres + P.koff * 4;
+  uint32_t* cs = cell_start + (size_t)p * (kGridCells + 1);
+  for (int c = threadIdx.x; c < kGridCells; c += 1024) cnt[c] = 0;
+  __syncthreads();
+  // eight centres per thread in flight: the loads are issued together, then the LDS atomics
+  constexpr int kU = 8;
+  for (long long j0 = threadIdx.x; j0 < P.k; j0 += 1024 * kU) {
+    int cell[kU];
+#pragma unroll
+    for (int u = 0; u < kU; ++u) {
+      const long long j = j0 + (long long)u * 1024;
+      cell[u] = -1;
+      if (j < P.k) {
+        const double* c = C + j * 4;
+        cell[u] = (grid_axis(c[0]) * kGridG + grid_axis(c[1])) * kGridG + grid_axis(c[2]);
+      }
+    }
+#pragma unroll
+    for (int u = 0; u < kU; ++u)
+      if (cell[u] >= 0) atomicAdd(&cnt[cell[u]], 1u);
+  }
+  __syncthreads();
+  // exclusive scan of the counters in place: wave w owns 2048 consecutive cells and walks them 64 at a time
+  // (consecutive lanes -> consecutive banks), carrying its running offset
+  const int lane = threadIdx.x & 63, w = threadIdx.x >> 6;
+  constexpr int kPerWave = kGridCells / 16;
   unsigned sum = 0;
-  for (int i = 0; i < per; ++i) { loc[i] = cs[1 + threadIdx.x * per + i]; sum += loc[i]; }
-  unsigned tot;
-  unsigned base = block_exscan<unsigned>(sum, red, &tot);
-  for (int i = 0; i < per; ++i) {
-    cur[threadIdx.x * per + i] = base;                   // fill cursor = start of the cell
-    base += loc[i];
-    cs[1 + threadIdx.x * per + i] = base;                // cs[c + 1] = end of cell c (cs[0] stays 0)
+  for (int it = 0; it < kPerWave / 64; ++it) sum += cnt[w * kPerWave + it * 64 + lane];
+  sum = wave_sum_u32(sum);
+  if (lane == 0) red[w] = sum;
+  __syncthreads();
+  unsigned running = 0, tot = 0;
+  for (int i = 0; i < 16; ++i) {
+    if (i < w) running += red[i];
+    tot += red[i];
+  }
+  for (int it = 0; it < kPerWave / 64; ++it) {
+    const int idx = w * kPerWave + it * 64 + lane;
+    const unsigned v = cnt[idx];
+    const unsigned inc = wave_incscan_u32(v);
+    cnt[idx] = running + inc - v;                          // cursor = start of the cell
+    running += __shfl(inc, 63, 64);
+  }
+  __syncthreads();
+  for (int c = threadIdx.x; c < kGridCells; c += 1024) cs[c] = cnt[c];
+  if (threadIdx.x == 0) cs[kGridCells] = tot;
+  __syncthreads();
+  for (long long j0 = threadIdx.x; j0 < P.k; j0 += 1024 * kU) {
+    int cell[kU];
+#pragma unroll
+    for (int u = 0; u < kU; ++u) {
+      const long long j = j0 + (long long)u * 1024;
+      cell[u] = -1;
+      if (j < P.k) {
+        const double* c = C + j * 4;
+        cell[u] = (grid_axis(c[0]) * kGridG + grid_axis(c[1])) * kGridG + grid_axis(c[2]);
+      }
+    }
+#pragma unroll
+    for (int u = 0; u < kU; ++u)
+      if (cell[u] >= 0) order[P.koff + atomicAdd(&cnt[cell[u]], 1u)] = (uint32_t)(j0 + (long long)u * 1024);
   }
 }
 
-__global__ __launch_bounds__(256) void grid_fill_kernel(const MbkP* __restrict__ probs, const double* __restrict__ centres,
-                                                        uint32_t* __restrict__ cursor, uint32_t* __restrict__ order) {
-  const MbkP P = probs[blockIdx.y];
-  const long long j = (long long)blockIdx.x * blockDim.x + threadIdx.x;
-  if (j >= P.k) return;
-  const double* c = centres + (P.koff + j) * 4;
-  const int cell = (grid_axis(c[0]) * kGridG + grid_axis(c[1])) * kGridG + grid_axis(c[2]);
-  const unsigned pos = atomicAdd(&cursor[(size_t)blockIdx.y * kGridCells + cell], 1u);
-  order[P.koff + pos] = (uint32_t)j;
-}
-
-__global__ __launch_bounds__(256) void mbk_assign_grid_kernel(const uint32_t* __restrict__ keys, const MbkP* __restrict__ probs,
-                                                              const double* __restrict__ centres, const uint32_t* __restrict__ cell_start,
-                                                              const uint32_t* __restrict__ order, int32_t* __restrict__ labels,
-                                                              const long long* __restrict__ blk_off) {
-  int p = 0;
-  while (blockIdx.x >= blk_off[p + 1]) ++p;
-  const MbkP P = probs[p];
-  const long long i = ((long long)blockIdx.x - blk_off[p]) * 256 + threadIdx.x;
-  if (i >= P.n) return;
-  const uint32_t kk = keys[P.off + i];
+// nearest centre of one point through the grid: first arg-min of csq_j + (-2) <x, c_j> (ties -> smaller j)
+__device__ __forceinline__ int grid_nearest(uint32_t kk, const uint32_t* __restrict__ cs, const uint32_t* __restrict__ ord,
+                                            const double* __restrict__ C, double* best_out) {
   const double x0 = (double)key_r(kk), x1 = (double)key_g(kk), x2 = (double)key_b(kk);
   const double xsq = (x0 * x0 + x1 * x1) + x2 * x2;
   const int cx = (int)key_r(kk) / kCellSide, cy = (int)key_g(kk) / kCellSide, cz = (int)key_b(kk) / kCellSide;
-  const uint32_t* cs = cell_start + (size_t)p * (kGridCells + 1);
-  const uint32_t* ord = order + P.koff;
-  const double* C = centres + P.koff * 4;
   double bd = INFINITY;
   int bj = 0x7fffffff;
   for (int r = 0; r < kGridG; ++r) {
@@ -952,7 +984,113 @@ __global__ __launch_bounds__(256) void mbk_assign_grid_kernel(const uint32_t* __
       }
     }
   }
-  labels[P.off + i] = bj;
+  if (best_out) *best_out = bd;
+  return bj;
+}
+
+__global__ __launch_bounds__(256) void mbk_assign_grid_kernel(const uint32_t* __restrict__ keys, const MbkP* __restrict__ probs,
+                                                              const double* __restrict__ centres, const uint32_t* __restrict__ cell_start,
+                                                              const uint32_t* __restrict__ order, int32_t* __restrict__ labels,
+                                                              const long long* __restrict__ blk_off) {
+  int p = 0;
+  while (blockIdx.x >= blk_off[p + 1]) ++p;
+  const MbkP P = probs[p];
+  const long long i = ((long long)blockIdx.x - blk_off[p]) * 256 + threadIdx.x;
+  if (i >= P.n) return;
+  labels[P.off + i] = grid_nearest(keys[P.off + i], cell_start + (size_t)p * (kGridCells + 1), order + P.koff, centres + P.koff * 4, nullptr);
+}
+
+// Wave-cooperative variant for the batch E-step: only 1000 points per problem are in flight there, so a
+// thread-per-point walk would be a chain of dependent loads with nothing to hide their latency.  The 64 lanes
+// share one point and take the cells of a ring side by side; same per-centre arithmetic, same arg-min.
+__device__ __forceinline__ void grid_scan_shell(int r_lo, int r_hi, int cx, int cy, int cz, double x0, double x1, double x2,
+                                                const uint32_t* __restrict__ cs, const uint32_t* __restrict__ ord,
+                                                const double* __restrict__ C, double& bd, int& bj) {
+  const int lane = threadIdx.x & 63;
+  const int side = 2 * r_hi + 1, vol = side * side * side;
+  for (int t = lane; t < vol; t += 64) {
+    const int dx = t / (side * side) - r_hi, dy = (t / side) % side - r_hi, dz = t % side - r_hi;
+    if (max(abs(dx), max(abs(dy), abs(dz))) < r_lo) continue;          // interior: searched in an earlier pass
+    const int ix = cx + dx, iy = cy + dy, iz = cz + dz;
+    if ((unsigned)ix >= (unsigned)kGridG || (unsigned)iy >= (unsigned)kGridG || (unsigned)iz >= (unsigned)kGridG) continue;
+    const int cell = (ix * kGridG + iy) * kGridG + iz;
+    const uint32_t e0 = cs[cell], e1 = cs[cell + 1];
+    for (uint32_t e = e0; e < e1; ++e) {
+      const int j = (int)ord[e];
+      const double* c = C + (size_t)j * 4;
+      const double d = c[3] + (-2.0 * km64_dot(x0, x1, x2, c[0], c[1], c[2]));
+      if (d < bd || (d == bd && j < bj)) { bd = d; bj = j; }
+    }
+  }
+  // wave arg-min, ties to the smaller centre index; every lane ends with the result
+#pragma unroll
+  for (int o = 32; o > 0; o >>= 1) {
+    const double od = __shfl_xor(bd, o, 64);
+    const int oj = __shfl_xor(bj, o, 64);
+    if (od < bd || (od == bd && oj < bj)) { bd = od; bj = oj; }
+  }
+}
+
+// batch E-step through the grid (many problems in flight: the brute-force E-step would be the bottleneck);
+// writes the same (distance, label) the tiled kernel + tile reduction produce, into tile 0 of the partials
+__global__ __launch_bounds__(256) void mbk_batch_estep_grid_kernel(const uint32_t* __restrict__ keys, const MbkP* __restrict__ probs,
+                                                                   const double* __restrict__ centres, const double* __restrict__ state,
+                                                                   long long step, unsigned long long seed, const uint32_t* __restrict__ cell_start,
+                                                                   const uint32_t* __restrict__ order, double* __restrict__ pdist,
+                                                                   int32_t* __restrict__ pidx, const long long* __restrict__ part_off) {
+  const int p = blockIdx.y;
+  const MbkP P = probs[p];
+  if (state[p * 16 + 4] != 0.0) return;
+  const int bs = (int)min((long long)1000, P.n);
+  const int b = blockIdx.x * 4 + (threadIdx.x >> 6);     // one wave per batch point
+  if (b >= bs) return;
+  const unsigned long long src = bounded(counter_hash(seed, 2ull * (unsigned long long)step, (unsigned long long)b), (unsigned long long)P.n);
+  const uint32_t kk = keys[P.off + src];
+  const uint32_t* cs = cell_start + (size_t)p * (kGridCells + 1);
+  const uint32_t* ord = order + P.koff;
+  const double* C = centres + P.koff * 4;
+  const double x0 = (double)key_r(kk), x1 = (double)key_g(kk), x2 = (double)key_b(kk);
+  const double xsq = (x0 * x0 + x1 * x1) + x2 * x2;
+  const int cx = (int)key_r(kk) / kCellSide, cy = (int)key_g(kk) / kCellSide, cz = (int)key_b(kk) / kCellSide;
+  double bd = INFINITY;
+  int bj = 0x7fffffff;
+  grid_scan_shell(0, 1, cx, cy, cz, x0, x1, x2, cs, ord, C, bd, bj);   // rings 0 and 1: the 27-cell cube
+  for (int r = 2; r < kGridG; ++r) {
+    const double lb = (double)((r - 1) * kCellSide);     // same stop rule as grid_nearest()
+    if (bd + xsq <= lb * lb - 1e-6) break;
+    grid_scan_shell(r, r, cx, cy, cz, x0, x1, x2, cs, ord, C, bd, bj);
+  }
+  if ((threadIdx.x & 63) == 0) {
+    pdist[part_off[p] + b] = bd;
+    pidx[part_off[p] + b] = bj;
+  }
+}
+
+// ---- init sample order: (Morton code, index) sort keys ------------------------------------------------
+__device__ __forceinline__ uint32_t spread3(uint32_t v) {
+  v &= 0xFFu;
+  v = (v | (v << 16)) & 0xFF0000FFu;
+  v = (v | (v << 8)) & 0x0F00F00Fu;
+  v = (v | (v << 4)) & 0xC30C30C3u;
+  v = (v | (v << 2)) & 0x49249249u;
+  return v;
+}
+__global__ __launch_bounds__(256) void sample_sortkey_kernel(const uint32_t* __restrict__ keys, const MbkP* __restrict__ probs, int n_prob,
+                                                             const int32_t* __restrict__ init_idx, unsigned long long* __restrict__ out,
+                                                             long long total) {
+  const long long t = (long long)blockIdx.x * 256 + threadIdx.x;
+  if (t >= total) return;
+  int p = 0;
+  while (p + 1 < n_prob && probs[p + 1].init_off <= t) ++p;
+  const uint32_t idx = (uint32_t)init_idx[t];
+  const uint32_t kk = keys[probs[p].off + idx];
+  const uint32_t m = (spread3(kk >> 16) << 2) | (spread3(kk >> 8) << 1) | spread3(kk);
+  out[t] = ((unsigned long long)p << 56) | ((unsigned long long)m << 32) | idx;
+}
+__global__ __launch_bounds__(256) void sample_unpack_kernel(const unsigned long long* __restrict__ sorted, int32_t* __restrict__ init_idx,
+                                                            long long total) {
+  const long long t = (long long)blockIdx.x * 256 + threadIdx.x;
+  if (t < total) init_idx[t] = (int32_t)(uint32_t)sorted[t];
 }
 
 static int ensure_scratch(rhccq_ctx* ctx, size_t bytes) {
@@ -1058,6 +1196,48 @@ int rhccq_debug_stamps(unsigned long long* out16_host) {
 }
 #endif
 
+// ---- canonical order of the init samples -------------------------------------------------------------
+// sort key = problem << 56 | Morton code of the sampled colour << 32 | sample index: one device radix sort
+// (rocPRIM through hipCUB) orders the samples of every problem at once by (Morton code, index)
+int64_t rhccq_mbk_order_bytes(int64_t total) { return total <= 0 ? 0 : 16 * total + (8ll << 20); }
+
+int rhccq_mbk_order(rhccq_ctx* ctx, const uint32_t* keys, const rhccq_mbk_problem* probs, int32_t n_prob, int32_t* init_idx, void* tmp,
+                    int64_t tmp_bytes) {
+  if (!ctx || !keys || !probs || !init_idx || !tmp || n_prob <= 0) return rhccq_fail(ctx, RHCCQ_E_ARG, "mbk_order: bad argument");
+  if (n_prob > 256) return rhccq_fail(ctx, RHCCQ_E_LIMIT, "mbk_order: more than 256 problems in one call");
+  std::string stage;
+  stage.resize(sizeof(MbkP) * (size_t)n_prob);
+  MbkP* hp = (MbkP*)stage.data();
+  long long total = 0;
+  for (int i = 0; i < n_prob; ++i) {
+    const rhccq_mbk_problem& q = probs[i];
+    if (q.init_n <= 0 || q.init_off != total || q.n <= 0 || q.n > 0x7fffffffll) return rhccq_fail(ctx, RHCCQ_E_ARG, "mbk_order: bad problem");
+    hp[i] = MbkP{q.off, q.n, q.k, q.koff, q.init_off, q.init_n, q.rand_off, q.first, q.T};
+    total += q.init_n;
+  }
+  if (total > 0x7fffffffll) return rhccq_fail(ctx, RHCCQ_E_LIMIT, "mbk_order: too many samples");
+  if (tmp_bytes < rhccq_mbk_order_bytes(total)) return rhccq_fail(ctx, RHCCQ_E_ARG, "mbk_order: tmp too small");
+  if (int e = ensure_scratch(ctx, align256(sizeof(MbkP) * n_prob))) return e;
+  MbkP* dp = (MbkP*)ctx->scratch;
+  if (int e = put(ctx, dp, hp, sizeof(MbkP) * n_prob)) return e;
+  RHCCQ_HIP(ctx, hipStreamSynchronize(ctx->stream));      // `stage` is pageable host memory
+  unsigned long long* a = (unsigned long long*)tmp;
+  unsigned long long* b = a + total;
+  void* cub_tmp = (void*)(b + total);
+  size_t cub_avail = (size_t)tmp_bytes - 16 * (size_t)total, cub_need = 0;
+  hipcub::DoubleBuffer<unsigned long long> buf(a, b);
+  int top = 56;
+  while ((1 << (top - 56)) < n_prob) ++top;
+  RHCCQ_HIP(ctx, hipcub::DeviceRadixSort::SortKeys(nullptr, cub_need, buf, (int)total, 0, top, ctx->stream));
+  if (cub_need > cub_avail) return rhccq_fail(ctx, RHCCQ_E_LIMIT, "mbk_order: sort scratch exceeds tmp");
+  const unsigned grid = (unsigned)((total + 255) / 256);
+  hipLaunchKernelGGL(sample_sortkey_kernel, dim3(grid), dim3(256), 0, ctx->stream, keys, dp, n_prob, init_idx, a, total);
+  RHCCQ_HIP(ctx, hipcub::DeviceRadixSort::SortKeys(cub_tmp, cub_need, buf, (int)total, 0, top, ctx->stream));
+  hipLaunchKernelGGL(sample_unpack_kernel, dim3(grid), dim3(256), 0, ctx->stream, buf.Current(), init_idx, total);
+  RHCCQ_LAUNCH_CHECK(ctx);
+  return 0;
+}
+
 int rhccq_mbk_init(rhccq_ctx* ctx, const uint32_t* keys, const rhccq_mbk_problem* probs, int32_t n_prob, const int32_t* init_idx,
                    const double* rand, double* centres, int32_t* chosen) {
   if (!ctx || !keys || !probs || !init_idx || !rand || !centres || !chosen || n_prob <= 0)
@@ -1101,12 +1281,26 @@ int rhccq_mbk_steps(rhccq_ctx* ctx, const uint32_t* keys, const rhccq_mbk_proble
   long long blocks;
   int max_tiles;
   if (int e = layout_work(ctx, probs, n_prob, work, work_bytes, &v, &blocks, &max_tiles)) return e;
+  // many problems in flight (a batch of frames): the brute-force E-step (sum k x 1000 float64 distance
+  // evaluations per step) would dominate, so the centres are re-binned every step and the batch is assigned
+  // through the grid; with few problems the tiled brute-force kernel has fewer launches per step
+  long long ksum = 0;
+  for (int i = 0; i < n_prob; ++i) ksum += probs[i].k;
+  bool use_grid = ksum >= 200000;
+  if (const char* e = getenv("RHCCQ_MBK_ESTEP")) use_grid = e[0] == 'g';  // test hook: "grid" / "tiles" (results are identical)
   for (int s = 0; s < n_steps; ++s) {
     const long long step = step0 + s;
-    hipLaunchKernelGGL(mbk_batch_estep_kernel, dim3(max_tiles * kPtChunks, n_prob), dim3(256), 0, ctx->stream, keys, v.probs, centres, state, step,
-                       (unsigned long long)seed, v.pdist, v.pidx, v.part_off);
+    if (use_grid) {
+      hipLaunchKernelGGL(grid_build_kernel, dim3(n_prob), dim3(1024), 0, ctx->stream, v.probs, centres, v.cell_start, v.order,
+                         (const double*)state);
+      hipLaunchKernelGGL(mbk_batch_estep_grid_kernel, dim3(250, n_prob), dim3(256), 0, ctx->stream, keys, v.probs, centres, state, step,
+                         (unsigned long long)seed, v.cell_start, v.order, v.pdist, v.pidx, v.part_off);
+    } else {
+      hipLaunchKernelGGL(mbk_batch_estep_kernel, dim3(max_tiles * kPtChunks, n_prob), dim3(256), 0, ctx->stream, keys, v.probs, centres, state, step,
+                         (unsigned long long)seed, v.pdist, v.pidx, v.part_off);
+    }
     hipLaunchKernelGGL(mbk_update_kernel, dim3(n_prob), dim3(kUpdThreads), 0, ctx->stream, keys, v.probs, centres, weights, state, step,
-                       (unsigned long long)seed, v.pdist, v.pidx, v.part_off);
+                       (unsigned long long)seed, v.pdist, v.pidx, v.part_off, use_grid ? 1 : 0);
   }
   RHCCQ_LAUNCH_CHECK(ctx);
   return 0;
@@ -1120,11 +1314,8 @@ int rhccq_mbk_assign(rhccq_ctx* ctx, const uint32_t* keys, const rhccq_mbk_probl
   int max_tiles;
   if (int e = layout_work(ctx, probs, n_prob, work, work_bytes, &v, &blocks, &max_tiles)) return e;
   if (blocks > 0x7fffffffll) return rhccq_fail(ctx, RHCCQ_E_LIMIT, "mbk_assign: too many points");
-  RHCCQ_HIP(ctx, hipMemsetAsync(v.cell_start, 0, (size_t)n_prob * (kGridCells + 1) * 4, ctx->stream));
-  const dim3 gk((unsigned)((v.max_k + 255) / 256), n_prob);
-  hipLaunchKernelGGL(grid_count_kernel, gk, dim3(256), 0, ctx->stream, v.probs, centres, v.cell_start);
-  hipLaunchKernelGGL(grid_scan_kernel, dim3(n_prob), dim3(1024), 0, ctx->stream, v.cell_start, v.cursor);
-  hipLaunchKernelGGL(grid_fill_kernel, gk, dim3(256), 0, ctx->stream, v.probs, centres, v.cursor, v.order);
+  hipLaunchKernelGGL(grid_build_kernel, dim3(n_prob), dim3(1024), 0, ctx->stream, v.probs, centres, v.cell_start, v.order,
+                     (const double*)nullptr);
   hipLaunchKernelGGL(mbk_assign_grid_kernel, dim3((unsigned)blocks), dim3(256), 0, ctx->stream, keys, v.probs, centres, v.cell_start, v.order,
                      labels_out, v.blk_off);
   RHCCQ_LAUNCH_CHECK(ctx);

@@ -342,13 +342,6 @@ class Rhccq:
             init_size = min(init_size, n)
             rs.randint(0, n, init_size)                      # validation_indices: stream position only
             init_idx = rs.randint(0, n, init_size) if init_size < n else np.arange(n)
-            # canonical sample order: (Morton code of the colour, index): 64 consecutive samples form a
-            # compact box, which is what the exact block pruning of mbk_init_kernel relies on
-            if torch.is_tensor(key_list[i]):
-                skeys = key_list[i][torch.from_numpy(init_idx).to(self.device)].cpu().numpy().view(np.uint32)
-            else:
-                skeys = np.asarray(key_list[i])[init_idx]
-            init_idx = init_idx[np.lexsort((init_idx, morton3(skeys)))]
             T = 2 + int(math.log(k))
             first = first_centre_index(init_size, rs.random_sample())
             u = rs.uniform(size=max((k - 1) * T, 1))
@@ -362,6 +355,11 @@ class Rhccq:
             max_steps = max(max_steps, (100 * n) // bs)
         d_init = self.dev(np.concatenate(init_list))
         d_rand = self.dev(np.concatenate(rand_list))
+        # canonical sample order (Morton code of the colour, index), on the device: 64 consecutive samples
+        # form a compact box, which is what the exact block pruning of mbk_init_kernel relies on
+        obytes = int(self.lib.rhccq_mbk_order_bytes(ioff))
+        otmp = self.empty((obytes,), torch.uint8)
+        self._check(self.lib.rhccq_mbk_order(self.ctx, self._p(keys), probs, n_prob, self._p(d_init), self._p(otmp), obytes), "mbk_order")
         K = int(koff[-1])
         centres = self.zeros((K, 4), torch.float64)
         chosen = self.zeros((K,), torch.int32)

@@ -114,7 +114,11 @@ def test_cluster_means(rh, O):
     assert np.array_equal(O.unpack_rgb(means.cpu().numpy()), want.astype(np.uint8))
 
 
-def test_minibatch_vs_oracle_bit_exact(rh, O):
+@pytest.mark.parametrize("estep", ["tiles", "grid"])
+def test_minibatch_vs_oracle_bit_exact(rh, O, estep, monkeypatch):
+    """Both batch E-step variants (tiled brute force for few problems; per-step re-binned centre grid when a batch
+    of frames puts many problems in flight) against the oracle: step count, centres and labels bit-exact."""
+    monkeypatch.setenv("RHCCQ_MBK_ESTEP", estep)
     g = load("g10_minibatch.npz")
     pal, _ = O.unique_colors(g["img"])
     pal = pal[~np.all(pal == 0, axis=1)]
