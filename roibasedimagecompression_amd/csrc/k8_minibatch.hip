@@ -111,8 +111,12 @@ __device__ unsigned long long g_init_stamps[16];
     _acc[slot] += _t - _last;                        \
     _last = _t;                                      \
   } while (0)
+#define SUBSTART() unsigned long long _sub = clock64()
+#define SUB(slot) do { const unsigned long long _t = clock64(); _acc[slot] += _t - _sub; _sub = _t; } while (0)
 #else
 #define STAMP(slot) do {} while (0)
+#define SUBSTART() do {} while (0)
+#define SUB(slot) do {} while (0)
 #endif
 
 // ---- wave helpers on DPP (VALU, no LDS crossbar): sums / max of one u32 per lane ---------------------
@@ -216,6 +220,7 @@ __device__ __forceinline__ void commit_block(int b, uint32_t ck, uint2 sv, uint2
 
 constexpr int kMaxItems = 16384;           // (candidate, block) work items per step held in LDS
 constexpr int kMaxTouch = 1024;
+constexpr int kEvalItems = 8;             // (candidate, block) items a wave keeps in flight per round of the evaluation
 
 __device__ __forceinline__ void init_body(const uint32_t* __restrict__ keys, const MbkP& P, const int32_t* __restrict__ init_idx,
                                           const double* __restrict__ rand, double* __restrict__ centres, int32_t* __restrict__ cho,
@@ -273,7 +278,7 @@ __device__ __forceinline__ void init_body(const uint32_t* __restrict__ keys, con
   __syncthreads();
   const int persb = (nsb + 63) >> 6;                     // super-blocks per lane in the level-1 search
 #ifdef RHCCQ_STAMPS
-  unsigned long long _acc[8] = {0, 0, 0, 0, 0, 0, 0, 0};
+  unsigned long long _acc[16] = {0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0};
   unsigned long long _last = clock64();
 #endif
   for (int c = 1; c < k; ++c) {
@@ -314,8 +319,9 @@ __device__ __forceinline__ void init_body(const uint32_t* __restrict__ keys, con
             cum += v;
             ++sb;
           }
-          sb = __shfl(sb, src, 64);
-          cum = __shfl(cum, src, 64);
+          sb = __builtin_amdgcn_readlane(sb, src);
+          cum = ((unsigned long long)(unsigned)__builtin_amdgcn_readlane((int)(cum >> 32), src) << 32) |
+                (unsigned)__builtin_amdgcn_readlane((int)(unsigned)cum, src);
           // level 2: the 16 blocks of the super-block
           const int b2 = sb * 16 + (lane & 15);
           const unsigned long long v2 = (lane < 16 && b2 < nb) ? tb.bsum[b2] : 0u;
@@ -324,7 +330,7 @@ __device__ __forceinline__ void init_body(const uint32_t* __restrict__ keys, con
           if (m2) {
             const int l2 = __ffsll((long long)m2) - 1;
             const int b = sb * 16 + l2;
-            const unsigned long long cum2 = cum + __shfl(inc2 - v2, l2, 64);
+            const unsigned long long cum2 = cum + (unsigned)__builtin_amdgcn_readlane((int)(unsigned)(inc2 - v2), l2);
             // level 3: the 64 samples of the block
             const int i = (b << 6) + lane;
             const uint2 sv = samp[i];
@@ -332,7 +338,7 @@ __device__ __forceinline__ void init_body(const uint32_t* __restrict__ keys, con
             const unsigned long long m3 = __ballot(i < n && (double)(cum2 + inc3) >= r);
             const int l3 = m3 ? __ffsll((long long)m3) - 1 : min(63, n - 1 - (b << 6));
             cand = (b << 6) + l3;
-            ck = (uint32_t)__shfl((int)sv.x, l3, 64);
+            ck = (uint32_t)__builtin_amdgcn_readlane((int)sv.x, l3);
             found = true;
           }
         }
@@ -367,26 +373,40 @@ __device__ __forceinline__ void init_body(const uint32_t* __restrict__ keys, con
     STAMP(2);
     const bool use_list = s_items != nullptr && sh.overflow == 0;
     const int n_items = sh.n_items;
+#ifdef RHCCQ_STAMPS
+    _acc[5] += (unsigned long long)n_items;
+    _acc[7] += n_items > 128 ? 1 : 0;
+#endif
     int* touch_w = s_touch + ((c & 1) ? kMaxTouch : 0);      // list written by this step's commit
     int* n_touch_w = &sh.n_touch2[c & 1];
     // ================= phase 2: potentials ==================================================================
-    // all waves share the (candidate, block) items evenly, 8 items (8 x 512 B of samples) in flight per wave
+    // all waves share the (candidate, block) items evenly, kEvalItems (x 512 B of samples) in flight per wave
     if (use_list) {
-      for (int i0 = wave * 8; i0 < n_items; i0 += kInitWaves * 8) {
-        uint32_t it[8];
-        uint2 sv[8];
+      // Items, candidates and block numbers are wave-uniform: they are moved to scalar registers (readlane) so
+      // that the per-item work is a handful of vector instructions -- one CU's four SIMDs issue for all 16
+      // waves, and the instruction count, not memory latency, sets the length of this phase.
+      const uint32_t ckv = lane < T ? sh.ckey[lane] : 0u;              // lane t: key of candidate t
+      const unsigned cnv = norm2_key(ckv);
+      const int n_it = __builtin_amdgcn_readfirstlane(n_items);
+      SUBSTART();
+      for (int i0 = wave * kEvalItems; i0 < n_it; i0 += kInitWaves * kEvalItems) {
+        const uint32_t itv = (lane < kEvalItems && i0 + lane < n_it) ? s_items[i0 + lane] : 0xffffffffu;
+        uint2 sv[kEvalItems];
 #pragma unroll
-        for (int q = 0; q < 8; ++q) it[q] = i0 + q < n_items ? s_items[i0 + q] : 0xffffffffu;
-#pragma unroll
-        for (int q = 0; q < 8; ++q) sv[q] = samp[((it[q] == 0xffffffffu ? 0u : (it[q] & 0xffffffu)) << 6) + lane];
+        for (int q = 0; q < kEvalItems; ++q) {
+          const uint32_t it = (uint32_t)__builtin_amdgcn_readlane((int)itv, q);
+          sv[q] = samp[((it == 0xffffffffu ? 0u : (it & 0xffffffu)) << 6) + lane];
+        }
+        SUB(8);
         // consecutive items mostly belong to one candidate (a candidate appends its blocks in runs): keep a
         // per-lane partial sum while the candidate does not change, reduce across the wave only on a change
         int cur_t = -1;
-        unsigned acc = 0;                                // <= 8 items * 195075 per lane
+        unsigned acc = 0;                                // <= kEvalItems * 195075 per lane
 #pragma unroll
-        for (int q = 0; q < 8; ++q) {
-          if (it[q] == 0xffffffffu) continue;
-          const int t = (int)(it[q] >> 24);
+        for (int q = 0; q < kEvalItems; ++q) {
+          const uint32_t it = (uint32_t)__builtin_amdgcn_readlane((int)itv, q);
+          if (it == 0xffffffffu) break;                  // items are dense: the first gap ends the batch
+          const int t = (int)(it >> 24);
           if (t != cur_t) {
             if (cur_t >= 0) {
               const unsigned sdel = wave_sum_u32(acc);
@@ -395,13 +415,18 @@ __device__ __forceinline__ void init_body(const uint32_t* __restrict__ keys, con
             cur_t = t;
             acc = 0;
           }
-          const unsigned d = (unsigned)dist2_keys(sh.ckey[t], sv[q].x);
-          acc += sv[q].y > d ? sv[q].y - d : 0u;
+          const uint32_t ck = (uint32_t)__builtin_amdgcn_readlane((int)ckv, t);
+          const unsigned na = (unsigned)__builtin_amdgcn_readlane((int)cnv, t);
+          // closest - d, clamped at 0, with d = na + |x|^2 - 2 <ck, x>
+          const unsigned nbna = __builtin_amdgcn_udot4(sv[q].x, sv[q].x, na, false);
+          const unsigned c2d = sv[q].y + 2u * __builtin_amdgcn_udot4(ck, sv[q].x, 0u, false);
+          acc += c2d > nbna ? c2d - nbna : 0u;
         }
         if (cur_t >= 0) {
           const unsigned sdel = wave_sum_u32(acc);
           if (lane == 0 && sdel) atomicAdd(&sh.delta[cur_t], (unsigned long long)sdel);
         }
+        SUB(9);
       }
     } else {
       for (int t = wave; t < T; t += kInitWaves) {
@@ -424,11 +449,23 @@ __device__ __forceinline__ void init_body(const uint32_t* __restrict__ keys, con
     __syncthreads();
     STAMP(3);
     // ================= phase 3: greedy choice + commit ======================================================
-    int best = 0;
-    unsigned long long bd = sh.delta[0];                 // largest reduction == smallest potential; first wins ties
-    for (int t = 1; t < T; ++t)
-      if (sh.delta[t] > bd) { bd = sh.delta[t]; best = t; }
-    const uint32_t kb = sh.ckey[best];
+#ifdef RHCCQ_STAMPS
+    const unsigned long long _am0 = clock64();
+#endif
+    // largest reduction == smallest potential; the first candidate wins ties.  Lane t holds delta[t]: the
+    // wave maximum of the high words, then of the low words among the lanes that share it, then the first lane
+    // (a serial loop over T LDS reads was 10 % of the step)
+    const unsigned long long dv = lane < T ? sh.delta[lane] : 0ull;
+    const unsigned dhi = (unsigned)(dv >> 32), dlo = (unsigned)dv;
+    const unsigned mhi = wave_max_u32(dhi);
+    const unsigned mlo = wave_max_u32(dhi == mhi ? dlo : 0u);
+    const unsigned long long bd = ((unsigned long long)mhi << 32) | mlo;
+    const int best = __ffsll((long long)__ballot(lane < T && dv == bd)) - 1;
+    const uint32_t kb = (uint32_t)__builtin_amdgcn_readlane((int)(lane < T ? sh.ckey[lane] : 0u), best);
+#ifdef RHCCQ_STAMPS
+    _acc[10] += clock64() - _am0 + (kb & 0);
+#endif
+    SUBSTART();
     if (false) {
     } else if (use_list) {
       // lane l of wave w looks at item w + 16 l (one LDS read covers 1024 items); the wave then commits the
@@ -465,6 +502,12 @@ __device__ __forceinline__ void init_body(const uint32_t* __restrict__ keys, con
         }
       }
     }
+    SUB(11);
+#ifdef RHCCQ_STAMPS
+    __syncthreads();
+    _acc[6] += (unsigned long long)*n_touch_w;
+#endif
+    SUB(12);
     if (tid == 0) { cho[c] = sh.cand[best]; sh.pot = pot - bd; sh.n_items = 0; sh.overflow = 0; sh.n_touch2[(c + 1) & 1] = 0; }
     if (tid < T) s_u[((c + 1) & 1) * T + tid] = u_next;
     __syncthreads();
@@ -483,7 +526,7 @@ __device__ __forceinline__ void init_body(const uint32_t* __restrict__ keys, con
   }
 #ifdef RHCCQ_STAMPS
   if (tid == 0 && blockIdx.x == gridDim.x - 1)
-    for (int i = 0; i < 8; ++i) g_init_stamps[i] += _acc[i];
+    for (int i = 0; i < 16; ++i) g_init_stamps[i] += _acc[i];
 #endif
   for (int j = tid; j < k; j += kInitThreads) {
     const uint32_t kk = samp[cho[j]].x;

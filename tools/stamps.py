@@ -23,8 +23,10 @@ out = (ctypes.c_ulonglong * 16)()
 rh.lib.rhccq_debug_stamps.argtypes = [ctypes.c_void_p]
 print("rc", rh.lib.rhccq_debug_stamps(out))
 v = np.array(list(out), dtype=np.float64)
-names = ["search", "enumerate", "barrier1", "evaluate+b2", "commit+b3", "-", "-"]
-tot = v[:7].sum()
-for n, x in zip(names, v[:7]):
+names = ["search", "enumerate", "barrier1", "evaluate+b2", "commit+b3"]
+tot = v[:5].sum()
+print("items/pick", v[5] / (k - 1), "winner blocks/pick", v[6] / (k - 1), "picks with > 128 items", v[7] / (k - 1))
+for n, x in zip(names, v[:5]):
     print(f"{n:18s} {x/ (k-1):10.0f} cycles/step  {100*x/tot:5.1f}%")
 print("total cycles/step", tot / (k - 1))
+print("sub-stamps (wave 0):", {i: round(v[i] / (k - 1)) for i in range(8, 16)})
