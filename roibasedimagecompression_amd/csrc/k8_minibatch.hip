@@ -77,28 +77,44 @@ __device__ __forceinline__ unsigned long long init_exscan64(unsigned long long v
   return base + inc - v;
 }
 
-// squared distance from a colour to a box [lo, hi] (packed keys), exact integers
-__device__ __forceinline__ int box_dist2(uint32_t k, uint32_t lo, uint32_t hi) {
-  const int r = key_r(k), g = key_g(k), b = key_b(k);
-  const int dr = max(max((int)key_r(lo) - r, r - (int)key_r(hi)), 0);
-  const int dg = max(max((int)key_g(lo) - g, g - (int)key_g(hi)), 0);
-  const int db = max(max((int)key_b(lo) - b, b - (int)key_b(hi)), 0);
-  return __mul24(dr, dr) + __mul24(dg, dg) + __mul24(db, db);
+// Squared distance from a colour to a bounding box, exact integers, in 9 instructions: per channel the box is
+// kept as the i16 pair (lo, -hi) and the colour as (-k, k); their packed sum is (lo - k, k - hi), at most one
+// half of which is positive, so clamping at 0 and a packed dot product with itself adds that axis' square.
+typedef short rhccq_s2 __attribute__((ext_vector_type(2)));
+typedef unsigned short rhccq_us2 __attribute__((ext_vector_type(2)));
+struct CandP { uint32_t r, g, b; };                       // (-k, k) pairs of one colour
+__device__ __forceinline__ uint32_t box_pair(unsigned lo, unsigned hi) { return (lo & 0xffffu) | ((0u - hi) << 16); }
+__device__ __forceinline__ int pair_lo(uint32_t x) { return (int)(short)(x & 0xffffu); }
+__device__ __forceinline__ int pair_hi(uint32_t x) { return -(int)(short)(x >> 16); }
+__device__ __forceinline__ CandP cand_pairs(uint32_t k) {
+  const unsigned r = key_r(k), g = key_g(k), b = key_b(k);
+  return CandP{((0u - r) & 0xffffu) | (r << 16), ((0u - g) & 0xffffu) | (g << 16), ((0u - b) & 0xffffu) | (b << 16)};
+}
+__device__ __forceinline__ unsigned box_axis2(uint32_t box, uint32_t kp, unsigned acc) {
+  rhccq_s2 x = __builtin_bit_cast(rhccq_s2, box) + __builtin_bit_cast(rhccq_s2, kp);
+  x = __builtin_elementwise_max(x, (rhccq_s2)(short)0);
+  const rhccq_us2 y = __builtin_bit_cast(rhccq_us2, x);
+  return __builtin_amdgcn_udot2(y, y, acc, false);
+}
+__device__ __forceinline__ unsigned box_dist2(const CandP& c, uint32_t xr, uint32_t xg, uint32_t xb) {
+  return box_axis2(xr, c.r, box_axis2(xg, c.g, box_axis2(xb, c.b, 0u)));
 }
 
 // per problem scratch layout: samp[np] (uint2 = {key, closest}) and, when the tables do not fit LDS,
-// lo[nb] hi[nb] bmax[nb] bsum[nb] sblo[nsb] sbhi[nsb] sbmax[nsb]
+// xr[nb] xg[nb] xb[nb] bmax[nb] bsum[nb] sxr[nsb] sxg[nsb] sxb[nsb] sbmax[nsb] sbsum[nsb]
 //   nb = ceil(init_n / 64) blocks of 64 samples, np = nb * 64, nsb = ceil(nb / 16) super-blocks
-constexpr int kInitLdsBlocks = 4096;   // tables in LDS up to 262144 init samples (64 KB + 3 KB)
+constexpr int kInitLdsBlocks = 4096;   // tables in LDS up to 262144 init samples (80 KB + 5 KB)
 constexpr int kInitLdsSuper = kInitLdsBlocks / 16;
 
 struct InitTables {
-  uint32_t* lo;     // per block: packed min corner of the bounding box
-  uint32_t* hi;     // packed max corner
+  uint32_t* xr;     // per block: bounding box, one (lo, -hi) i16 pair per channel
+  uint32_t* xg;
+  uint32_t* xb;
   uint32_t* bmax;   // max closest distance in the block
   uint32_t* bsum;   // sum of closest distances in the block
-  uint32_t* sblo;   // per super-block (16 blocks): box, max of bmax (may lag high), exact sum of bsum
-  uint32_t* sbhi;
+  uint32_t* sxr;    // per super-block (16 blocks): box, max of bmax (may lag high), exact sum of bsum
+  uint32_t* sxg;
+  uint32_t* sxb;
   uint32_t* sbmax;
   uint32_t* sbsum;
 };
@@ -176,11 +192,11 @@ __device__ __forceinline__ unsigned long long wave_incscan_u64(unsigned long lon
 // bounding box as the largest closest-distance inside it (then no sample of it can improve).
 // enumerate_hits: one wave, all super-blocks; calls f(block) wave-uniformly for every block that may improve.
 template <typename F>
-__device__ __forceinline__ void enumerate_hits(uint32_t ck, int nb, int nsb, const InitTables& tb, F&& f) {
+__device__ __forceinline__ void enumerate_hits(const CandP& ck, int nb, int nsb, const InitTables& tb, F&& f) {
   const int lane = threadIdx.x & 63;
   for (int base = 0; base < nsb; base += 64) {
     const int sb = base + lane;
-    const bool hsb = sb < nsb && (unsigned)box_dist2(ck, tb.sblo[sb], tb.sbhi[sb]) < tb.sbmax[sb];
+    const bool hsb = sb < nsb && box_dist2(ck, tb.sxr[sb], tb.sxg[sb], tb.sxb[sb]) < tb.sbmax[sb];
     unsigned long long msb = __ballot(hsb);
     while (msb) {
       // four hit super-blocks per round: lane -> (which super-block, which of its 16 blocks)
@@ -193,7 +209,7 @@ __device__ __forceinline__ void enumerate_hits(uint32_t ck, int nb, int nsb, con
       const int which = lane >> 4;
       const int my_sb = which == 0 ? sbi[0] : which == 1 ? sbi[1] : which == 2 ? sbi[2] : sbi[3];
       const int b = my_sb * 16 + (lane & 15);
-      const bool hb = my_sb >= 0 && b < nb && (unsigned)box_dist2(ck, tb.lo[b], tb.hi[b]) < tb.bmax[b];
+      const bool hb = my_sb >= 0 && b < nb && box_dist2(ck, tb.xr[b], tb.xg[b], tb.xb[b]) < tb.bmax[b];
       f(__ballot(hb), b, hb);
     }
   }
@@ -248,8 +264,9 @@ __device__ __forceinline__ void init_body(const uint32_t* __restrict__ keys, con
     }
     const unsigned dm = wave_max_u32(sv.y), ds = wave_sum_u32(sv.y);   // <= 64 * 195075 fits 32 bits
     if (lane == 0) {
-      tb.lo[b] = (r0 << 16) | (g0 << 8) | b0;
-      tb.hi[b] = (r1 << 16) | (g1 << 8) | b1;
+      tb.xr[b] = box_pair(r0, r1);
+      tb.xg[b] = box_pair(g0, g1);
+      tb.xb[b] = box_pair(b0, b1);
       tb.bmax[b] = dm;
       tb.bsum[b] = ds;
     }
@@ -257,16 +274,18 @@ __device__ __forceinline__ void init_body(const uint32_t* __restrict__ keys, con
   __syncthreads();
   unsigned long long psum = 0;
   for (int sb = tid; sb < nsb; sb += kInitThreads) {
-    unsigned r0 = 255, g0 = 255, b0 = 255, r1 = 0, g1 = 0, b1 = 0, m = 0, sum = 0;
+    int r0 = 255, g0 = 255, b0 = 255, r1 = 0, g1 = 0, b1 = 0;
+    unsigned m = 0, sum = 0;
     for (int b = sb * 16; b < min(sb * 16 + 16, nb); ++b) {
-      const uint32_t l = tb.lo[b], h = tb.hi[b];
-      r0 = min(r0, key_r(l)); g0 = min(g0, key_g(l)); b0 = min(b0, key_b(l));
-      r1 = max(r1, key_r(h)); g1 = max(g1, key_g(h)); b1 = max(b1, key_b(h));
+      const uint32_t xr = tb.xr[b], xg = tb.xg[b], xb = tb.xb[b];
+      r0 = min(r0, pair_lo(xr)); g0 = min(g0, pair_lo(xg)); b0 = min(b0, pair_lo(xb));
+      r1 = max(r1, pair_hi(xr)); g1 = max(g1, pair_hi(xg)); b1 = max(b1, pair_hi(xb));
       m = max(m, tb.bmax[b]);
       sum += tb.bsum[b];                                // <= 16 * 64 * 195075 < 2^32
     }
-    tb.sblo[sb] = (r0 << 16) | (g0 << 8) | b0;
-    tb.sbhi[sb] = (r1 << 16) | (g1 << 8) | b1;
+    tb.sxr[sb] = box_pair((unsigned)r0, (unsigned)r1);
+    tb.sxg[sb] = box_pair((unsigned)g0, (unsigned)g1);
+    tb.sxb[sb] = box_pair((unsigned)b0, (unsigned)b1);
     tb.sbmax[sb] = m;
     tb.sbsum[sb] = sum;
     psum += sum;
@@ -347,12 +366,15 @@ __device__ __forceinline__ void init_body(const uint32_t* __restrict__ keys, con
       STAMP(0);
       if (lane == 0) { sh.cand[t] = cand; sh.ckey[t] = ck; }
       if (s_items) {
-        enumerate_hits(ck, nb, nsb, tb, [&](unsigned long long mb, int b, bool hb) {
+        enumerate_hits(cand_pairs(ck), nb, nsb, tb, [&](unsigned long long mb, int b, bool hb) {
           const int cnt = __popcll(mb);
+#ifdef RHCCQ_STAMPS
+          _acc[13] += 1; _acc[14] += cnt;
+#endif
           if (cnt == 0) return;
           int base = 0;
           if (lane == 0) base = atomicAdd(&sh.n_items, cnt);
-          base = __shfl(base, 0, 64);
+          base = __builtin_amdgcn_readfirstlane(base);
           if (base + cnt > kMaxItems) { if (lane == 0) sh.overflow = 1; return; }
           if (hb) s_items[base + __popcll(mb & ((1ull << lane) - 1ull))] = ((uint32_t)t << 24) | (uint32_t)b;
         });
@@ -432,7 +454,7 @@ __device__ __forceinline__ void init_body(const uint32_t* __restrict__ keys, con
       for (int t = wave; t < T; t += kInitWaves) {
         const uint32_t ck = sh.ckey[t];
         unsigned long long delta = 0;
-        enumerate_hits(ck, nb, nsb, tb, [&](unsigned long long mb, int b, bool hb) {
+        enumerate_hits(cand_pairs(ck), nb, nsb, tb, [&](unsigned long long mb, int b, bool hb) {
           while (mb) {
             const int p = __ffsll((long long)mb) - 1;
             mb &= mb - 1;
@@ -483,15 +505,16 @@ __device__ __forceinline__ void init_body(const uint32_t* __restrict__ keys, con
       }
     } else {
       // wave w owns super-blocks sb = w (mod 16)
+      const CandP kbp = cand_pairs(kb);
       for (int base = 0; base * kInitWaves + wave < nsb; base += 64) {
         const int sb = (base + lane) * kInitWaves + wave;
-        const bool hsb = sb < nsb && (unsigned)box_dist2(kb, tb.sblo[sb], tb.sbhi[sb]) < tb.sbmax[sb];
+        const bool hsb = sb < nsb && box_dist2(kbp, tb.sxr[sb], tb.sxg[sb], tb.sxb[sb]) < tb.sbmax[sb];
         unsigned long long msb = __ballot(hsb);
         while (msb) {
           const int sx = (base + __ffsll((long long)msb) - 1) * kInitWaves + wave;
           msb &= msb - 1;
           const int b = sx * 16 + (lane & 15);
-          const bool hb = lane < 16 && b < nb && (unsigned)box_dist2(kb, tb.lo[b], tb.hi[b]) < tb.bmax[b];
+          const bool hb = lane < 16 && b < nb && box_dist2(kbp, tb.xr[b], tb.xg[b], tb.xb[b]) < tb.bmax[b];
           unsigned long long mb = __ballot(hb);
           while (mb) {
             const int p = __ffsll((long long)mb) - 1;
@@ -541,7 +564,7 @@ __global__ __launch_bounds__(kInitThreads) void mbk_init_kernel(const uint32_t* 
                                                                 double* __restrict__ centres, int32_t* __restrict__ chosen,
                                                                 uint32_t* scratch, const long long* __restrict__ scratch_off) {
   __shared__ InitShared sh;
-  __shared__ uint32_t s_tab[4 * kInitLdsBlocks + 4 * kInitLdsSuper];
+  __shared__ uint32_t s_tab[5 * kInitLdsBlocks + 5 * kInitLdsSuper];
   __shared__ uint32_t s_items[kMaxItems];
   __shared__ double s_u[2 * kTMaxI];
   __shared__ int s_touch[2 * kMaxTouch];
@@ -550,14 +573,15 @@ __global__ __launch_bounds__(kInitThreads) void mbk_init_kernel(const uint32_t* 
   uint2* samp = reinterpret_cast<uint2*>(scratch + scratch_off[blockIdx.x]);
   InitTables tb;
   if (nb <= kInitLdsBlocks) {
-    tb.lo = s_tab; tb.hi = s_tab + kInitLdsBlocks; tb.bmax = s_tab + 2 * kInitLdsBlocks; tb.bsum = s_tab + 3 * kInitLdsBlocks;
-    tb.sblo = s_tab + 4 * kInitLdsBlocks; tb.sbhi = tb.sblo + kInitLdsSuper; tb.sbmax = tb.sbhi + kInitLdsSuper;
-    tb.sbsum = tb.sbmax + kInitLdsSuper;
+    tb.xr = s_tab; tb.xg = s_tab + kInitLdsBlocks; tb.xb = s_tab + 2 * kInitLdsBlocks;
+    tb.bmax = s_tab + 3 * kInitLdsBlocks; tb.bsum = s_tab + 4 * kInitLdsBlocks;
+    tb.sxr = s_tab + 5 * kInitLdsBlocks; tb.sxg = tb.sxr + kInitLdsSuper; tb.sxb = tb.sxg + kInitLdsSuper;
+    tb.sbmax = tb.sxb + kInitLdsSuper; tb.sbsum = tb.sbmax + kInitLdsSuper;
     init_body(keys, P, init_idx, rand, centres, chosen + P.koff, samp, tb, sh, s_u, s_touch, s_items);
   } else {
     uint32_t* g = reinterpret_cast<uint32_t*>(samp + np);
-    tb.lo = g; tb.hi = g + nb; tb.bmax = g + 2 * nb; tb.bsum = g + 3 * nb;
-    tb.sblo = g + 4 * nb; tb.sbhi = tb.sblo + nsb; tb.sbmax = tb.sbhi + nsb; tb.sbsum = tb.sbmax + nsb;
+    tb.xr = g; tb.xg = g + nb; tb.xb = g + 2 * nb; tb.bmax = g + 3 * nb; tb.bsum = g + 4 * nb;
+    tb.sxr = g + 5 * nb; tb.sxg = tb.sxr + nsb; tb.sxb = tb.sxg + nsb; tb.sbmax = tb.sxb + nsb; tb.sbsum = tb.sbmax + nsb;
     init_body(keys, P, init_idx, rand, centres, chosen + P.koff, samp, tb, sh, s_u, s_touch, nullptr);
   }
 }
@@ -1299,7 +1323,7 @@ int rhccq_mbk_init(rhccq_ctx* ctx, const uint32_t* keys, const rhccq_mbk_problem
     hp[i] = MbkP{q.off, q.n, q.k, q.koff, q.init_off, q.init_n, q.rand_off, q.first, q.T};
     ho[i] = (long long)words;
     const size_t nb = (size_t)((q.init_n + 63) / 64);
-    words += 2 * nb * 64 + 4 * nb + 4 * ((nb + 15) / 16) + 8;
+    words += 2 * nb * 64 + 5 * nb + 5 * ((nb + 15) / 16) + 8;
     words = (words + 63) & ~(size_t)63;
   }
   const size_t head = align256(sizeof(MbkP) * n_prob) + align256(8 * (size_t)n_prob);
