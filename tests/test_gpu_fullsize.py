@@ -1,0 +1,99 @@
+"""Full-size cases of BASELINE.json (configs[1] single 4K frame, configs[2] 1080p two-tier batch) through
+size-independent properties -- the numpy oracle would need hours at these sizes.  GPU only."""
+import numpy as np
+import pytest
+
+pytestmark = pytest.mark.gpu
+
+
+@pytest.fixture(scope="module")
+def rh():
+    from roibasedimagecompression_amd.ops import Rhccq
+    return Rhccq(0)
+
+
+def _frame(rh, H, W, seed, q_roi, q_non, tiles=(2, 1)):
+    import torch
+    from roibasedimagecompression_amd import synth
+    from roibasedimagecompression_amd.frame import ClassSpec
+    img = synth.photo(H, W, seed)
+    (lr, nr, br), (ln, nn, bn) = synth.frame_classes(H, W, tiles)
+    specs = [ClassSpec(torch.from_numpy(lr).to(rh.device), np.zeros(nr, np.int64), [br], q_roi),
+             ClassSpec(torch.from_numpy(ln).to(rh.device), np.zeros(nn, np.int64), [bn], q_non)]
+    return img, torch.from_numpy(img).to(rh.device), specs, lr, ln
+
+
+def _idx(out):
+    idx = out["indices"].cpu().numpy()
+    return (idx.view(np.uint16) if out["indices_dtype"] == "uint16" else idx).astype(np.int64)
+
+
+def test_4k_frame_properties(rh):
+    import torch
+    from roibasedimagecompression_amd.frame import FrameEncoder
+    H, W = 2160, 3840
+    img, rgb, specs, lr, ln = _frame(rh, H, W, 1234, 20, 20)
+    enc = FrameEncoder(rh)
+    a = enc.encode(rgb, specs)
+    b = enc.encode(rgb, specs)
+    assert np.array_equal(a["palette"], b["palette"]) and torch.equal(a["indices"], b["indices"])      # deterministic
+    pal, idx = np.asarray(a["palette"]), _idx(a).reshape(H, W)
+    assert idx.min() >= 0 and idx.max() < len(pal)
+    used = np.bincount(idx.ravel(), minlength=len(pal)) > 0
+    assert used[1:].all()                                    # index 0 is the reserved transparent black (merging.py:60)
+    keys = (img[..., 0].astype(np.uint32) << 16) | (img[..., 1].astype(np.uint32) << 8) | img[..., 2]
+    # one (class, segment, colour) -> one final index: the whole hierarchy is a function of the palette entry
+    rng = np.random.default_rng(0)
+    # (pixels of the 3 px ROI / non-ROI overlap are painted by whichever class comes last: left out)
+    for lab, other in ((lr, ln), (ln, lr)):
+        for s in range(1, int(lab.max()) + 1):
+            pos = np.flatnonzero((lab.ravel() == s) & (other.ravel() == 0))
+            pos = pos[rng.integers(0, len(pos), 400000)]
+            k, i = keys.ravel()[pos], idx.ravel()[pos]
+            order = np.argsort(k, kind="stable")
+            k, i = k[order], i[order]
+            same = k[1:] == k[:-1]
+            assert (i[1:][same] == i[:-1][same]).all()
+    # a pixel covered by both classes (the 3 px overlap) takes the colour of the class painted last; every pixel
+    # decodes to a colour near its own: the three levels average at most eps-connected / k-means neighbours
+    dec = pal[idx]
+    err = dec.astype(np.float64) - img
+    psnr = 10 * np.log10(255.0 ** 2 / np.mean(err ** 2))
+    assert psnr > 28.0, psnr
+    assert np.abs(err).max() < 128
+
+
+def test_4k_dct_extension_parseval(rh):
+    """EXTENSION (no reference counterpart): orthonormal 8x8 DCT-II keeps each block's energy (tolerance 1e-4
+    relative: float32 coefficients of float64 dot products) and its DC term is 8 x the block mean."""
+    import torch
+    H, W = 2160, 3840
+    img, rgb, specs, lr, ln = _frame(rh, H, W, 1234, 20, 20)
+    roi = torch.from_numpy((lr > 0).astype(np.uint8)).to(rh.device)
+    luma, qstep = rh.luma_qstep(rgb, roi, 8, 4.0, 16.0)
+    coef, q = rh.dct_quant(luma, 8, qstep)
+    L = luma.cpu().numpy().astype(np.float64).reshape(H // 8, 8, W // 8, 8)
+    C = coef.cpu().numpy().astype(np.float64).reshape(H // 8, 8, W // 8, 8)
+    e_l, e_c = (L ** 2).sum(axis=(1, 3)), (C ** 2).sum(axis=(1, 3))
+    assert np.abs(e_c - e_l).max() <= 1e-4 * e_l.max()
+    assert np.abs(C[:, 0, :, 0] - 8.0 * L.mean(axis=(1, 3))).max() <= 1e-3
+    qs = qstep.cpu().numpy().astype(np.float64)
+    want = np.rint(C / qs[:, None, :, None])
+    got = q.cpu().numpy().reshape(H // 8, 8, W // 8, 8)
+    assert (np.abs(got - want) <= 1).all() and (got == want).mean() > 0.999     # ties of rint on f32-rounded coef
+
+
+def test_1080p_two_tier_batch_equals_frame_by_frame(rh):
+    """configs[2] shape (two-tier 20/10, 1080p), a batch of 4 instead of 64 to bound the test time"""
+    import torch
+    from roibasedimagecompression_amd.frame import FrameEncoder
+    frames = []
+    for i in range(4):
+        _, rgb, specs, _, _ = _frame(rh, 1080, 1920, 1234 + i, 20, 10, tiles=(3, 4))
+        frames.append((rgb, specs))
+    enc = FrameEncoder(rh)
+    batch = enc.encode_batch(frames)
+    for i in (0, 3):
+        single = enc.encode(*frames[i])
+        assert np.array_equal(single["palette"], batch[i]["palette"])
+        assert torch.equal(single["indices"], batch[i]["indices"])

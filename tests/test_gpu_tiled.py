@@ -20,8 +20,13 @@ def _free_port():
     return p
 
 
-def _inputs():
+def _inputs(size):
     from roibasedimagecompression_amd import synth
+    if size == "8k":                                         # BASELINE.json configs[3]: one 7680x4320 frame
+        H, W = 4320, 7680
+        img = synth.photo(H, W, 1234)
+        (lr, nr, br), (ln, nn, bn) = synth.frame_classes(H, W, (2, 1))
+        return img, (lr, nr, br), (ln, nn, bn)
     H, W = 128, 192
     img = synth.photo(H, W, 31)
     img[60:64, 90:100] = 0                                   # in-segment black across the tile seam
@@ -29,14 +34,14 @@ def _inputs():
     return img, (lr, nr, br), (ln, nn, bn)
 
 
-def _worker(rank, world, port, ret):
+def _worker(rank, world, port, ret, size):
     os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), HSA_ENABLE_IPC_MODE_LEGACY="0")
     dist.init_process_group("gloo", rank=rank, world_size=world)
     try:
         from roibasedimagecompression_amd.frame import ClassSpec
         from roibasedimagecompression_amd.ops import Rhccq
         from roibasedimagecompression_amd.parallel import TiledFrameEncoder, tile_grid
-        img, (lr, nr, br), (ln, nn, bn) = _inputs()
+        img, (lr, nr, br), (ln, nn, bn) = _inputs(size)
         H, W = img.shape[:2]
         rh = Rhccq(0)
         tiles = tile_grid(H, W, 1, world)
@@ -52,10 +57,13 @@ def _worker(rank, world, port, ret):
         dist.destroy_process_group()
 
 
-def test_tiled_two_ranks_equals_single_gpu():
+@pytest.mark.parametrize("size", ["small", "8k"])
+def test_tiled_two_ranks_equals_single_gpu(size):
+    """`8k`: the full-size frame of BASELINE.json configs[3] (too large for the oracle) -- the size-independent
+    property is that the tile-parallel result equals the single-GPU one bit for bit."""
     from roibasedimagecompression_amd.frame import ClassSpec, FrameEncoder
     from roibasedimagecompression_amd.ops import Rhccq
-    img, (lr, nr, br), (ln, nn, bn) = _inputs()
+    img, (lr, nr, br), (ln, nn, bn) = _inputs(size)
     H, W = img.shape[:2]
     rh = Rhccq(0)
     specs = [ClassSpec(torch.from_numpy(lr).to(rh.device), np.zeros(nr, np.int64), [br], 20),
@@ -66,7 +74,9 @@ def test_tiled_two_ranks_equals_single_gpu():
         sidx = sidx.view(np.uint16)
     mgr = mp.Manager()
     ret = mgr.dict()
-    mp.spawn(_worker, args=(2, _free_port(), ret), nprocs=2, join=True)
+    del specs
+    torch.cuda.empty_cache()
+    mp.spawn(_worker, args=(2, _free_port(), ret, size), nprocs=2, join=True)
     full = np.zeros((H, W), np.int64)
     for rank in (0, 1):
         pal, idx, (r0, c0, h, w) = ret[rank]
