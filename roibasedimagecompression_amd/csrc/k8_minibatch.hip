@@ -52,9 +52,10 @@ struct InitShared {
   unsigned long long pots[kTMaxI];
   int cand[kTMaxI];
   uint32_t ckey[kTMaxI];
+  uint32_t ckp[kTMaxI][4];                                // (-k, k) channel pairs of the candidates (box tests)
   unsigned long long delta[kTMaxI];
   unsigned long long pot;
-  int n_touch2[2], n_items, overflow;
+  int n_touch2[2], n_items, overflow, n_hits;
 };
 
 __device__ __forceinline__ unsigned long long init_exscan64(unsigned long long v, InitShared& sh, unsigned long long* total) {
@@ -234,14 +235,15 @@ __device__ __forceinline__ void commit_block(int b, uint32_t ck, uint2 sv, uint2
   }
 }
 
-constexpr int kMaxItems = 16384;           // (candidate, block) work items per step held in LDS
+constexpr int kMaxItems = 12288;           // (candidate, block) work items per step held in LDS
+constexpr int kMaxHits = kTMaxI * kInitLdsSuper;   // (candidate, super-block) pairs per step
 constexpr int kMaxTouch = 1024;
 constexpr int kEvalItems = 8;             // (candidate, block) items a wave keeps in flight per round of the evaluation
 
 __device__ __forceinline__ void init_body(const uint32_t* __restrict__ keys, const MbkP& P, const int32_t* __restrict__ init_idx,
                                           const double* __restrict__ rand, double* __restrict__ centres, int32_t* __restrict__ cho,
                                           uint2* samp, InitTables tb, InitShared& sh, double* s_u /* [2][kTMaxI] */, int* s_touch,
-                                          uint32_t* s_items /* nullptr: no work list (tables in global memory) */) {
+                                          uint32_t* s_items /* nullptr: no work list (tables in global memory) */, uint32_t* s_hits) {
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
   const int n = (int)P.init_n, k = (int)P.k, T = P.T;
   const int nb = (n + 63) >> 6, np = nb << 6, nsb = (nb + 15) >> 4;
@@ -291,7 +293,7 @@ __device__ __forceinline__ void init_body(const uint32_t* __restrict__ keys, con
     psum += sum;
   }
   psum = block_sum<unsigned long long>(psum, sh.red64);
-  if (tid == 0) { cho[0] = P.first; sh.n_touch2[0] = 0; sh.n_touch2[1] = 0; sh.pot = psum; sh.n_items = 0; sh.overflow = 0; }
+  if (tid == 0) { cho[0] = P.first; sh.n_touch2[0] = 0; sh.n_touch2[1] = 0; sh.pot = psum; sh.n_items = 0; sh.overflow = 0; sh.n_hits = 0; }
   if (tid < kTMaxI) sh.delta[tid] = 0;
   if (tid < T && k > 1) s_u[T + tid] = rand[P.rand_off + tid];         // uniforms of step 1 -> buffer 1
   __syncthreads();
@@ -364,22 +366,12 @@ __device__ __forceinline__ void init_body(const uint32_t* __restrict__ keys, con
       }
       if (!found) ck = samp[cand].x;
       STAMP(0);
-      if (lane == 0) { sh.cand[t] = cand; sh.ckey[t] = ck; }
-      if (s_items) {
-        enumerate_hits(cand_pairs(ck), nb, nsb, tb, [&](unsigned long long mb, int b, bool hb) {
-          const int cnt = __popcll(mb);
-#ifdef RHCCQ_STAMPS
-          _acc[13] += 1; _acc[14] += cnt;
-#endif
-          if (cnt == 0) return;
-          int base = 0;
-          if (lane == 0) base = atomicAdd(&sh.n_items, cnt);
-          base = __builtin_amdgcn_readfirstlane(base);
-          if (base + cnt > kMaxItems) { if (lane == 0) sh.overflow = 1; return; }
-          if (hb) s_items[base + __popcll(mb & ((1ull << lane) - 1ull))] = ((uint32_t)t << 24) | (uint32_t)b;
-        });
+      if (lane == 0) {
+        sh.cand[t] = cand;
+        sh.ckey[t] = ck;
+        const CandP cp = cand_pairs(ck);
+        sh.ckp[t][0] = cp.r; sh.ckp[t][1] = cp.g; sh.ckp[t][2] = cp.b;
       }
-      STAMP(1);
     } else {
       // idle waves refresh the super-block maxima the previous winner touched (a stale, larger sbmax is
       // conservative, so the candidate waves may read either value)
@@ -391,6 +383,75 @@ __device__ __forceinline__ void init_body(const uint32_t* __restrict__ keys, con
         if ((i & 15) == 0) tb.sbmax[sb] = m;
       }
     }
+    if (s_items) {
+      // ============ phase 1b: which blocks can each candidate improve?  All 16 waves, two balanced stages ======
+      SUBSTART();
+      __syncthreads();
+      SUB(13);
+      // stage 1: (candidate, 64 super-blocks) units -> list of (candidate, super-block) pairs that pass the box test
+      const int n_chunks = (nsb + 63) >> 6;
+      const float inv_chunks = 1.0f / (float)n_chunks;
+      // (two units / two rounds are kept in flight per wave: each is a chain of dependent LDS accesses)
+      for (int u0 = wave; u0 < T * n_chunks; u0 += 2 * kInitWaves) {
+        bool hit[2];
+        uint32_t word[2];
+#pragma unroll
+        for (int q = 0; q < 2; ++q) {
+          const int u = u0 + q * kInitWaves;
+          const bool uv = u < T * n_chunks;
+          const int t = uv ? (int)(((float)u + 0.5f) * inv_chunks) : 0, chunk = uv ? u - t * n_chunks : 0;
+          const CandP cp{sh.ckp[t][0], sh.ckp[t][1], sh.ckp[t][2]};
+          const int sb = chunk * 64 + lane;
+          const int sbc = min(sb, nsb - 1);
+          hit[q] = uv && sb < nsb && box_dist2(cp, tb.sxr[sbc], tb.sxg[sbc], tb.sxb[sbc]) < tb.sbmax[sbc];
+          word[q] = ((uint32_t)t << 24) | (uint32_t)sb;
+        }
+        const unsigned long long m0 = __ballot(hit[0]), m1 = __ballot(hit[1]);
+        const int c0 = __popcll(m0), c1 = __popcll(m1);
+        if (c0 + c1) {
+          int base = 0;
+          if (lane == 0) base = atomicAdd(&sh.n_hits, c0 + c1);
+          base = __builtin_amdgcn_readfirstlane(base);
+          const unsigned long long below = (1ull << lane) - 1ull;
+          if (hit[0]) s_hits[base + __popcll(m0 & below)] = word[0];
+          if (hit[1]) s_hits[base + c0 + __popcll(m1 & below)] = word[1];
+        }
+      }
+      SUB(14);
+      __syncthreads();
+      SUB(15);
+      // stage 2: four pairs per wave and round, one lane per block of the super-block -> (candidate, block) items
+      const int n_hits = __builtin_amdgcn_readfirstlane(sh.n_hits);
+      for (int h0 = wave * 4; h0 < n_hits; h0 += 2 * kInitWaves * 4) {
+        bool hb[2];
+        uint32_t word[2];
+#pragma unroll
+        for (int q = 0; q < 2; ++q) {
+          const int h = h0 + q * kInitWaves * 4 + (lane >> 4);
+          const uint32_t pv = h < n_hits ? s_hits[h] : 0xffffffffu;
+          const int t = (int)(pv >> 24) & (kTMaxI - 1);
+          const int b = (int)(pv & 0xffffffu) * 16 + (lane & 15);
+          const int bc = min(b, nb - 1);
+          const CandP cp{sh.ckp[t][0], sh.ckp[t][1], sh.ckp[t][2]};
+          hb[q] = pv != 0xffffffffu && b < nb && box_dist2(cp, tb.xr[bc], tb.xg[bc], tb.xb[bc]) < tb.bmax[bc];
+          word[q] = ((uint32_t)t << 24) | (uint32_t)b;
+        }
+        const unsigned long long m0 = __ballot(hb[0]), m1 = __ballot(hb[1]);
+        const int c0 = __popcll(m0), c1 = __popcll(m1);
+        if (c0 + c1) {
+          int base = 0;
+          if (lane == 0) base = atomicAdd(&sh.n_items, c0 + c1);
+          base = __builtin_amdgcn_readfirstlane(base);
+          if (base + c0 + c1 > kMaxItems) { if (lane == 0) sh.overflow = 1; }
+          else {
+            const unsigned long long below = (1ull << lane) - 1ull;
+            if (hb[0]) s_items[base + __popcll(m0 & below)] = word[0];
+            if (hb[1]) s_items[base + c0 + __popcll(m1 & below)] = word[1];
+          }
+        }
+      }
+    }
+    STAMP(1);
     __syncthreads();
     STAMP(2);
     const bool use_list = s_items != nullptr && sh.overflow == 0;
@@ -531,7 +592,7 @@ __device__ __forceinline__ void init_body(const uint32_t* __restrict__ keys, con
     _acc[6] += (unsigned long long)*n_touch_w;
 #endif
     SUB(12);
-    if (tid == 0) { cho[c] = sh.cand[best]; sh.pot = pot - bd; sh.n_items = 0; sh.overflow = 0; sh.n_touch2[(c + 1) & 1] = 0; }
+    if (tid == 0) { cho[c] = sh.cand[best]; sh.pot = pot - bd; sh.n_items = 0; sh.overflow = 0; sh.n_hits = 0; sh.n_touch2[(c + 1) & 1] = 0; }
     if (tid < T) s_u[((c + 1) & 1) * T + tid] = u_next;
     __syncthreads();
     STAMP(4);
@@ -566,6 +627,7 @@ __global__ __launch_bounds__(kInitThreads) void mbk_init_kernel(const uint32_t* 
   __shared__ InitShared sh;
   __shared__ uint32_t s_tab[5 * kInitLdsBlocks + 5 * kInitLdsSuper];
   __shared__ uint32_t s_items[kMaxItems];
+  __shared__ uint32_t s_hits[kMaxHits];
   __shared__ double s_u[2 * kTMaxI];
   __shared__ int s_touch[2 * kMaxTouch];
   const MbkP P = probs[blockIdx.x];
@@ -577,12 +639,12 @@ __global__ __launch_bounds__(kInitThreads) void mbk_init_kernel(const uint32_t* 
     tb.bmax = s_tab + 3 * kInitLdsBlocks; tb.bsum = s_tab + 4 * kInitLdsBlocks;
     tb.sxr = s_tab + 5 * kInitLdsBlocks; tb.sxg = tb.sxr + kInitLdsSuper; tb.sxb = tb.sxg + kInitLdsSuper;
     tb.sbmax = tb.sxb + kInitLdsSuper; tb.sbsum = tb.sbmax + kInitLdsSuper;
-    init_body(keys, P, init_idx, rand, centres, chosen + P.koff, samp, tb, sh, s_u, s_touch, s_items);
+    init_body(keys, P, init_idx, rand, centres, chosen + P.koff, samp, tb, sh, s_u, s_touch, s_items, s_hits);
   } else {
     uint32_t* g = reinterpret_cast<uint32_t*>(samp + np);
     tb.xr = g; tb.xg = g + nb; tb.xb = g + 2 * nb; tb.bmax = g + 3 * nb; tb.bsum = g + 4 * nb;
     tb.sxr = g + 5 * nb; tb.sxg = tb.sxr + nsb; tb.sxb = tb.sxg + nsb; tb.sbmax = tb.sxb + nsb; tb.sbsum = tb.sbmax + nsb;
-    init_body(keys, P, init_idx, rand, centres, chosen + P.koff, samp, tb, sh, s_u, s_touch, nullptr);
+    init_body(keys, P, init_idx, rand, centres, chosen + P.koff, samp, tb, sh, s_u, s_touch, nullptr, nullptr);
   }
 }
 
