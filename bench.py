@@ -66,28 +66,24 @@ def one_step(rh, enc, rgb, specs, roi_mask, block, stage_acc=None, extra=()):
 
 
 def roofline_probe(rh, rgb, specs, iters=5):
-    """Live HIP-event timing (events recorded on the stream the kernel is launched on) of the heaviest
-    HBM-streaming kernel of the path, job_scan_kernel (K0 + K1a: one read of RGB + every class label map,
-    colour-bit set).  Every timed launch starts from cleared bitmaps / stats, as in a real frame."""
+    """HIP-event timing (events recorded on the stream the kernel is launched on) of the heaviest HBM-streaming
+    kernel of the path, job_scan_kernel<true> (K0 + K1a: one read of RGB + every class label map, one byte flag
+    per pixel).  `rh.scan_events` brackets EVERY launch of the process -- the frames of the timed region, the
+    stream-regime probe and `iters` extra back-to-back launches on cleared flags -- so that the average is the
+    one `rocprofv3 --kernel-trace --stats` reports for the same command."""
     import torch
     H, W = int(rgb.shape[0]), int(rgb.shape[1])
     labels = [c.labels for c in specs]
     job_base = np.concatenate([[0], np.cumsum([c.n_seg for c in specs])])[:-1]
     n_jobs = sum(c.n_seg for c in specs)
-    total = 0.0
-    for it in range(iters + 1):
+    n_before = len(rh.scan_events)
+    for it in range(iters):
         bitmaps, stats = rh.new_job_state(n_jobs)
-        bytemaps = rh.zeros((n_jobs, 1 << 24), torch.uint8)      # byte colour flags, cleared like in a real frame
-        torch.cuda.synchronize()
-        ev0, ev1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
-        n, ptrs, bases = rh._class_args(labels, job_base)
-        ev0.record(rh.stream)
-        rh._check(rh.lib.rhccq_job_scan_bytes(rh.ctx, rh._p(rgb), H, W, n, ptrs, bases, 0, rh._p(bytemaps), rh._p(stats)), "job_scan_bytes")
-        ev1.record(rh.stream)
-        torch.cuda.synchronize()
-        if it > 0:                                  # first launch = warm-up
-            total += ev0.elapsed_time(ev1) * 1e-3
-    t = total / iters
+        rh.job_scan(rgb, labels, job_base, bitmaps, stats, black_is_colour=False)
+    torch.cuda.synchronize()
+    times = [e0.elapsed_time(e1) * 1e-3 for e0, e1 in rh.scan_events]
+    t = float(np.mean(times))
+    t_probe = float(np.mean(times[n_before:]))
     px = H * W
     algo_bytes = px * (3 + 4 * len(specs))          # RGB + one int32 label per class, read once
     # HBM traffic per launch from the PMC passes kept under profiles/ (separate FETCH_SIZE / WRITE_SIZE runs of
@@ -100,8 +96,35 @@ def roofline_probe(rh, rgb, specs, iters=5):
             traffic = (2 * rec["FETCH_SIZE"]["mean"] + rec["WRITE_SIZE"]["mean"]) * 1024
     return {"bound": "hbm", "kernel": "job_scan_kernel<true>", "achieved": algo_bytes / t / 1e9, "peak": HBM_PEAK_GBS,
             "unit": "GB/s", "frac": algo_bytes / t / 1e9 / HBM_PEAK_GBS, "traffic": traffic,
-            "algorithmic_bytes_per_launch": algo_bytes, "avg_launch_s": t,
-            "note": "per-pixel passes are < 0.3 % of the step; the step is bound by the sequential k-means++ chain (mbk_init_kernel)"}
+            "algorithmic_bytes_per_launch": algo_bytes, "avg_launch_s": t, "launches": len(times),
+            "avg_launch_s_back_to_back": t_probe,
+            "note": "per-pixel passes are < 0.3 % of the step; the step is bound by the sequential k-means++ chain "
+                    "(dominant_kernel); launches inside a 16-frame batch (1 GiB of byte flags live) run ~195 us, "
+                    "single-frame launches ~140-185 us"}
+
+
+def chain_probe(rh, enc, rgb, specs, ms_per_step):
+    """The kernel that dominates the step: mbk_init_kernel, the sequential k-means++ chain of the level-1
+    MiniBatchKMeans problems (one workgroup per segment palette).  HIP events around its launch."""
+    import math
+    S = enc.prepare(rgb, specs)
+    jobs, _ = enc.level1_jobs(S)
+    parts, ks = [], []
+    for jb in jobs:
+        if "keys_dev" not in jb:
+            continue
+        nbk = jb["keys_dev"][1:] if jb["has_black"] else jb["keys_dev"]
+        if int(nbk.numel()) >= 10000:
+            parts.append(nbk)
+            ks.append(math.ceil(int(nbk.numel()) * (jb["quality"] / 100) / 10))
+    if not parts:
+        return None
+    t = {}
+    rh.minibatch_kmeans(parts, ks, return_device=True, timing=t)
+    return {"kernel": "mbk_init_kernel", "launch_ms": t["init_ms"], "problems": len(ks), "picks_longest_chain": max(ks),
+            "us_per_pick": t["init_ms"] * 1e3 / max(ks), "share_of_step": t["init_ms"] / ms_per_step,
+            "bound": "one workgroup per problem; each pick depends on the previous one; the per-pick time is the "
+                     "instruction issue of one CU over ~1000 instructions per wave (DESIGN.md section 3)"}
 
 
 def neighbour_probe(rh):
@@ -174,6 +197,7 @@ def main():
     from roibasedimagecompression_amd.ops import Rhccq
     from roibasedimagecompression_amd.frame import FrameEncoder
     rh = Rhccq(local)
+    rh.scan_events = []
     enc = FrameEncoder(rh)
     H, W = args.height, args.width
     # at >= 4K the reference's SLIC scaling yields <= 2 segments per region (SURVEY.md 8a preface)
@@ -223,14 +247,12 @@ def main():
         line["final_colours"] = int(len(out["palette"]))
         line["unique_colours_per_segment"] = [int(v) for v in out["n_unique"]]
         if not args.no_probes and world == 1:
-            line["roofline"] = roofline_probe(rh, rgb, specs)
+            line["dominant_kernel"] = chain_probe(rh, enc, rgb, specs, dt / args.steps * 1e3 / B)
             line["neighbour_pass"] = neighbour_probe(rh)
-        else:
-            line["roofline"] = roofline_probe(rh, rgb, specs)
         if not args.no_probes and world == 1 and B == 1:
-            # the same path in the stream regime (configs[4]: many 4K frames in flight): 8 frames per step share
+            # the same path in the stream regime (configs[4]: many 4K frames in flight): 16 frames per step share
             # one batched clustering launch per level, so the sequential k-means++ chains run side by side
-            nb = 8
+            nb = 16
             more = []
             for i in range(1, nb):
                 _, r_i, sp_i, m_i, _ = build_inputs(rh, H, W, 1234 + i, (2, 1), args.quality, args.quality, args.sigma)
@@ -242,8 +264,9 @@ def main():
             torch.cuda.synchronize()
             d1 = time.perf_counter() - t1
             line["stream_regime"] = {"frames_per_step": nb, "value": nb * H * W / d1 / 1e6, "unit": "Mpixels/s", "ms_per_step": d1 * 1e3,
-                                     "note": "python bench.py --frames-per-step 8 times this regime as the main value"}
+                                     "note": "python bench.py --frames-per-step 16 times this regime as the main value"}
             del more
+        line["roofline"] = roofline_probe(rh, rgb, specs)
         if args.cpu_sample and world == 1:
             line["cpu_baseline"] = cpu_baseline(img, lr, ln, args.cpu_sample, args.quality)
         else:

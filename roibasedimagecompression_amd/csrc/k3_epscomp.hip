@@ -5,13 +5,17 @@
 // encoder/compression/clustering.py:233-235 (KD-tree radius_neighbors materialising ~N^2 neighbour
 // lists + Cython DFS).
 //
-// MI355X design (one workgroup per palette, everything staged in LDS; the palette is <= 40 KB):
-//   K3  fixed-radius neighbour pass over an LDS-staged spatial grid in RGB space.  Cells have side
-//       s with 3 (s-1)^2 <= eps^2 whenever that keeps the grid <= 16^3: then all points of a cell are
-//       mutually within eps (a clique) and only ONE witness pair per pair of nearby cells is needed;
-//       a wave searches a cell pair 64 candidate pairs at a time and stops at the first hit
-//       (wave ballot).  For small eps (cell side fixed at 16) every pair of nearby cells is tested
-//       exhaustively.
+// MI355X design (one workgroup per palette).  Two kernels share the algorithm:
+//   eps_components_lds_kernel  palettes of <= RHCCQ_EPS_LDS_MAX points (every DBSCAN-branch palette of the
+//       reference: N < 10 000): keys, parents, the cell permutation and a grid of up to 30^3 cells (packed u16
+//       counters) all live in LDS; sparse palettes (n < 3 x occupied cells) switch to one thread per point.
+//   eps_components_kernel      larger inputs of the generic entry point: same passes, arrays in global
+//       memory, grid <= 16^3.
+//   K3  fixed-radius neighbour pass over the RGB grid.  Cells have side s with 3 (s-1)^2 <= eps^2 whenever that
+//       keeps the grid within its cap: then all points of a cell are mutually within eps (a clique) and only
+//       ONE witness pair per pair of nearby cells is needed; a wave searches a cell pair 64 candidate pairs at
+//       a time and stops at the first hit (wave ballot).  For small eps (cell side at its minimum) every pair
+//       of nearby cells is tested exhaustively.
 //   K4  lock-free union-find in LDS (root = smallest index, atomicCAS linking, path halving), then a
 //       flag + block prefix-sum turns roots into sklearn's label order.
 // The eps predicate is the exact integer d2 <= thr; pairs with d2 == boundary (eps^2 integral) are
@@ -22,7 +26,7 @@
 namespace rhccq {
 
 constexpr int kEpsThreads = 512;
-constexpr int kMaxCells = 4096;  // 16^3
+constexpr int kMaxCells = 4096;  // 16^3 (global-memory variant)
 
 struct EpsArrays {
   uint32_t* keys;     // [n]

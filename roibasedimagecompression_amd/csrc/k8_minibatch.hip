@@ -120,7 +120,7 @@ struct InitTables {
   uint32_t* sbsum;
 };
 
-#ifdef RHCCQ_STAMPS   // diagnostic build only (tools_stamps.py): per-phase cycle shares of the init chain
+#ifdef RHCCQ_STAMPS   // diagnostic build only (tools/stamps.py): per-phase cycle shares of the init chain
 __device__ unsigned long long g_init_stamps[16];
 #define STAMP(slot)                                  \
   do {                                               \

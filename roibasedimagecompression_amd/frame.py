@@ -81,24 +81,27 @@ def _merge(comps, bbox):
         return None
     if len(comps) == 1:
         return comps[0]
-    seqs = []
+    seqs, sel = [], []
     for c in reversed(comps):
         valid = np.nonzero((c.keys != 0) & (c.fp < _FP_NONE))[0]
-        seqs.append(c.keys[valid[np.argsort(c.fp[valid])]])   # first positions of distinct entries are distinct
+        v = valid[np.argsort(c.fp[valid])]                    # first positions of distinct entries are distinct
+        sel.append(v)
+        seqs.append(c.keys[v])
     allk = np.concatenate(seqs) if seqs else np.zeros(0, np.uint32)
-    u, first = np.unique(allk, return_index=True)
+    u, first, inv = np.unique(allk, return_index=True, return_inverse=True)
     order = np.argsort(first, kind="stable")
     gkeys = np.concatenate([np.zeros(1, np.uint32), u[order]])
     rank = np.empty(len(u), np.int64)
     rank[order] = np.arange(1, len(u) + 1)
+    gidx = rank[inv.reshape(-1)]                              # global index of every listed entry, in allk order
     gfp = np.full(len(gkeys), _FP_NONE, np.int64)
     maps = {}
-    for c in comps:
-        valid = (c.keys != 0) & (c.fp < _FP_NONE)
-        lut = np.zeros(len(c.keys), np.int32)                  # black / unused -> canvas 0
-        pos = np.searchsorted(u, c.keys[valid])
-        lut[valid] = rank[pos]
-        _scatter_min(len(gfp), lut[valid], c.fp[valid], out=gfp)
+    off = len(allk)
+    for c, v in zip(comps, reversed(sel)):                    # comps in their own order; allk holds them reversed
+        off -= len(v)
+        lut = np.zeros(len(c.keys), np.int32)                 # black / unused -> canvas 0
+        lut[v] = gidx[off:off + len(v)]
+        _scatter_min(len(gfp), lut[v], c.fp[v], out=gfp)
         for job, m in c.maps.items():
             maps[job] = lut[m]
     minr, minc, maxr, maxc = bbox

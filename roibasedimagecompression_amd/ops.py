@@ -14,6 +14,7 @@ Reference functions served (paths relative to the reference root):
 """
 import ctypes as C
 import math
+import os
 
 import numpy as np
 import torch
@@ -25,6 +26,17 @@ INT_MAX = 2 ** 31 - 1
 BITMAP_WORDS = 524288
 MINIBATCH_THRESHOLD = 10000          # clustering.py:205
 SEED = 42                            # random_state=42 at every sklearn call site of the reference
+
+
+_RNG_POOL = None
+
+
+def _rng_pool():
+    global _RNG_POOL
+    if _RNG_POOL is None:
+        from concurrent.futures import ThreadPoolExecutor
+        _RNG_POOL = ThreadPoolExecutor(max_workers=min(8, os.cpu_count() or 1))
+    return _RNG_POOL
 
 
 def pack_rgb(rgb):
@@ -174,6 +186,7 @@ class Rhccq:
         return bitmaps, stats
 
     BYTEMAP_MAX_JOBS = 64        # 16 MiB of byte flags per job: up to 1 GiB of the 288 GB
+    scan_events = None           # a list here makes job_scan() bracket its kernel with HIP events (bench.py)
 
     def job_scan(self, rgb, labels, job_base, bitmaps, stats, black_is_colour, bytemaps=None):
         """K0 + K1a.  With few jobs the colour flags go through byte maps (plain stores) and are packed into
@@ -184,8 +197,15 @@ class Rhccq:
         if bytemaps is None and n_jobs <= self.BYTEMAP_MAX_JOBS:
             bytemaps = self.zeros((n_jobs, 1 << 24), torch.uint8)
         if bytemaps is not None:
+            ev = None
+            if self.scan_events is not None:                  # measurement hook (bench.py): HIP events on the launch stream
+                ev = (torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True))
+                ev[0].record()
             self._check(self.lib.rhccq_job_scan_bytes(self.ctx, self._p(rgb), H, W, n, ptrs, bases, int(black_is_colour),
                                                       self._p(bytemaps), self._p(stats)), "job_scan_bytes")
+            if ev is not None:
+                ev[1].record()
+                self.scan_events.append(ev)
             self._check(self.lib.rhccq_bytemap_pack(self.ctx, self._p(bytemaps), n_jobs, self._p(bitmaps)), "bytemap_pack")
         else:
             self._check(self.lib.rhccq_job_scan(self.ctx, self._p(rgb), H, W, n, ptrs, bases, int(black_is_colour),
@@ -316,11 +336,12 @@ class Rhccq:
         return out[:k], sums[:k]
 
     # -- K8 -----------------------------------------------------------------------------------------
-    def minibatch_kmeans(self, key_list, k_list, return_info=False, poll_steps=64, return_device=False):
+    def minibatch_kmeans(self, key_list, k_list, return_info=False, poll_steps=64, return_device=False, timing=None):
         """Batched MiniBatchKMeans(k, batch_size=1000, random_state=42).fit_predict labels in the
         canonical arithmetic of oracle.minibatch_kmeans_labels.  key_list items are numpy arrays or
         device int32 tensors (kept resident); labels come back as numpy arrays, or as device tensors
-        with return_device=True."""
+        with return_device=True.  `timing` (a dict) receives the HIP-event duration of the k-means++ launch
+        (events on the launch stream)."""
         n_prob = len(key_list)
         if n_prob == 0:
             return ([], []) if return_info else []
@@ -333,7 +354,10 @@ class Rhccq:
         init_list, rand_list = [], []
         ioff = roff = 0
         max_steps = 0
-        for i, (n, k) in enumerate(zip(sizes, k_list)):
+        def draw(args):
+            # numpy's legacy generator releases the GIL while it fills arrays: the streams of the problems are
+            # drawn side by side (the GPU is idle until the init kernel has them)
+            n, k = args
             rs = np.random.RandomState(SEED)
             bs = min(1000, n)
             init_size = 3 * bs
@@ -345,14 +369,20 @@ class Rhccq:
             T = 2 + int(math.log(k))
             first = first_centre_index(init_size, rs.random_sample())
             u = rs.uniform(size=max((k - 1) * T, 1))
+            return init_idx.astype(np.int32), T, first, u
+
+        todo = list(zip(sizes, k_list))
+        drawn = list(_rng_pool().map(draw, todo)) if n_prob > 1 else [draw(todo[0])]
+        for i, ((n, k), (init_idx, T, first, u)) in enumerate(zip(todo, drawn)):
+            init_size = len(init_idx)
             p = probs[i]
             p.off, p.n, p.k, p.koff = int(offs[i]), n, k, int(koff[i])
             p.init_off, p.init_n, p.rand_off, p.first, p.T = ioff, init_size, roff, first, T
-            init_list.append(init_idx.astype(np.int32))
+            init_list.append(init_idx)
             rand_list.append(u)
             ioff += init_size
             roff += len(u)
-            max_steps = max(max_steps, (100 * n) // bs)
+            max_steps = max(max_steps, (100 * n) // min(1000, n))
         d_init = self.dev(np.concatenate(init_list))
         d_rand = self.dev(np.concatenate(rand_list))
         # canonical sample order (Morton code of the colour, index), on the device: 64 consecutive samples
@@ -363,8 +393,15 @@ class Rhccq:
         K = int(koff[-1])
         centres = self.zeros((K, 4), torch.float64)
         chosen = self.zeros((K,), torch.int32)
+        if timing is not None:
+            ev = (torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True))
+            ev[0].record()
         self._check(self.lib.rhccq_mbk_init(self.ctx, self._p(keys), probs, n_prob, self._p(d_init), self._p(d_rand),
                                             self._p(centres), self._p(chosen)), "mbk_init")
+        if timing is not None:
+            ev[1].record()
+            ev[1].synchronize()
+            timing["init_ms"] = ev[0].elapsed_time(ev[1])
         weights = self.zeros((K,), torch.float64)
         st0 = np.zeros((n_prob, 16))
         st0[:, 8] = k_list                                   # every centre starts with zero weight
