@@ -190,10 +190,16 @@ def main():
     world = int(os.environ.get("WORLD_SIZE", "1"))
     rank = int(os.environ.get("RANK", "0"))
     local = int(os.environ.get("LOCAL_RANK", "0"))
+    rehearsal = os.environ.get("RHCCQ_BENCH_REHEARSAL") == "1"     # several ranks on ONE GPU over gloo: exercises the
+    if rehearsal:                                                   # launch path on a one-GPU box, never a bench line
+        local = 0
     if world > 1:
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
         torch.cuda.set_device(local)
-        dist.init_process_group("nccl", device_id=torch.device("cuda", local))
+        if rehearsal:
+            dist.init_process_group("gloo")
+        else:
+            dist.init_process_group("nccl", device_id=torch.device("cuda", local))
     from roibasedimagecompression_amd.ops import Rhccq
     from roibasedimagecompression_amd.frame import FrameEncoder
     rh = Rhccq(local)
@@ -234,7 +240,7 @@ def main():
         "metric": "Mpixels/s encoded (ROI cluster + DCT/quant) at 4K RGB",
         "value": px / dt / 1e6, "unit": "Mpixels/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
         "ms_per_step": dt / args.steps * 1e3, "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
-        "dtype": "u8 keys / int32 exact k-means++ / f64 Lloyd+mini-batch", "data": "synthetic",
+        "dtype": "u8 keys / int32 exact k-means++ / f64 Lloyd+mini-batch", "data": "synthetic" + (" (REHEARSAL: ranks share one GPU)" if rehearsal else ""),
         "config": {"workload": (f"configs[1]: single {W}x{H} RGB synthetic 'photo' frame per GPU (seed 1234+rank, sigma={args.sigma}), " if B == 1 else
                                 f"batch of {B} {W}x{H} RGB synthetic 'photo' frames per GPU per step (seeds 1234+rank*{B}+i, sigma={args.sigma}), ")
                                + f"one quality tier q={args.quality} (levels {args.quality}/{min(2*args.quality,100)}/{min(4*args.quality,100)}), "
