@@ -285,7 +285,7 @@ class Rhccq:
             thr, bnd, rr = eps_threshold(e)
             desc[i] = (offs[i], sizes[i], thr, bnd)
             r2[i] = rr
-        keys = self.dev(np.concatenate([np.asarray(k).astype(np.int64) for k in key_list]).astype(np.int32))
+        keys = self.dev(np.concatenate(key_list).astype(np.uint32).view(np.int32))
         d_desc, d_r2 = self.dev(desc), self.dev(r2)
         labels = self.empty((int(offs[-1]),), torch.int32)
         ncomp = self.empty((n_prob,), torch.int32)
@@ -313,7 +313,7 @@ class Rhccq:
             desc[i] = (offs[i], n, k, 0, first_centre_index(n, u0), T)
             need = max(need, (k - 1) * T)
         rand = self.mt.ensure(need, self.device)
-        keys = self.dev(np.concatenate([np.asarray(k).astype(np.int64) for k in key_list]).astype(np.int32))
+        keys = self.dev(np.concatenate(key_list).astype(np.uint32).view(np.int32))
         d_desc, d_koff = self.dev(desc), self.dev(koff[:-1].copy())
         work = self.empty((8 * int(koff[-1]) + 8,), torch.float64)
         labels = self.empty((int(offs[-1]),), torch.int32)

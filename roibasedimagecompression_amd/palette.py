@@ -144,15 +144,27 @@ def cluster_palettes(rh, jobs):
         if not run:
             break
         labs = rh.kmeans_split([jobs[nd.seg]["keys"][nb_idx[nd.seg][nd.members]] for nd, _ in run], [k for _, k in run])
-        for (nd, k), lab in zip(run, labs):
+        # children of every node of this level at once: one stable sort of (node, label) instead of an argsort
+        # per node (a 4K frame has ~10^2 split nodes per level, a batch of frames ~10^3)
+        sizes = np.array([len(l) for l in labs], np.int64)
+        cat = np.concatenate(labs).astype(np.int64)
+        node_of = np.repeat(np.arange(len(run), dtype=np.int64), sizes)
+        members = np.concatenate([nd.members for nd, _ in run])
+        key = node_of * (int(cat.max()) + 1) + cat
+        order = np.argsort(key, kind="stable")                     # ascending label; ascending index inside
+        skey = key[order]
+        starts = np.concatenate([[0], np.flatnonzero(skey[1:] != skey[:-1]) + 1, [len(skey)]])
+        child_node = node_of[order[starts[:-1]]]
+        smem = members[order]
+        for nd, _ in run:
             nd.children = []
-            order = np.argsort(lab, kind="stable")
-            bounds = np.flatnonzero(np.diff(lab[order])) + 1
-            for sub in np.split(order, bounds):
-                ch = _Node(nd.seg, nd.members[sub])
-                nd.children.append(ch)
-                if len(ch.members) > jobs[nd.seg]["mc"] and _n_splits(len(ch.members), jobs[nd.seg]["mc"]) > 0:
-                    frontier.append(ch)
+        for ci in range(len(starts) - 1):
+            nd = run[child_node[ci]][0]
+            ch = _Node(nd.seg, smem[starts[ci]:starts[ci + 1]])
+            nd.children.append(ch)
+            mc = jobs[nd.seg]["mc"]
+            if len(ch.members) > mc and _n_splits(len(ch.members), mc) > 0:
+                frontier.append(ch)
     # ---- leaves in reference order, floor means on the device (K2)
     results = []
     all_keys, all_leaf = [], []
