@@ -1,6 +1,7 @@
-"""Placeholder for a stage that is UPSTREAM/DOWNSTREAM of the MI355X hot path (SURVEY.md 8f "next" rows).
-The names exist so that the reference's import lines resolve; a deployment keeps the reference's own
-module here (it needs OpenCV / scikit-image, which this build does not re-implement yet)."""
+"""decoder/uncompression/comparison.py of the reference: `calculate_quality_metrics` runs on the MI355X
+(roibasedimagecompression_amd/api/comparison.py); the OpenCV / matplotlib helpers of that module are placeholders
+-- a deployment keeps the reference's own functions for them."""
+from roibasedimagecompression_amd.api.comparison import calculate_quality_metrics  # noqa: F401
 
 
 def _upstream(name):
@@ -11,7 +12,6 @@ def _upstream(name):
     return fn
 
 
-calculate_quality_metrics = _upstream("calculate_quality_metrics")
 create_difference_visualization = _upstream("create_difference_visualization")
 print_quality_report = _upstream("print_quality_report")
 plot_comparison = _upstream("plot_comparison")

@@ -181,6 +181,19 @@ int rhccq_merge_paint(rhccq_ctx* ctx, const int32_t* idx, int32_t h, int32_t w, 
 int rhccq_decode(rhccq_ctx* ctx, const void* idx, int32_t idx_elem_bytes, int64_t n, const uint8_t* palette,
                  int64_t pal_n, uint8_t* rgb_out);
 
+/* ---- quality metrics (decoder/uncompression/comparison.py:30-80 calculate_quality_metrics) ------
+ * a, b: uint8 RGB interleaved device images (4-byte aligned), n_pixels = H*W.
+ * sums5 (device): [0..2] sum of squared differences per channel, [3] sum of |differences|, [4] max |difference|
+ * -> MSE / RMSE / MAE / max error / per-channel MSE / PSNR (comparison.py:40,63-78) on the host. */
+int rhccq_error_sums(rhccq_ctx* ctx, const uint8_t* a, const uint8_t* b, int64_t n_pixels, uint64_t* sums5);
+/* structural_similarity(a, b, data_range=255, channel_axis=2, win_size=7) (comparison.py:47-49; algorithm of
+ * scikit-image, unpinned by the reference): partial (device) receives, per workgroup tile, the sum over its
+ * window centres of S for each channel; mean SSIM = sum(partial) / ((H-6)*(W-6)) averaged over the channels.
+ * rhccq_ssim7_blocks gives the number of tiles (host only). */
+int64_t rhccq_ssim7_blocks(int32_t H, int32_t W);
+int rhccq_ssim7_sums(rhccq_ctx* ctx, const uint8_t* a, const uint8_t* b, int32_t H, int32_t W, double* partial,
+                     int64_t n_blocks);
+
 /* ---- EXTENSION (no reference counterpart): block DCT-II + region quantisation --
  * plane: float32[H*W]; block in {8,16}; qstep: float32 per tile [(H/block)*(W/block)];
  * coef_out float32[H*W] (may be NULL), q_out int16[H*W]. */

@@ -761,6 +761,61 @@ def decode_container(pkg):
 
 
 # --------------------------------------------------------------------------------------
+# Quality metrics (decoder/uncompression/comparison.py:30-80).  PARITY UNPINNED for ssim / psnr: the
+# reference calls scikit-image (absent from the build container, unpinned in requirements.txt), so these
+# restate scikit-image's published algorithm with scipy.ndimage.uniform_filter (the routine it calls).
+# --------------------------------------------------------------------------------------
+def structural_similarity_win7(x, y):
+    """skimage.metrics.structural_similarity(x, y, data_range=255, win_size=7) for one 2-D uint8 channel:
+    uniform filter, sample covariance (cov_norm = NP / (NP - 1)), K1 = 0.01, K2 = 0.03, mean over the
+    region a full window fits (crop by (win_size - 1) // 2)."""
+    from scipy.ndimage import uniform_filter
+    if min(x.shape) < 7:
+        raise ValueError("win_size exceeds image extent")
+    x = x.astype(np.float64)
+    y = y.astype(np.float64)
+    NP = 49
+    cov_norm = NP / (NP - 1)
+    ux = uniform_filter(x, size=7)
+    uy = uniform_filter(y, size=7)
+    uxx = uniform_filter(x * x, size=7)
+    uyy = uniform_filter(y * y, size=7)
+    uxy = uniform_filter(x * y, size=7)
+    vx = cov_norm * (uxx - ux * ux)
+    vy = cov_norm * (uyy - uy * uy)
+    vxy = cov_norm * (uxy - ux * uy)
+    R = 255.0
+    C1 = (0.01 * R) ** 2
+    C2 = (0.03 * R) ** 2
+    A1, A2, B1, B2 = (2 * ux * uy + C1, 2 * vxy + C2, ux ** 2 + uy ** 2 + C1, vx + vy + C2)
+    S = (A1 * A2) / (B1 * B2)
+    pad = 3
+    return S[pad:-pad, pad:-pad].mean(dtype=np.float64)
+
+
+def quality_metrics(original, reconstructed):
+    """calculate_quality_metrics (comparison.py:30-80): same keys, same dtypes (float32 statistics of float32
+    arrays; float64 psnr / ssim as scikit-image returns them)."""
+    of = original.astype(np.float32)
+    rf = reconstructed.astype(np.float32)
+    m = {}
+    err = np.mean((original.astype(np.float64) - reconstructed.astype(np.float64)) ** 2, dtype=np.float64)
+    with np.errstate(divide="ignore"):
+        m["psnr"] = 10 * np.log10((255.0 ** 2) / err)            # skimage.metrics.peak_signal_noise_ratio
+    try:
+        m["ssim"] = np.mean([structural_similarity_win7(original[..., c], reconstructed[..., c]) for c in range(3)])
+    except ValueError:
+        m["ssim"] = np.float64(0.0)                              # comparison.py:51-61 falls back to zeros per channel
+    m["mse"] = np.mean((of - rf) ** 2)
+    m["rmse"] = np.sqrt(m["mse"])
+    m["mae"] = np.mean(np.abs(of - rf))
+    m["max_error"] = np.max(np.abs(of - rf))
+    for i, ch in enumerate("rgb"):
+        m[f"mse_{ch}"] = np.mean((of[..., i] - rf[..., i]) ** 2)
+    return m
+
+
+# --------------------------------------------------------------------------------------
 # EXTENSION (no reference counterpart, SURVEY 8a-13): block DCT-II + per-region quantisation
 # --------------------------------------------------------------------------------------
 def dct_quant_blocks(plane, block, qstep_map):

@@ -430,6 +430,24 @@ class Rhccq:
                          "koff": koff, "weights": weights.cpu().numpy()}
         return out
 
+    # -- quality metrics (comparison.py:30-80) ------------------------------------------------------
+    def error_sums(self, a, b):
+        """a, b: uint8[H,W,3] device -> int64[5]: per-channel sum of squared differences, sum |d|, max |d|."""
+        assert a.dtype == torch.uint8 and b.dtype == torch.uint8 and a.shape == b.shape and a.is_contiguous() and b.is_contiguous()
+        sums = self.empty((5,), torch.int64)
+        self._check(self.lib.rhccq_error_sums(self.ctx, self._p(a), self._p(b), a.numel() // 3, self._p(sums)), "error_sums")
+        return sums.cpu().numpy()
+
+    def ssim7(self, a, b):
+        """mean SSIM per channel (float64[3]) with skimage's defaults for win_size=7, data_range=255."""
+        H, W = int(a.shape[0]), int(a.shape[1])
+        nb = int(self.lib.rhccq_ssim7_blocks(H, W))
+        if nb == 0:
+            raise ValueError("win_size exceeds image extent")          # skimage's message
+        part = self.empty((nb, 3), torch.float64)
+        self._check(self.lib.rhccq_ssim7_sums(self.ctx, self._p(a), self._p(b), H, W, self._p(part), nb), "ssim7")
+        return part.cpu().numpy().sum(axis=0) / float((H - 6) * (W - 6))
+
     # -- K6 / decode ------------------------------------------------------------------------------
     def remap(self, idx, lut):
         out = torch.empty_like(idx)

@@ -232,3 +232,32 @@ def test_container_rejects_foreign_pickles():
         O.load_container(b"RHCCQ" + struct.pack("<I", len(evil)) + evil)
     with pytest.raises(ValueError):
         O.load_container(b"NOPE!" + b"\0" * 8)
+
+
+def test_quality_metrics_restatement_against_the_definition():
+    """SSIM / PSNR restatement (scikit-image's algorithm; the reference's comparison.py:30-80 calls it) against a
+    direct window-by-window evaluation of the published formula.  PARITY UNPINNED: neither scikit-image nor a
+    reference fixture is available for these numbers."""
+    from oracle import rhccq_oracle as O
+    rng = np.random.default_rng(0)
+    x = rng.integers(0, 256, (20, 23, 3)).astype(np.uint8)
+    y = np.clip(x.astype(int) + rng.integers(-20, 20, x.shape), 0, 255).astype(np.uint8)
+    C1, C2 = (0.01 * 255) ** 2, (0.03 * 255) ** 2
+    per_channel = []
+    for c in range(3):
+        a, b = x[..., c].astype(np.float64), y[..., c].astype(np.float64)
+        tot = []
+        for r in range(3, 17):
+            for q in range(3, 20):
+                wa, wb = a[r - 3:r + 4, q - 3:q + 4], b[r - 3:r + 4, q - 3:q + 4]
+                ua, ub = wa.mean(), wb.mean()
+                va, vb = wa.var(ddof=1), wb.var(ddof=1)
+                vab = ((wa - ua) * (wb - ub)).sum() / 48
+                tot.append(((2 * ua * ub + C1) * (2 * vab + C2)) / ((ua * ua + ub * ub + C1) * (va + vb + C2)))
+        per_channel.append(np.mean(tot))
+    m = O.quality_metrics(x, y)
+    assert abs(m["ssim"] - np.mean(per_channel)) < 1e-12
+    mse = np.mean((x.astype(np.float64) - y.astype(np.float64)) ** 2)
+    assert abs(m["psnr"] - 10 * np.log10(255.0 ** 2 / mse)) < 1e-12
+    assert abs(float(m["mse"]) - mse) < 1e-3 and m["mse"].dtype == np.float32
+    assert m["max_error"] == np.abs(x.astype(int) - y.astype(int)).max()
