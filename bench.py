@@ -68,9 +68,10 @@ def one_step(rh, enc, rgb, specs, roi_mask, block, stage_acc=None, extra=()):
 def roofline_probe(rh, rgb, specs, iters=5):
     """HIP-event timing (events recorded on the stream the kernel is launched on) of the heaviest HBM-streaming
     kernel of the path, job_scan_kernel<true> (K0 + K1a: one read of RGB + every class label map, one byte flag
-    per pixel).  `rh.scan_events` brackets EVERY launch of the process -- the frames of the timed region, the
-    stream-regime probe and `iters` extra back-to-back launches on cleared flags -- so that the average is the
-    one `rocprofv3 --kernel-trace --stats` reports for the same command."""
+    per pixel): `iters` launches on cleared flags, as in a real frame.  `rh.scan_events` also brackets every
+    in-frame launch of the process; those brackets are reported separately because an event recorded right
+    behind the 64 MiB flag memset adds its own packet latency (~100 us) to the kernel time.  `rocprofv3
+    --kernel-trace --stats` of the default command (profiles/) averages all launches: 143.7 us over 12."""
     import torch
     H, W = int(rgb.shape[0]), int(rgb.shape[1])
     labels = [c.labels for c in specs]
@@ -82,8 +83,8 @@ def roofline_probe(rh, rgb, specs, iters=5):
         rh.job_scan(rgb, labels, job_base, bitmaps, stats, black_is_colour=False)
     torch.cuda.synchronize()
     times = [e0.elapsed_time(e1) * 1e-3 for e0, e1 in rh.scan_events]
-    t = float(np.mean(times))
-    t_probe = float(np.mean(times[n_before:]))
+    t_all = float(np.mean(times))                   # brackets of in-frame launches also hold the event packets' own latency
+    t = float(np.mean(times[n_before:]))            # back-to-back launches: bracket == kernel time (rocprofv3 agrees to ~1 %)
     px = H * W
     algo_bytes = px * (3 + 4 * len(specs))          # RGB + one int32 label per class, read once
     # HBM traffic per launch from the PMC passes kept under profiles/ (separate FETCH_SIZE / WRITE_SIZE runs of
@@ -96,11 +97,11 @@ def roofline_probe(rh, rgb, specs, iters=5):
             traffic = (2 * rec["FETCH_SIZE"]["mean"] + rec["WRITE_SIZE"]["mean"]) * 1024
     return {"bound": "hbm", "kernel": "job_scan_kernel<true>", "achieved": algo_bytes / t / 1e9, "peak": HBM_PEAK_GBS,
             "unit": "GB/s", "frac": algo_bytes / t / 1e9 / HBM_PEAK_GBS, "traffic": traffic,
-            "algorithmic_bytes_per_launch": algo_bytes, "avg_launch_s": t, "launches": len(times),
-            "avg_launch_s_back_to_back": t_probe,
+            "algorithmic_bytes_per_launch": algo_bytes, "avg_launch_s": t, "launches": iters,
+            "avg_event_bracket_s_all_launches": t_all, "all_launches": len(times),
             "note": "per-pixel passes are < 0.3 % of the step; the step is bound by the sequential k-means++ chain "
-                    "(dominant_kernel); launches inside a 16-frame batch (1 GiB of byte flags live) run ~195 us, "
-                    "single-frame launches ~140-185 us"}
+                    "(dominant_kernel); HIP-event brackets include the dispatch latency onto an idle stream (~15-25 us "
+                    "above the kernel time rocprofv3 reports)"}
 
 
 def chain_probe(rh, enc, rgb, specs, ms_per_step):
@@ -172,7 +173,7 @@ def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=3)
-    ap.add_argument("--warmup", type=int, default=1)
+    ap.add_argument("--warmup", type=int, default=2)
     ap.add_argument("--height", type=int, default=2160)
     ap.add_argument("--width", type=int, default=3840)
     ap.add_argument("--quality", type=int, default=20, help="one ROI quality tier (configs[1])")
@@ -183,6 +184,13 @@ def main():
     ap.add_argument("--frames-per-step", type=int, default=1,
                     help="frames encoded together per step (default 1 = BASELINE configs[1], a single frame; > 1 is the "
                          "stream / batch regime of configs[2] and [4]: one batched clustering launch per level)")
+    ap.add_argument("--stream-probe", action="store_true",
+                    help="also time 48 frames in the stream regime (3 lanes x batches of 8) and report it as `stream_regime`; "
+                         "off by default so that every job_scan launch of the default command belongs to the single-frame workload "
+                         "(the population the roofline object and the committed rocprof summary average)")
+    ap.add_argument("--lanes", type=int, default=1,
+                    help="stream regime: batches of --frames-per-step frames in flight on this many host threads, each with "
+                         "its own HIP stream (stream.StreamEncoder); a step is then lanes x frames-per-step frames")
     args = ap.parse_args()
 
     import torch
@@ -202,8 +210,8 @@ def main():
             dist.init_process_group("nccl", device_id=torch.device("cuda", local))
     from roibasedimagecompression_amd.ops import Rhccq
     from roibasedimagecompression_amd.frame import FrameEncoder
+    Rhccq.scan_events = []          # class-wide: the lanes of the stream regime own their own contexts
     rh = Rhccq(local)
-    rh.scan_events = []
     enc = FrameEncoder(rh)
     H, W = args.height, args.width
     # at >= 4K the reference's SLIC scaling yields <= 2 segments per region (SURVEY.md 8a preface)
@@ -219,15 +227,39 @@ def main():
             dist.barrier()
         torch.cuda.synchronize()
 
-    for _ in range(args.warmup):
-        one_step(rh, enc, rgb, specs, roi_mask, args.block, extra=extra)
-    barrier()
-    t0 = time.perf_counter()
-    out = None
-    for _ in range(args.steps):
-        out, q = one_step(rh, enc, rgb, specs, roi_mask, args.block, extra=extra)
-    barrier()
-    dt = time.perf_counter() - t0
+    L = max(1, args.lanes)
+    if L > 1:
+        # stream regime with several batches in flight: the timed region is ONE run over steps x lanes batches
+        from roibasedimagecompression_amd.stream import StreamEncoder
+        from roibasedimagecompression_amd.frame import ClassSpec  # noqa: F401
+        batch_frames = [(rgb, specs)] + [(r, sp) for r, sp, _ in extra]
+        masks = [roi_mask] + [m for _, _, m in extra]
+        se = StreamEncoder(local, batch=B, lanes=L)
+
+        def run(n_steps):
+            outs = se.run(batch_frames * (L * n_steps))
+            for _ in range(L * n_steps):                        # the DCT extension of every frame, as in one_step
+                for (r, _), m in zip(batch_frames, masks):
+                    l2, q2 = rh.luma_qstep(r, m, args.block, 4.0, 16.0)
+                    rh.dct_quant(l2, args.block, q2, want_coef=False)
+            return outs
+        run(max(args.warmup, 1))
+        barrier()
+        t0 = time.perf_counter()
+        out = run(args.steps)[0]
+        barrier()
+        dt = time.perf_counter() - t0
+        B = B * L
+    else:
+        for _ in range(args.warmup):
+            one_step(rh, enc, rgb, specs, roi_mask, args.block, extra=extra)
+        barrier()
+        t0 = time.perf_counter()
+        out = None
+        for _ in range(args.steps):
+            out, q = one_step(rh, enc, rgb, specs, roi_mask, args.block, extra=extra)
+        barrier()
+        dt = time.perf_counter() - t0
     if world > 1:
         t = torch.tensor([dt], dtype=torch.float64, device=rh.device)
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
@@ -246,7 +278,7 @@ def main():
                                + f"one quality tier q={args.quality} (levels {args.quality}/{min(2*args.quality,100)}/{min(4*args.quality,100)}), "
                                "2 segments per class, ROI ellipse 35 % + 3 px overlap; "
                                f"{args.block}x{args.block} DCT + two-tier quantisation extension in the timed region",
-                   "frames_per_step_per_gpu": B, "parallelism": f"frame-parallel x{world}"},
+                   "frames_per_step_per_gpu": B, "lanes": L, "parallelism": f"frame-parallel x{world}"},
     }
     if rank == 0:
         line["stages_ms"] = {k: round(v * 1e3, 3) for k, v in stages.items()}
@@ -255,22 +287,27 @@ def main():
         if not args.no_probes and world == 1:
             line["dominant_kernel"] = chain_probe(rh, enc, rgb, specs, dt / args.steps * 1e3 / B)
             line["neighbour_pass"] = neighbour_probe(rh)
-        if not args.no_probes and world == 1 and B == 1:
-            # the same path in the stream regime (configs[4]: many 4K frames in flight): 16 frames per step share
-            # one batched clustering launch per level, so the sequential k-means++ chains run side by side
-            nb = 16
-            more = []
-            for i in range(1, nb):
-                _, r_i, sp_i, m_i, _ = build_inputs(rh, H, W, 1234 + i, (2, 1), args.quality, args.quality, args.sigma)
-                more.append((r_i, sp_i, m_i))
-            one_step(rh, enc, rgb, specs, roi_mask, args.block, extra=more)
+        if args.stream_probe and world == 1 and B == 1 and L == 1:
+            # the same path in the stream regime (configs[4]: many 4K frames on one GPU): batches of 8 frames share one
+            # batched clustering launch per level (the sequential k-means++ chains run side by side) and 3 batches are
+            # in flight on 3 host threads / HIP streams, so one batch's host work hides behind another's GPU work
+            from roibasedimagecompression_amd.stream import StreamEncoder
+            nb, lanes, reps = 8, 3, 6
+            more = [(rgb, specs)]
+            for i in range(1, 2 * nb):
+                _, r_i, sp_i, _, _ = build_inputs(rh, H, W, 1234 + i, (2, 1), args.quality, args.quality, args.sigma)
+                more.append((r_i, sp_i))
+            se = StreamEncoder(local, batch=nb, lanes=lanes)
+            se.run(more + more[:nb])                                            # warm-up: one batch per lane
             torch.cuda.synchronize()
             t1 = time.perf_counter()
-            one_step(rh, enc, rgb, specs, roi_mask, args.block, extra=more)
+            se.run(more * (reps // 2))
             torch.cuda.synchronize()
             d1 = time.perf_counter() - t1
-            line["stream_regime"] = {"frames_per_step": nb, "value": nb * H * W / d1 / 1e6, "unit": "Mpixels/s", "ms_per_step": d1 * 1e3,
-                                     "note": "python bench.py --frames-per-step 16 times this regime as the main value"}
+            line["stream_regime"] = {"frames": reps * nb, "frames_per_batch": nb, "lanes": lanes, "value": reps * nb * H * W / d1 / 1e6,
+                                     "unit": "Mpixels/s", "wall_s": d1,
+                                     "note": "palette hierarchy only (no DCT extension); python bench.py --frames-per-step 16 --lanes 4 "
+                                             "times this regime as the main value"}
             del more
         line["roofline"] = roofline_probe(rh, rgb, specs)
         if args.cpu_sample and world == 1:

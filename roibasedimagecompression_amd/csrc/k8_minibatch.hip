@@ -18,8 +18,6 @@
 //          learning-rate update, the low-count reassignment and sklearn's EWA early-stopping rule.
 //   assign final E-step over all N points, brute force, 4 points per thread, centres (pre-scaled by -2,
 //          exact) tiled through LDS; float64 VALU bound (K = 3 is not an MFMA shape).
-#include <stdlib.h>
-
 #include <hipcub/hipcub.hpp>
 
 #include "rhccq_common.h"
@@ -1403,7 +1401,8 @@ int rhccq_mbk_init(rhccq_ctx* ctx, const uint32_t* keys, const rhccq_mbk_problem
 }
 
 int rhccq_mbk_steps(rhccq_ctx* ctx, const uint32_t* keys, const rhccq_mbk_problem* probs, int32_t n_prob, int64_t step0,
-                    int32_t n_steps, uint64_t seed, double* centres, double* weights, double* state, void* work, int64_t work_bytes) {
+                    int32_t n_steps, uint64_t seed, double* centres, double* weights, double* state, void* work, int64_t work_bytes,
+                    int32_t estep_mode) {
   if (!ctx || !keys || !probs || !centres || !weights || !state || !work || n_prob <= 0 || n_steps < 0 || step0 < 0)
     return rhccq_fail(ctx, RHCCQ_E_ARG, "mbk_steps: bad argument");
   WorkView v;
@@ -1415,8 +1414,8 @@ int rhccq_mbk_steps(rhccq_ctx* ctx, const uint32_t* keys, const rhccq_mbk_proble
   // through the grid; with few problems the tiled brute-force kernel has fewer launches per step
   long long ksum = 0;
   for (int i = 0; i < n_prob; ++i) ksum += probs[i].k;
-  bool use_grid = ksum >= 200000;
-  if (const char* e = getenv("RHCCQ_MBK_ESTEP")) use_grid = e[0] == 'g';  // test hook: "grid" / "tiles" (results are identical)
+  if (estep_mode < RHCCQ_ESTEP_AUTO || estep_mode > RHCCQ_ESTEP_GRID) return rhccq_fail(ctx, RHCCQ_E_ARG, "mbk_steps: bad estep_mode");
+  const bool use_grid = estep_mode == RHCCQ_ESTEP_GRID || (estep_mode == RHCCQ_ESTEP_AUTO && ksum >= 200000);
   for (int s = 0; s < n_steps; ++s) {
     const long long step = step0 + s;
     if (use_grid) {

@@ -336,12 +336,13 @@ class Rhccq:
         return out[:k], sums[:k]
 
     # -- K8 -----------------------------------------------------------------------------------------
-    def minibatch_kmeans(self, key_list, k_list, return_info=False, poll_steps=64, return_device=False, timing=None):
+    def minibatch_kmeans(self, key_list, k_list, return_info=False, poll_steps=64, return_device=False, timing=None, estep="auto"):
         """Batched MiniBatchKMeans(k, batch_size=1000, random_state=42).fit_predict labels in the
         canonical arithmetic of oracle.minibatch_kmeans_labels.  key_list items are numpy arrays or
         device int32 tensors (kept resident); labels come back as numpy arrays, or as device tensors
         with return_device=True.  `timing` (a dict) receives the HIP-event duration of the k-means++ launch
-        (events on the launch stream)."""
+        (events on the launch stream).  `estep`: "auto" | "tiles" | "grid" -- how the batch E-step searches the
+        centres (include/rhccq.h, identical results); "auto" looks at the centres of the problems still running."""
         n_prob = len(key_list)
         if n_prob == 0:
             return ([], []) if return_info else []
@@ -409,13 +410,20 @@ class Rhccq:
         wbytes = int(self.lib.rhccq_mbk_work_bytes(probs, n_prob))
         work = self.empty((max(wbytes, 8),), torch.uint8)
         step = 0
+        k_arr = np.asarray(k_list, np.int64)
+        limit = np.array([(100 * n) // min(1000, n) for n in sizes], np.int64)
+        running = np.ones(n_prob, bool)
         while step < max_steps:
             ns = min(poll_steps, max_steps - step)
+            # the grid E-step pays when many centres are in flight; once only stragglers are left the tiled
+            # brute force has fewer and shorter launches per step
+            mode = {"tiles": 1, "grid": 2}.get(estep) or (2 if int(k_arr[running].sum()) >= 200000 else 1)
             self._check(self.lib.rhccq_mbk_steps(self.ctx, self._p(keys), probs, n_prob, step, ns, SEED, self._p(centres),
-                                                 self._p(weights), self._p(state), self._p(work), wbytes), "mbk_steps")
+                                                 self._p(weights), self._p(state), self._p(work), wbytes, mode), "mbk_steps")
             step += ns
             st = state.cpu().numpy()
-            if all(st[i, 4] != 0 or st[i, 5] >= (100 * sizes[i]) // min(1000, sizes[i]) for i in range(n_prob)):
+            running = (st[:, 4] == 0) & (st[:, 5] < limit)
+            if not running.any():
                 break
         labels = self.empty((int(offs[-1]),), torch.int32)
         self._check(self.lib.rhccq_mbk_assign(self.ctx, self._p(keys), probs, n_prob, self._p(centres), self._p(work), wbytes,

@@ -164,3 +164,26 @@ def test_encode_batch_equals_frame_by_frame(rh):
     for a, b in zip(single, batch):
         assert np.array_equal(a["palette"], b["palette"]) and a["indices_dtype"] == b["indices_dtype"]
         assert torch.equal(a["indices"], b["indices"])
+
+
+def test_stream_encoder_equals_frame_by_frame(rh):
+    """batches in flight on two lanes (host threads with their own HIP stream and context) == each frame alone"""
+    import torch
+    from roibasedimagecompression_amd import synth
+    from roibasedimagecompression_amd.frame import ClassSpec, FrameEncoder
+    from roibasedimagecompression_amd.stream import StreamEncoder
+    frames = []
+    for seed in range(7):
+        H, W = (96, 128) if seed % 2 else (160, 192)
+        img = synth.photo(H, W, 40 + seed, sigma=5.0 if seed == 3 else 2.0)
+        (lr, nr, br), (ln, nn, bn) = synth.frame_classes(H, W, (2, 2))
+        specs = [ClassSpec(torch.from_numpy(lr).to(rh.device), np.zeros(nr, np.int64), [br], 20),
+                 ClassSpec(torch.from_numpy(ln).to(rh.device), np.zeros(nn, np.int64), [bn], 10)]
+        frames.append((torch.from_numpy(img).to(rh.device), specs))
+    enc = FrameEncoder(rh)
+    single = [enc.encode(rgb, specs) for rgb, specs in frames]
+    got = StreamEncoder(0, batch=2, lanes=2).run(frames)
+    assert len(got) == len(single)
+    for a, b in zip(single, got):
+        assert np.array_equal(a["palette"], b["palette"]) and a["indices_dtype"] == b["indices_dtype"]
+        assert torch.equal(a["indices"], b["indices"])

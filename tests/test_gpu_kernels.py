@@ -115,17 +115,16 @@ def test_cluster_means(rh, O):
 
 
 @pytest.mark.parametrize("estep", ["tiles", "grid"])
-def test_minibatch_vs_oracle_bit_exact(rh, O, estep, monkeypatch):
+def test_minibatch_vs_oracle_bit_exact(rh, O, estep):
     """Both batch E-step variants (tiled brute force for few problems; per-step re-binned centre grid when a batch
     of frames puts many problems in flight) against the oracle: step count, centres and labels bit-exact."""
-    monkeypatch.setenv("RHCCQ_MBK_ESTEP", estep)
     g = load("g10_minibatch.npz")
     pal, _ = O.unique_colors(g["img"])
     pal = pal[~np.all(pal == 0, axis=1)]
     rng = np.random.default_rng(2)
     P2 = np.unique(rng.integers(0, 256, (30000, 3)).astype(np.uint8), axis=0)
     cases = [(pal, int(np.ceil(len(pal) * 0.2 / 10))), (pal, int(np.ceil(len(pal) * 0.1 / 10))), (P2, 450)]
-    labs, info = rh.minibatch_kmeans([O.pack_rgb(P) for P, _ in cases], [k for _, k in cases], return_info=True)
+    labs, info = rh.minibatch_kmeans([O.pack_rgb(P) for P, _ in cases], [k for _, k in cases], return_info=True, estep=estep)
     for i, ((P, k), l) in enumerate(zip(cases, labs)):
         ol, oi = O.minibatch_kmeans_labels(P, k, return_info=True)
         st = info["state"][i]
