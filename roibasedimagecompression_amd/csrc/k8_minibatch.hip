@@ -1220,6 +1220,22 @@ __global__ __launch_bounds__(256) void sample_unpack_kernel(const unsigned long 
   if (t < total) init_idx[t] = (int32_t)(uint32_t)sorted[t];
 }
 
+// ---- uniform(size=count) of numpy's legacy RandomState from the resident raw MT19937 words (mt.py) ---------
+__global__ __launch_bounds__(256) void mt_uniforms_kernel(const uint32_t* __restrict__ words, long long pos, long long count,
+                                                          double* __restrict__ out) {
+  const long long i = (long long)blockIdx.x * 256 + threadIdx.x;
+  if (i >= count) return;
+  const uint2 w = *reinterpret_cast<const uint2*>(words + pos + 2 * i);
+  out[i] = ((double)(w.x >> 5) * 67108864.0 + (double)(w.y >> 6)) / 9007199254740992.0;
+}
+__global__ __launch_bounds__(256) void mt_uniforms_odd_kernel(const uint32_t* __restrict__ words, long long pos, long long count,
+                                                              double* __restrict__ out) {
+  const long long i = (long long)blockIdx.x * 256 + threadIdx.x;
+  if (i >= count) return;
+  const uint32_t a = words[pos + 2 * i], b = words[pos + 2 * i + 1];
+  out[i] = ((double)(a >> 5) * 67108864.0 + (double)(b >> 6)) / 9007199254740992.0;
+}
+
 static int ensure_scratch(rhccq_ctx* ctx, size_t bytes) {
   if (ctx->scratch_bytes >= bytes) return 0;
   if (ctx->scratch) RHCCQ_HIP(ctx, hipFree(ctx->scratch));
@@ -1361,6 +1377,18 @@ int rhccq_mbk_order(rhccq_ctx* ctx, const uint32_t* keys, const rhccq_mbk_proble
   hipLaunchKernelGGL(sample_sortkey_kernel, dim3(grid), dim3(256), 0, ctx->stream, keys, dp, n_prob, init_idx, a, total);
   RHCCQ_HIP(ctx, hipcub::DeviceRadixSort::SortKeys(cub_tmp, cub_need, buf, (int)total, 0, top, ctx->stream));
   hipLaunchKernelGGL(sample_unpack_kernel, dim3(grid), dim3(256), 0, ctx->stream, buf.Current(), init_idx, total);
+  RHCCQ_LAUNCH_CHECK(ctx);
+  return 0;
+}
+
+int rhccq_mt_uniforms(rhccq_ctx* ctx, const uint32_t* words, int64_t pos, int64_t count, double* out) {
+  if (!ctx || !words || !out || pos < 0 || count < 0) return rhccq_fail(ctx, RHCCQ_E_ARG, "mt_uniforms: bad argument");
+  if (count == 0) return 0;
+  const unsigned grid = (unsigned)((count + 255) / 256);
+  if ((pos & 1) == 0 && ((uintptr_t)words & 7u) == 0)
+    hipLaunchKernelGGL(mt_uniforms_kernel, dim3(grid), dim3(256), 0, ctx->stream, words, (long long)pos, (long long)count, out);
+  else
+    hipLaunchKernelGGL(mt_uniforms_odd_kernel, dim3(grid), dim3(256), 0, ctx->stream, words, (long long)pos, (long long)count, out);
   RHCCQ_LAUNCH_CHECK(ctx);
   return 0;
 }

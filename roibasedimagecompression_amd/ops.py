@@ -21,22 +21,12 @@ import torch
 
 from . import _lib
 from ._lib import MbkProblem, RhccqError
+from .mt import MtWords
 
 INT_MAX = 2 ** 31 - 1
 BITMAP_WORDS = 524288
 MINIBATCH_THRESHOLD = 10000          # clustering.py:205
 SEED = 42                            # random_state=42 at every sklearn call site of the reference
-
-
-_RNG_POOL = None
-
-
-def _rng_pool():
-    global _RNG_POOL
-    if _RNG_POOL is None:
-        from concurrent.futures import ThreadPoolExecutor
-        _RNG_POOL = ThreadPoolExecutor(max_workers=min(8, os.cpu_count() or 1))
-    return _RNG_POOL
 
 
 def pack_rgb(rgb):
@@ -139,6 +129,15 @@ class Rhccq:
             raise RhccqError(f"rhccq_ctx_create failed ({rc})")
         self.ctx = h
         self.mt = _MtStream()
+        self.mtw = MtWords()
+        self._mtw_dev = None
+
+    def _mt_words_dev(self, n):
+        """the first n raw MT19937 words on the device (uploaded once, regrown geometrically)"""
+        if self._mtw_dev is None or self._mtw_dev.numel() < n:
+            w = self.mtw.ensure(max(n, 1 << 22))
+            self._mtw_dev = torch.from_numpy(w.view(np.int32)).to(self.device)
+        return self._mtw_dev
 
     def close(self):
         if getattr(self, "ctx", None):
@@ -352,40 +351,44 @@ class Rhccq:
         koff = np.concatenate([[0], np.cumsum(k_list)]).astype(np.int64)
         parts = [k if torch.is_tensor(k) else self.dev(np.ascontiguousarray(np.asarray(k)).astype(np.uint32).view(np.int32)) for k in key_list]
         keys = parts[0] if n_prob == 1 else torch.cat(parts)
-        init_list, rand_list = [], []
+        init_list = []
         ioff = roff = 0
         max_steps = 0
-        def draw(args):
-            # numpy's legacy generator releases the GIL while it fills arrays: the streams of the problems are
-            # drawn side by side (the GPU is idle until the init kernel has them)
-            n, k = args
-            rs = np.random.RandomState(SEED)
+        # numpy's RandomState(42) stream of every problem, replayed from the cached raw MT19937 words (mt.py): the
+        # sample indices on the host (vectorised rejection sampling), the k-means++ uniforms on the device
+        mtw = self.mtw
+        upos = []
+        for i, (n, k) in enumerate(zip(sizes, k_list)):
             bs = min(1000, n)
             init_size = 3 * bs
             if init_size < k:
                 init_size = 3 * k
             init_size = min(init_size, n)
-            rs.randint(0, n, init_size)                      # validation_indices: stream position only
-            init_idx = rs.randint(0, n, init_size) if init_size < n else np.arange(n)
+            pos = 0
+            _, used = mtw.randint(pos, n, init_size)             # validation_indices: stream position only
+            pos += used
+            if init_size < n:
+                init_idx, used = mtw.randint(pos, n, init_size)
+                pos += used
+            else:
+                init_idx = np.arange(n)
             T = 2 + int(math.log(k))
-            first = first_centre_index(init_size, rs.random_sample())
-            u = rs.uniform(size=max((k - 1) * T, 1))
-            return init_idx.astype(np.int32), T, first, u
-
-        todo = list(zip(sizes, k_list))
-        drawn = list(_rng_pool().map(draw, todo)) if n_prob > 1 else [draw(todo[0])]
-        for i, ((n, k), (init_idx, T, first, u)) in enumerate(zip(todo, drawn)):
-            init_size = len(init_idx)
+            first = first_centre_index(init_size, mtw.double(pos))
+            pos += 2
+            nu = max((k - 1) * T, 1)
             p = probs[i]
             p.off, p.n, p.k, p.koff = int(offs[i]), n, k, int(koff[i])
             p.init_off, p.init_n, p.rand_off, p.first, p.T = ioff, init_size, roff, first, T
-            init_list.append(init_idx)
-            rand_list.append(u)
+            init_list.append(init_idx.astype(np.int32))
+            upos.append((pos, nu, roff))
             ioff += init_size
-            roff += len(u)
-            max_steps = max(max_steps, (100 * n) // min(1000, n))
+            roff += nu
+            max_steps = max(max_steps, (100 * n) // bs)
+        words = self._mt_words_dev(max(pos + 2 * nu for pos, nu, _ in upos))
+        d_rand = self.empty((roff,), torch.float64)
+        for pos, nu, ro in upos:
+            self._check(self.lib.rhccq_mt_uniforms(self.ctx, self._p(words), pos, nu, C.c_void_p(d_rand.data_ptr() + 8 * ro)), "mt_uniforms")
         d_init = self.dev(np.concatenate(init_list))
-        d_rand = self.dev(np.concatenate(rand_list))
         # canonical sample order (Morton code of the colour, index), on the device: 64 consecutive samples
         # form a compact box, which is what the exact block pruning of mbk_init_kernel relies on
         obytes = int(self.lib.rhccq_mbk_order_bytes(ioff))
