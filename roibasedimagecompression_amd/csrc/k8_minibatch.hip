@@ -650,7 +650,8 @@ __global__ __launch_bounds__(kInitThreads) void mbk_init_kernel(const uint32_t* 
 // mini-batch steps
 // ------------------------------------------------------------------------------------------------
 constexpr int kBatch = 1024;        // padded batch (sklearn batch_size = 1000)
-constexpr int kTileC = 512;         // centres per workgroup in the batch E-step (16 KB of LDS)
+constexpr int kTileC = 512;         // centres per workgroup in the batch E-step (16 KB of LDS; 1024 halves the partials the
+                                    // update folds but leaves too few workgroups: measured 9 % slower per step)
 constexpr int kPtChunks = kBatch / 256;   // a workgroup takes 256 of the batch points
 
 // state[p][16] = {ewa, ewa_min, no_improvement, since_reassign, done, steps_done, have_ewa, have_min, n_zero_weight, ...}
@@ -659,8 +660,10 @@ __global__ __launch_bounds__(256) void mbk_batch_estep_kernel(const uint32_t* __
                                                               long long step, unsigned long long seed, double* __restrict__ pdist,
                                                               int32_t* __restrict__ pidx, const long long* __restrict__ part_off) {
   const int p = blockIdx.y;
+  const double done = state[p * 16 + 4];                 // independent table reads, issued together
   const MbkP P = probs[p];
-  if (state[p * 16 + 4] != 0.0) return;
+  const long long po = part_off[p];
+  if (done != 0.0) return;
   const int n_tiles = (int)((P.k + kTileC - 1) / kTileC);
   const int tile = blockIdx.x / kPtChunks, chunk = blockIdx.x % kPtChunks;
   if (tile >= n_tiles) return;
@@ -672,8 +675,8 @@ __global__ __launch_bounds__(256) void mbk_batch_estep_kernel(const uint32_t* __
     sc[i] = (i & 3) == 3 ? v : -2.0 * v;               // pre-scale by -2 (exact): dist = csq + dot'
   }
   __syncthreads();
-  double* pd = pdist + part_off[p] + (size_t)tile * kBatch;
-  int32_t* pi = pidx + part_off[p] + (size_t)tile * kBatch;
+  double* pd = pdist + po + (size_t)tile * kBatch;
+  int32_t* pi = pidx + po + (size_t)tile * kBatch;
   const int b = chunk * 256 + threadIdx.x;
   if (b < bs) {
     const unsigned long long src = bounded(counter_hash(seed, 2ull * (unsigned long long)step, (unsigned long long)b), (unsigned long long)P.n);
@@ -687,6 +690,49 @@ __global__ __launch_bounds__(256) void mbk_batch_estep_kernel(const uint32_t* __
     }
     pd[b] = bd;
     pi[b] = j0 + bj;
+  }
+}
+
+// Fold of the per-tile partial arg-mins, in tile order (first arg-min), into the slot of tile 0.  One wave per 16
+// batch points: lane = (tile group g << 4) | point; a lane loads its tiles g, g + 4, g + 8, ... (16 loads in flight,
+// 16 consecutive points = one full line per tile), keeps their first minimum, and two shuffles merge the four
+// groups (smaller distance, then smaller tile).  Folding inside the single-workgroup update kernel meant ~700 KB
+// through one CU's few outstanding misses (10-14 us of every step); a last-arriving-workgroup fold inside the
+// E-step needs an agent-scope release (an L2 write-back) in every one of its ~900 workgroups and was slower still.
+__global__ __launch_bounds__(64) void mbk_fold_tiles_kernel(const MbkP* __restrict__ probs, const double* __restrict__ state,
+                                                            double* __restrict__ pdist, int32_t* __restrict__ pidx,
+                                                            const long long* __restrict__ part_off) {
+  const int p = blockIdx.y;
+  // the three table reads are independent: issue them together (a kernel this short is a chain of cold misses)
+  const double done = state[p * 16 + 4];
+  const long long pk = probs[p].k, pn = probs[p].n, po = part_off[p];
+  if (done != 0.0) return;
+  const int n_tiles = (int)((pk + kTileC - 1) / kTileC);
+  if (n_tiles == 1) return;
+  const int bs = (int)min((long long)1000, pn);
+  const int lane = threadIdx.x, g = lane >> 4;
+  const int b = min(blockIdx.x * 16 + (lane & 15), bs - 1);      // clamped lanes redo the last point (same value written)
+  const double* fd = pdist + po + b;
+  double bd = INFINITY;
+  int bt = 0x7fffffff;
+  for (int t0 = g; t0 < n_tiles; t0 += 64) {
+    double dv[16];
+#pragma unroll
+    for (int q = 0; q < 16; ++q) dv[q] = t0 + 4 * q < n_tiles ? fd[(size_t)(t0 + 4 * q) * kBatch] : INFINITY;
+#pragma unroll
+    for (int q = 0; q < 16; ++q)
+      if (dv[q] < bd) { bd = dv[q]; bt = t0 + 4 * q; }
+  }
+#pragma unroll
+  for (int o = 16; o <= 32; o <<= 1) {
+    const double od = __shfl_xor(bd, o, 64);
+    const int ot = __shfl_xor(bt, o, 64);
+    if (od < bd || (od == bd && ot < bt)) { bd = od; bt = ot; }
+  }
+  if (g == 0 && bt != 0) {
+    const int32_t bj = pidx[po + b + (size_t)bt * kBatch];
+    pdist[po + b] = bd;
+    pidx[po + b] = bj;
   }
 }
 
@@ -744,16 +790,26 @@ __device__ __forceinline__ bool reassign_sel(double w, double thr, bool capped, 
   return w == sel_w && eq_rank < take;
 }
 
+#ifdef RHCCQ_STAMPS
+__device__ unsigned long long g_upd_stamps[16];
+#define USTAMP(slot) do { if (tid == 0 && p == 0) { const unsigned long long _t = clock64(); atomicAdd(&g_upd_stamps[slot], _t - _ul); _ul = _t; } } while (0)
+#else
+#define USTAMP(slot) do {} while (0)
+#endif
+
 __global__ __launch_bounds__(kUpdThreads) void mbk_update_kernel(const uint32_t* __restrict__ keys, const MbkP* __restrict__ probs,
                                                                  double* __restrict__ centres, double* __restrict__ weights,
                                                                  double* __restrict__ state, long long step, unsigned long long seed,
                                                                  const double* __restrict__ pdist, const int32_t* __restrict__ pidx,
-                                                                 const long long* __restrict__ part_off, int single_tile) {
+                                                                 const long long* __restrict__ part_off) {
   __shared__ UpdShared sh;
   const int p = blockIdx.x, tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
-  const MbkP P = probs[p];
   double* st = state + p * kStateStride;
-  if (st[4] != 0.0) return;
+  // independent table reads issued together: the kernel is a chain of dependent accesses, every cold miss counts
+  const double st_done = st[4], st_since = st[3], st_nzero = st[8];
+  const MbkP P = probs[p];
+  const long long po = part_off[p];
+  if (st_done != 0.0) return;
   const int k = (int)P.k;
   const long long n = P.n;
   const int bs = (int)min((long long)1000, n);
@@ -762,29 +818,20 @@ __global__ __launch_bounds__(kUpdThreads) void mbk_update_kernel(const uint32_t*
     if (tid == 0) st[4] = 2.0;                           // ran out of steps
     return;
   }
-  const int n_tiles = single_tile ? 1 : (k + kTileC - 1) / kTileC;
+#ifdef RHCCQ_STAMPS
+  unsigned long long _ul = clock64();
+  if (tid == 0 && p == 0) atomicAdd(&g_upd_stamps[15], 1ull);
+#endif
   double* C = centres + P.koff * 4;
   double* W = weights + P.koff;
   for (int i = tid; i < kHashSlots; i += kUpdThreads) {
     sh.hkey[i] = -1;
     sh.hsum[i][0] = sh.hsum[i][1] = sh.hsum[i][2] = sh.hsum[i][3] = 0;
   }
-  // ---- reduce the per-tile partial arg-mins in tile order (first arg-min) --------------------------
+  // ---- labels of the batch (the E-step kernels leave the folded arg-min in the slot of tile 0) ------------
   double per = 0.0;
   if (tid < bs) {
-    const double* pd = pdist + part_off[p] + tid;
-    const int32_t* pi = pidx + part_off[p] + tid;
-    double bd = pd[0];
-    int bt = 0;
-    for (int t0 = 1; t0 < n_tiles; t0 += 8) {            // 8 independent loads in flight, compared in tile order
-      double dv[8];
-#pragma unroll
-      for (int q = 0; q < 8; ++q) dv[q] = t0 + q < n_tiles ? pd[(size_t)(t0 + q) * kBatch] : INFINITY;
-#pragma unroll
-      for (int q = 0; q < 8; ++q)
-        if (dv[q] < bd) { bd = dv[q]; bt = t0 + q; }
-    }
-    const int bj = pi[(size_t)bt * kBatch];
+    const int bj = pidx[po + tid];
     const unsigned long long src = bounded(counter_hash(seed, 2ull * (unsigned long long)step, (unsigned long long)tid), (unsigned long long)n);
     const uint32_t kk = keys[P.off + src];
     sh.lab[tid] = bj;
@@ -793,19 +840,35 @@ __global__ __launch_bounds__(kUpdThreads) void mbk_update_kernel(const uint32_t*
     per = (d0 * d0 + d1 * d1) + d2 * d2;
   }
   sh.per[tid] = per;
+  USTAMP(0);
   // reassignment decision uses the weights BEFORE this step's update (sklearn _random_reassign):
   // st[8] = number of zero-weight centres, maintained by the reassignment sweep (it can only be non-zero
   // while every step reassigns)
-  double since = st[3] + (double)bs;
-  const bool do_reassign = st[8] > 0.0 || since >= 10.0 * (double)k;
+  double since = st_since + (double)bs;
+  const bool do_reassign = st_nzero > 0.0 || since >= 10.0 * (double)k;
   if (do_reassign) since = 0.0;
-  // ---- batch inertia: fixed 1024-leaf tree ----------------------------------------------------------
-  for (int s = 512; s >= 1; s >>= 1) {
-    __syncthreads();
-    if (tid < s) sh.per[tid] = sh.per[tid] + sh.per[tid + s];
-  }
+  // ---- batch inertia: the fixed 1024-leaf tree of the canonical spec (level s adds leaf i + s to leaf i,
+  // s = 512 ... 1), evaluated by ONE wave: lane i first folds its 16 leaves i + 64 h over the four high levels in
+  // registers, then the six low levels run on shuffles -- same additions in the same order, one barrier instead
+  // of ten (a barrier of 16 waves costs ~1 000 cycles here)
   __syncthreads();
-  const double inertia = sh.per[0];
+  double inertia = 0.0;
+  if (wave == 0) {
+    double v[16];
+#pragma unroll
+    for (int h = 0; h < 16; ++h) v[h] = sh.per[lane + 64 * h];
+#pragma unroll
+    for (int h = 0; h < 8; ++h) v[h] = v[h] + v[h + 8];          // s = 512
+#pragma unroll
+    for (int h = 0; h < 4; ++h) v[h] = v[h] + v[h + 4];          // s = 256
+#pragma unroll
+    for (int h = 0; h < 2; ++h) v[h] = v[h] + v[h + 2];          // s = 128
+    double t = v[0] + v[1];                                      // s = 64
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) t = t + __shfl_down(t, o, 64);   // s = 32 ... 1: lane i adds lane i + s
+    inertia = t;                                                 // valid in lane 0 == thread 0, its only reader
+  }
+  USTAMP(1);
   // ---- exact integer member sums per touched centre (LDS hash) -------------------------------------
   if (tid < bs) {
     const int j = sh.lab[tid];
@@ -826,21 +889,40 @@ __global__ __launch_bounds__(kUpdThreads) void mbk_update_kernel(const uint32_t*
     atomicAdd(&sh.hsum[h][3], 1u);
   }
   __syncthreads();
-  for (int h = tid; h < kHashSlots; h += kUpdThreads) {
-    const int j = sh.hkey[h];
-    if (j < 0) continue;
-    const double w = W[j], wn = w + (double)sh.hsum[h][3];
-    const double alpha = 1.0 / wn;
-    const double c0 = (C[j * 4] * w + (double)sh.hsum[h][0]) * alpha;
-    const double c1 = (C[j * 4 + 1] * w + (double)sh.hsum[h][1]) * alpha;
-    const double c2 = (C[j * 4 + 2] * w + (double)sh.hsum[h][2]) * alpha;
-    C[j * 4] = c0; C[j * 4 + 1] = c1; C[j * 4 + 2] = c2;
-    C[j * 4 + 3] = km64_csq(c0, c1, c2);
-    W[j] = wn;
+  USTAMP(2);
+  {
+    // kHashSlots / kUpdThreads = 2 slots per thread: both centres' loads are issued before either is used
+    static_assert(kHashSlots == 2 * kUpdThreads, "apply loop is unrolled for two slots per thread");
+    int jj[2];
+    double w0[2], cc[2][3];
+#pragma unroll
+    for (int q = 0; q < 2; ++q) {
+      jj[q] = sh.hkey[tid + q * kUpdThreads];
+      const int j = max(jj[q], 0);
+      w0[q] = W[j];
+      cc[q][0] = C[j * 4]; cc[q][1] = C[j * 4 + 1]; cc[q][2] = C[j * 4 + 2];
+    }
+#pragma unroll
+    for (int q = 0; q < 2; ++q) {
+      const int j = jj[q], h = tid + q * kUpdThreads;
+      if (j < 0) continue;
+      const double w = w0[q], wn = w + (double)sh.hsum[h][3];
+      const double alpha = 1.0 / wn;
+      const double c0 = (cc[q][0] * w + (double)sh.hsum[h][0]) * alpha;
+      const double c1 = (cc[q][1] * w + (double)sh.hsum[h][1]) * alpha;
+      const double c2 = (cc[q][2] * w + (double)sh.hsum[h][2]) * alpha;
+      C[j * 4] = c0; C[j * 4 + 1] = c1; C[j * 4 + 2] = c2;
+      C[j * 4 + 3] = km64_csq(c0, c1, c2);
+      W[j] = wn;
+    }
   }
   __syncthreads();
+  USTAMP(3);
   // ---- low-count reassignment (sklearn _mini_batch_step), coalesced sweeps over the weights ------------
   if (do_reassign) {
+#ifdef RHCCQ_STAMPS
+    if (tid == 0 && p == 0) atomicAdd(&g_upd_stamps[14], 1ull);
+#endif
     double wm = 0.0;
 #pragma unroll 8
     for (int j = tid; j < k; j += kUpdThreads) wm = fmax(wm, W[j]);
@@ -966,6 +1048,7 @@ __global__ __launch_bounds__(kUpdThreads) void mbk_update_kernel(const uint32_t*
     nzero = block_sum_i(nzero, sh);
     if (tid == 0) st[8] = (double)nzero;
   }
+  USTAMP(4);
   // ---- sklearn _mini_batch_convergence (EWA early stopping) -------------------------------------------
   if (tid == 0) {
     st[3] = since;
@@ -986,6 +1069,7 @@ __global__ __launch_bounds__(kUpdThreads) void mbk_update_kernel(const uint32_t*
     }
     if (step + 1 >= n_steps_max && st[4] == 0.0) st[4] = 2.0;
   }
+  USTAMP(5);
 }
 
 // ------------------------------------------------------------------------------------------------
@@ -1282,7 +1366,7 @@ struct WorkView {
   double* pdist;
   int32_t* pidx;
   uint32_t* cell_start;   // [n_prob][cells + 1]
-  uint32_t* cursor;       // [n_prob][cells]
+  uint32_t* cursor;       // [n_prob][cells] (spare)
   uint32_t* order;        // [sum k] centre indices grouped by cell (problem-relative)
   long long max_k;
 };
@@ -1332,6 +1416,11 @@ static int layout_work(rhccq_ctx* ctx, const rhccq_mbk_problem* probs, int n_pro
 }
 
 #ifdef RHCCQ_STAMPS
+int rhccq_debug_upd_stamps(unsigned long long* out16_host) {
+  if (hipDeviceSynchronize() != hipSuccess) return -2;
+  if (hipMemcpyFromSymbol(out16_host, HIP_SYMBOL(g_upd_stamps), sizeof(unsigned long long) * 16) != hipSuccess) return -2;
+  return 0;
+}
 int rhccq_debug_stamps(unsigned long long* out16_host) {
   if (hipDeviceSynchronize() != hipSuccess) return -2;
   if (hipMemcpyFromSymbol(out16_host, HIP_SYMBOL(g_init_stamps), sizeof(unsigned long long) * 16) != hipSuccess) return -2;
@@ -1454,9 +1543,11 @@ int rhccq_mbk_steps(rhccq_ctx* ctx, const uint32_t* keys, const rhccq_mbk_proble
     } else {
       hipLaunchKernelGGL(mbk_batch_estep_kernel, dim3(max_tiles * kPtChunks, n_prob), dim3(256), 0, ctx->stream, keys, v.probs, centres, state, step,
                          (unsigned long long)seed, v.pdist, v.pidx, v.part_off);
+      hipLaunchKernelGGL(mbk_fold_tiles_kernel, dim3((1000 + 15) / 16, n_prob), dim3(64), 0, ctx->stream, v.probs, (const double*)state, v.pdist, v.pidx,
+                         v.part_off);
     }
     hipLaunchKernelGGL(mbk_update_kernel, dim3(n_prob), dim3(kUpdThreads), 0, ctx->stream, keys, v.probs, centres, weights, state, step,
-                       (unsigned long long)seed, v.pdist, v.pidx, v.part_off, use_grid ? 1 : 0);
+                       (unsigned long long)seed, v.pdist, v.pidx, v.part_off);
   }
   RHCCQ_LAUNCH_CHECK(ctx);
   return 0;

@@ -30,3 +30,13 @@ for n, x in zip(names, v[:5]):
     print(f"{n:18s} {x/ (k-1):10.0f} cycles/step  {100*x/tot:5.1f}%")
 print("total cycles/step", tot / (k - 1))
 print("sub-stamps (wave 0):", {i: round(v[i] / (k - 1)) for i in range(8, 16)})
+
+out2 = (ctypes.c_ulonglong * 16)()
+rh.lib.rhccq_debug_upd_stamps.argtypes = [ctypes.c_void_p]
+print("rc", rh.lib.rhccq_debug_upd_stamps(out2))
+w = np.array(list(out2), dtype=np.float64)
+calls = max(w[15], 1)
+print("update kernel (problem 0, thread 0): calls", int(w[15]), "with reassignment", int(w[14]))
+for n, x in zip(["tile arg-min + labels", "inertia tree", "hash member sums", "apply centres", "reassignment", "EWA / state"], w[:6]):
+    print(f"{n:24s} {x / calls:10.0f} cycles/step")
+print("total", w[:6].sum() / calls)
