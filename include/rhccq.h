@@ -39,6 +39,16 @@ typedef struct rhccq_ctx rhccq_ctx;
 int rhccq_ctx_create(int device, void* hip_stream /* NULL = the default (null) stream */, rhccq_ctx** out);
 void rhccq_ctx_destroy(rhccq_ctx* ctx);
 const char* rhccq_last_error(const rhccq_ctx* ctx);
+/* Tuning knobs.  They only move the thresholds at which a kernel switches between two implementations of the
+ * same computation (results never change); the test-suite lowers them to drive the large-input paths with inputs
+ * the oracle can still check.
+ *   RHCCQ_OPT_INIT_LDS_BLOCKS  k-means++ (rhccq_mbk_init): block tables live in LDS while the init sample has at
+ *                              most this many 64-sample blocks (0..4096, default 4096), in global memory beyond;
+ *   RHCCQ_OPT_INIT_MAX_ITEMS   capacity of the shared (candidate, block) work list (1..12288, default 12288);
+ *                              picks that exceed it evaluate each candidate by its own enumeration instead. */
+#define RHCCQ_OPT_INIT_LDS_BLOCKS 1
+#define RHCCQ_OPT_INIT_MAX_ITEMS 2
+int rhccq_ctx_set_int(rhccq_ctx* ctx, int32_t option, int64_t value);
 int rhccq_sync(rhccq_ctx* ctx);                 /* hipStreamSynchronize on the context stream */
 void* rhccq_stream(rhccq_ctx* ctx);             /* the hipStream_t in use */
 int rhccq_abi_version(void);

@@ -27,6 +27,7 @@ PROTOTYPES = {
     "rhccq_ctx_create": (c_int32, [c_int32, c_void_p, C.POINTER(c_void_p)]),
     "rhccq_ctx_destroy": (None, [c_void_p]),
     "rhccq_last_error": (C.c_char_p, [c_void_p]),
+    "rhccq_ctx_set_int": (c_int32, [c_void_p, c_int32, c_int64]),
     "rhccq_sync": (c_int32, [c_void_p]),
     "rhccq_stream": (c_void_p, [c_void_p]),
     "rhccq_params": (c_int32, [c_int64, c_double, C.POINTER(c_double), C.POINTER(c_int64)]),

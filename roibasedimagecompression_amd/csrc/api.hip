@@ -39,6 +39,22 @@ void rhccq_ctx_destroy(rhccq_ctx* ctx) {
 
 const char* rhccq_last_error(const rhccq_ctx* ctx) { return ctx ? ctx->err.c_str() : "null context"; }
 
+int rhccq_ctx_set_int(rhccq_ctx* ctx, int32_t option, int64_t value) {
+  if (!ctx) return RHCCQ_E_ARG;
+  switch (option) {
+    case RHCCQ_OPT_INIT_LDS_BLOCKS:
+      if (value < 0 || value > 4096) return rhccq_fail(ctx, RHCCQ_E_ARG, "RHCCQ_OPT_INIT_LDS_BLOCKS: 0..4096");
+      ctx->opt_init_lds_blocks = (int)value;
+      return 0;
+    case RHCCQ_OPT_INIT_MAX_ITEMS:
+      if (value < 1 || value > 12288) return rhccq_fail(ctx, RHCCQ_E_ARG, "RHCCQ_OPT_INIT_MAX_ITEMS: 1..12288");
+      ctx->opt_init_max_items = (int)value;
+      return 0;
+    default:
+      return rhccq_fail(ctx, RHCCQ_E_ARG, "unknown option");
+  }
+}
+
 int rhccq_sync(rhccq_ctx* ctx) {
   if (!ctx) return RHCCQ_E_ARG;
   RHCCQ_HIP(ctx, hipStreamSynchronize(ctx->stream));

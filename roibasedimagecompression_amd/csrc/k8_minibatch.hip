@@ -241,7 +241,8 @@ constexpr int kEvalItems = 8;             // (candidate, block) items a wave kee
 __device__ __forceinline__ void init_body(const uint32_t* __restrict__ keys, const MbkP& P, const int32_t* __restrict__ init_idx,
                                           const double* __restrict__ rand, double* __restrict__ centres, int32_t* __restrict__ cho,
                                           uint2* samp, InitTables tb, InitShared& sh, double* s_u /* [2][kTMaxI] */, int* s_touch,
-                                          uint32_t* s_items /* nullptr: no work list (tables in global memory) */, uint32_t* s_hits) {
+                                          uint32_t* s_items /* nullptr: no work list (tables in global memory) */, uint32_t* s_hits,
+                                          int max_items) {
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
   const int n = (int)P.init_n, k = (int)P.k, T = P.T;
   const int nb = (n + 63) >> 6, np = nb << 6, nsb = (nb + 15) >> 4;
@@ -440,7 +441,7 @@ __device__ __forceinline__ void init_body(const uint32_t* __restrict__ keys, con
           int base = 0;
           if (lane == 0) base = atomicAdd(&sh.n_items, c0 + c1);
           base = __builtin_amdgcn_readfirstlane(base);
-          if (base + c0 + c1 > kMaxItems) { if (lane == 0) sh.overflow = 1; }
+          if (base + c0 + c1 > max_items) { if (lane == 0) sh.overflow = 1; }
           else {
             const unsigned long long below = (1ull << lane) - 1ull;
             if (hb[0]) s_items[base + __popcll(m0 & below)] = word[0];
@@ -621,7 +622,8 @@ __device__ __forceinline__ void init_body(const uint32_t* __restrict__ keys, con
 __global__ __launch_bounds__(kInitThreads) void mbk_init_kernel(const uint32_t* __restrict__ keys, const MbkP* __restrict__ probs,
                                                                 const int32_t* __restrict__ init_idx, const double* __restrict__ rand,
                                                                 double* __restrict__ centres, int32_t* __restrict__ chosen,
-                                                                uint32_t* scratch, const long long* __restrict__ scratch_off) {
+                                                                uint32_t* scratch, const long long* __restrict__ scratch_off,
+                                                                int lds_blocks, int max_items) {
   __shared__ InitShared sh;
   __shared__ uint32_t s_tab[5 * kInitLdsBlocks + 5 * kInitLdsSuper];
   __shared__ uint32_t s_items[kMaxItems];
@@ -632,17 +634,17 @@ __global__ __launch_bounds__(kInitThreads) void mbk_init_kernel(const uint32_t* 
   const int nb = ((int)P.init_n + 63) >> 6, np = nb << 6, nsb = (nb + 15) >> 4;
   uint2* samp = reinterpret_cast<uint2*>(scratch + scratch_off[blockIdx.x]);
   InitTables tb;
-  if (nb <= kInitLdsBlocks) {
+  if (nb <= lds_blocks) {
     tb.xr = s_tab; tb.xg = s_tab + kInitLdsBlocks; tb.xb = s_tab + 2 * kInitLdsBlocks;
     tb.bmax = s_tab + 3 * kInitLdsBlocks; tb.bsum = s_tab + 4 * kInitLdsBlocks;
     tb.sxr = s_tab + 5 * kInitLdsBlocks; tb.sxg = tb.sxr + kInitLdsSuper; tb.sxb = tb.sxg + kInitLdsSuper;
     tb.sbmax = tb.sxb + kInitLdsSuper; tb.sbsum = tb.sbmax + kInitLdsSuper;
-    init_body(keys, P, init_idx, rand, centres, chosen + P.koff, samp, tb, sh, s_u, s_touch, s_items, s_hits);
+    init_body(keys, P, init_idx, rand, centres, chosen + P.koff, samp, tb, sh, s_u, s_touch, s_items, s_hits, max_items);
   } else {
     uint32_t* g = reinterpret_cast<uint32_t*>(samp + np);
     tb.xr = g; tb.xg = g + nb; tb.xb = g + 2 * nb; tb.bmax = g + 3 * nb; tb.bsum = g + 4 * nb;
     tb.sxr = g + 5 * nb; tb.sxg = tb.sxr + nsb; tb.sxb = tb.sxg + nsb; tb.sbmax = tb.sxb + nsb; tb.sbsum = tb.sbmax + nsb;
-    init_body(keys, P, init_idx, rand, centres, chosen + P.koff, samp, tb, sh, s_u, s_touch, nullptr, nullptr);
+    init_body(keys, P, init_idx, rand, centres, chosen + P.koff, samp, tb, sh, s_u, s_touch, nullptr, nullptr, 0);
   }
 }
 
@@ -1512,7 +1514,10 @@ int rhccq_mbk_init(rhccq_ctx* ctx, const uint32_t* keys, const rhccq_mbk_problem
   if (int e = put(ctx, dp, hp, sizeof(MbkP) * n_prob)) return e;
   if (int e = put(ctx, dof, ho, 8 * (size_t)n_prob)) return e;
   RHCCQ_HIP(ctx, hipStreamSynchronize(ctx->stream));
-  hipLaunchKernelGGL(mbk_init_kernel, dim3(n_prob), dim3(kInitThreads), 0, ctx->stream, keys, dp, init_idx, rand, centres, chosen, dscr, dof);
+  const int lds_blocks = ctx->opt_init_lds_blocks < 0 ? kInitLdsBlocks : ctx->opt_init_lds_blocks;
+  const int max_items = ctx->opt_init_max_items < 0 ? kMaxItems : ctx->opt_init_max_items;
+  hipLaunchKernelGGL(mbk_init_kernel, dim3(n_prob), dim3(kInitThreads), 0, ctx->stream, keys, dp, init_idx, rand, centres, chosen, dscr, dof,
+                     lds_blocks, max_items);
   RHCCQ_LAUNCH_CHECK(ctx);
   return 0;
 }

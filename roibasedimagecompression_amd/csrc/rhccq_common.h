@@ -15,6 +15,9 @@ struct rhccq_ctx {
   // small persistent device scratch (descriptor tables handed over from the host)
   void* scratch = nullptr;
   size_t scratch_bytes = 0;
+  // tuning knobs (rhccq_ctx_set_int); -1 = built-in value
+  int opt_init_lds_blocks = -1;
+  int opt_init_max_items = -1;
 };
 
 #define RHCCQ_HIP(ctx, expr)                                                        \

@@ -132,6 +132,12 @@ class Rhccq:
         self.mtw = MtWords()
         self._mtw_dev = None
 
+    OPT_INIT_LDS_BLOCKS, OPT_INIT_MAX_ITEMS = 1, 2
+
+    def set_option(self, option, value):
+        """rhccq_ctx_set_int: thresholds between equivalent kernel paths (include/rhccq.h)"""
+        self._check(self.lib.rhccq_ctx_set_int(self.ctx, int(option), int(value)), "ctx_set_int")
+
     def _mt_words_dev(self, n):
         """the first n raw MT19937 words on the device (uploaded once, regrown geometrically)"""
         if self._mtw_dev is None or self._mtw_dev.numel() < n:

@@ -181,10 +181,27 @@ def test_dct_quant_extension(rh, O, block):
     assert np.array_equal(q.cpu().numpy(), oq)
 
 
-def test_minibatch_init_chain_many_cases(rh, O):
+@pytest.mark.parametrize("path", ["default", "global_tables", "tiny_work_list"])
+def test_minibatch_init_chain_many_cases(rh, O, path):
     """The k-means++ chain of mbk_init_kernel (work list, lazy super-block maxima, hierarchical search) against
     the oracle's exact-integer k-means++ on the same Morton-ordered sample, for several shapes -- every pick
-    must be identical (this is the kernel where a reduction race once hid behind lucky timing)."""
+    must be identical (this is the kernel where a reduction race once hid behind lucky timing).
+    `global_tables` / `tiny_work_list` lower the thresholds (rhccq_ctx_set_int) so that the paths of very large
+    problems -- block tables in global memory beyond 262 144 samples, per-candidate evaluation when the shared
+    work list overflows -- run on inputs the oracle can check."""
+    import math
+    if path == "global_tables":
+        rh.set_option(rh.OPT_INIT_LDS_BLOCKS, 8)
+    elif path == "tiny_work_list":
+        rh.set_option(rh.OPT_INIT_MAX_ITEMS, 24)
+    try:
+        _init_chain_cases(rh, O)
+    finally:
+        rh.set_option(rh.OPT_INIT_LDS_BLOCKS, 4096)
+        rh.set_option(rh.OPT_INIT_MAX_ITEMS, 12288)
+
+
+def _init_chain_cases(rh, O):
     import math
     rng = np.random.default_rng(123)
     cases = []
