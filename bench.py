@@ -128,6 +128,36 @@ def chain_probe(rh, enc, rgb, specs, ms_per_step):
                      "instruction issue of one CU over ~1000 instructions per wave (DESIGN.md section 3)"}
 
 
+def pixel_probe(rh, rgb, iters=10):
+    """EXTENSION (no reference counterpart; BASELINE.json's north_star names it): the pixel-space fixed-radius
+    neighbour pass over (x, y, L, a, b) -- 3 B read + 4 B written per pixel -- and the union-find expansion,
+    HIP events on the launch stream."""
+    import ctypes as C
+    import torch
+    H, W = int(rgb.shape[0]), int(rgb.shape[1])
+    radius, eps, ws, min_pts = 2, 6.0, 1.0, 5
+    rh.px_dbscan(rgb, radius, eps, ws, min_pts)                      # warm-up (+ the linearisation table upload)
+    parent = rh.empty((H, W), torch.int32)
+    labels = rh.empty((H, W), torch.int32)
+    ev = [torch.cuda.Event(enable_timing=True) for _ in range(3)]
+    t_n = t_e = 0.0
+    for _ in range(iters):
+        ev[0].record()
+        rh._check(rh.lib.rhccq_px_neighbours(rh.ctx, rh._p(rgb), H, W, radius, eps, ws, min_pts, rh._p(rh._px_lut), rh._p(parent), C.c_void_p(0)),
+                  "px_neighbours")
+        ev[1].record()
+        rh._check(rh.lib.rhccq_px_expand(rh.ctx, rh._p(rgb), H, W, radius, eps, ws, rh._p(rh._px_lut), rh._p(parent), rh._p(labels)), "px_expand")
+        ev[2].record()
+        torch.cuda.synchronize()
+        t_n += ev[0].elapsed_time(ev[1]) * 1e-3
+        t_e += ev[1].elapsed_time(ev[2]) * 1e-3
+    t_n, t_e = t_n / iters, t_e / iters
+    algo = H * W * 7
+    return {"extension": True, "kernel": "px_neighbours_kernel", "params": {"radius": radius, "eps": eps, "spatial_weight": ws, "min_pts": min_pts},
+            "algorithmic_bytes_per_launch": algo, "avg_launch_s": t_n, "achieved_GB_s": algo / t_n / 1e9, "frac_of_hbm_peak": algo / t_n / 1e9 / HBM_PEAK_GBS,
+            "expansion_s": t_e, "clusters": int(torch.unique(labels).numel()) - 1, "Mpixels_per_s_neighbours_plus_expansion": H * W / (t_n + t_e) / 1e6}
+
+
 def neighbour_probe(rh):
     """K3/K4 eps-components microbench of SURVEY.md 8d (`palette-only`): 256 palettes x 4000 colours."""
     rng = np.random.default_rng(99)
@@ -287,6 +317,7 @@ def main():
         if not args.no_probes and world == 1:
             line["dominant_kernel"] = chain_probe(rh, enc, rgb, specs, dt / args.steps * 1e3 / B)
             line["neighbour_pass"] = neighbour_probe(rh)
+            line["pixel_neighbour_pass_extension"] = pixel_probe(rh, rgb)
         if args.stream_probe and world == 1 and B == 1 and L == 1:
             # the same path in the stream regime (configs[4]: many 4K frames on one GPU): batches of 8 frames share one
             # batched clustering launch per level (the sequential k-means++ chains run side by side) and 3 batches are

@@ -216,6 +216,21 @@ int64_t rhccq_ssim7_blocks(int32_t H, int32_t W);
 int rhccq_ssim7_sums(rhccq_ctx* ctx, const uint8_t* a, const uint8_t* b, int32_t H, int32_t W, double* partial,
                      int64_t n_blocks);
 
+/* ---- EXTENSION (no reference counterpart; named by BASELINE.json's north_star only): pixel-space DBSCAN ----
+ * Features (x, y, L, a, b); q is a neighbour of p when dx^2 + dy^2 <= radius^2 (radius 0..4) and
+ * dL^2 + da^2 + db^2 + spatial_weight^2 (dx^2 + dy^2) <= eps^2 (float32, operation order fixed in
+ * csrc/px_dbscan_ext.hip and oracle.px_dbscan).  lin_lut: device float[256], 8-bit sRGB -> linear.
+ * rhccq_px_neighbours (the "fixed-radius neighbour pass": 3 B read + 4 B written per pixel): parent_out[p] = p for
+ * a core pixel (>= min_pts neighbours, itself included), -1 otherwise; count_out (may be NULL) = neighbour count.
+ * rhccq_px_expand (the "region growing"): lock-free union-find over the core pixels, then
+ * labels_out[p] = 1 + smallest pixel index of p's cluster; non-core pixels take the smallest cluster among their
+ * core neighbours, 0 = noise.  `parent` is the array rhccq_px_neighbours produced (modified in place). */
+int rhccq_px_neighbours(rhccq_ctx* ctx, const uint8_t* rgb, int32_t H, int32_t W, int32_t radius, float eps,
+                        float spatial_weight, int32_t min_pts, const float* lin_lut, int32_t* parent_out,
+                        uint8_t* count_out);
+int rhccq_px_expand(rhccq_ctx* ctx, const uint8_t* rgb, int32_t H, int32_t W, int32_t radius, float eps,
+                    float spatial_weight, const float* lin_lut, int32_t* parent, int32_t* labels_out);
+
 /* ---- EXTENSION (no reference counterpart): block DCT-II + region quantisation --
  * plane: float32[H*W]; block in {8,16}; qstep: float32 per tile [(H/block)*(W/block)];
  * coef_out float32[H*W] (may be NULL), q_out int16[H*W]. */

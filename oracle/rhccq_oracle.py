@@ -761,6 +761,92 @@ def decode_container(pkg):
 
 
 # --------------------------------------------------------------------------------------
+# EXTENSION (no reference counterpart; named by BASELINE.json's north_star only): pixel-space DBSCAN on
+# (x, y, L, a, b).  Brute-force restatement of csrc/px_dbscan_ext.hip's definition: every float32 operation is
+# written in the same order, so counts, core flags and labels must be bit-identical.
+# --------------------------------------------------------------------------------------
+def px_cbrt(t):
+    t = np.asarray(t, np.float32)
+    i = t.view(np.int32) // np.int32(3) + np.int32(709921077)      # t > 0: floor division == C division
+    y = i.view(np.float32)
+    three = np.float32(3.0)
+    for _ in range(3):
+        y2 = y * y
+        num = y2 * y - t
+        den = three * y2
+        y = y - num / den
+    return y
+
+
+def px_lab(rgb, lut):
+    """float32 Lab planes of a uint8 image with the operation order of px_lab() in px_dbscan_ext.hip"""
+    f = np.float32
+    r, g, b = lut[rgb[..., 0]], lut[rgb[..., 1]], lut[rgb[..., 2]]
+    X = ((f(0.4124564) * r + f(0.3575761) * g) + f(0.1804375) * b) / f(0.95047)
+    Y = (f(0.2126729) * r + f(0.7151522) * g) + f(0.0721750) * b
+    Z = ((f(0.0193339) * r + f(0.1191920) * g) + f(0.9503041) * b) / f(1.08883)
+
+    def fn(t):
+        big = t > f(0.008856)
+        return np.where(big, px_cbrt(np.where(big, t, f(1.0))), f(7.787) * t + f(0.13793103)).astype(np.float32)
+    fx, fy, fz = fn(X), fn(Y), fn(Z)
+    return f(116.0) * fy - f(16.0), f(500.0) * (fx - fy), f(200.0) * (fy - fz)
+
+
+def px_dbscan(rgb, radius, eps, spatial_weight, min_pts, lut):
+    """labels int32[H,W] (0 noise, else 1 + smallest pixel index of the cluster), core bool[H,W], counts"""
+    from scipy.sparse import coo_matrix
+    from scipy.sparse.csgraph import connected_components
+    f = np.float32
+    H, W = rgb.shape[:2]
+    L, A, B = px_lab(rgb, np.asarray(lut, np.float32))
+    eps2 = f(eps) * f(eps)
+    ws2 = f(spatial_weight) * f(spatial_weight)
+    offs = [(dy, dx) for dy in range(-radius, radius + 1) for dx in range(-radius, radius + 1)
+            if dx * dx + dy * dy <= radius * radius and abs(dy) < H and abs(dx) < W]      # larger shifts leave the image
+    idx = np.arange(H * W).reshape(H, W)
+    near = {}
+    count = np.zeros((H, W), np.int64)
+    for dy, dx in offs:
+        ys, xs = slice(max(0, -dy), min(H, H - dy)), slice(max(0, -dx), min(W, W - dx))
+        yq, xq = slice(max(0, dy), min(H, H + dy)), slice(max(0, dx), min(W, W + dx))
+        dL, dA, dB = L[ys, xs] - L[yq, xq], A[ys, xs] - A[yq, xq], B[ys, xs] - B[yq, xq]
+        d2 = ((dL * dL + dA * dA) + dB * dB) + ws2 * f(dx * dx + dy * dy)
+        m = np.zeros((H, W), bool)
+        m[ys, xs] = d2 <= eps2
+        near[(dy, dx)] = m
+        count += m
+    core = count >= min_pts
+    rows, cols = [], []
+    for (dy, dx), m in near.items():
+        if (dy, dx) == (0, 0):
+            continue
+        ys, xs = np.nonzero(m & core)
+        q_core = core[ys + dy, xs + dx]
+        rows.append(idx[ys[q_core], xs[q_core]])
+        cols.append(idx[ys[q_core] + dy, xs[q_core] + dx])
+    rows = np.concatenate(rows) if rows else np.zeros(0, np.int64)
+    cols = np.concatenate(cols) if cols else np.zeros(0, np.int64)
+    g = coo_matrix((np.ones(len(rows), np.int8), (rows, cols)), shape=(H * W, H * W))
+    _, comp = connected_components(g, directed=False)
+    root = np.full(comp.max() + 1, H * W, np.int64)
+    np.minimum.at(root, comp, np.arange(H * W))
+    name = (root[comp] + 1).reshape(H, W)
+    labels = np.where(core, name, 0)
+    best = np.full((H, W), np.iinfo(np.int64).max)
+    for (dy, dx), m in near.items():
+        if (dy, dx) == (0, 0):
+            continue
+        ys, xs = np.nonzero(m & ~core)
+        q_core = core[ys + dy, xs + dx]
+        ys, xs = ys[q_core], xs[q_core]
+        np.minimum.at(best, (ys, xs), name[ys + dy, xs + dx])
+    border = ~core & (best < np.iinfo(np.int64).max)
+    labels = np.where(border, best, labels)
+    return labels.astype(np.int32), core, np.minimum(count, 255).astype(np.uint8)
+
+
+# --------------------------------------------------------------------------------------
 # Quality metrics (decoder/uncompression/comparison.py:30-80).  PARITY UNPINNED for ssim / psnr: the
 # reference calls scikit-image (absent from the build container, unpinned in requirements.txt), so these
 # restate scikit-image's published algorithm with scipy.ndimage.uniform_filter (the routine it calls).

@@ -447,6 +447,30 @@ class Rhccq:
                          "koff": koff, "weights": weights.cpu().numpy()}
         return out
 
+    # -- EXTENSION: pixel-space DBSCAN on (x, y, L, a, b) (no reference counterpart) ------------------------
+    @staticmethod
+    def srgb_linear_lut():
+        """8-bit sRGB -> linear, float32[256] (float64 formula rounded once); shared with oracle.px_dbscan"""
+        v = np.arange(256, dtype=np.float64) / 255.0
+        return np.where(v <= 0.04045, v / 12.92, ((v + 0.055) / 1.055) ** 2.4).astype(np.float32)
+
+    def px_dbscan(self, rgb, radius, eps, spatial_weight, min_pts, want_count=False):
+        """rgb uint8[H,W,3] device -> labels int32[H,W] (0 = noise, else 1 + smallest pixel index of the cluster),
+        core mask, optional neighbour counts."""
+        assert rgb.dtype == torch.uint8 and rgb.is_contiguous()
+        H, W = int(rgb.shape[0]), int(rgb.shape[1])
+        if getattr(self, "_px_lut", None) is None:
+            self._px_lut = self.dev(self.srgb_linear_lut())
+        parent = self.empty((H, W), torch.int32)
+        count = self.empty((H, W), torch.uint8) if want_count else None
+        self._check(self.lib.rhccq_px_neighbours(self.ctx, self._p(rgb), H, W, int(radius), float(eps), float(spatial_weight), int(min_pts),
+                                                 self._p(self._px_lut), self._p(parent), self._p(count)), "px_neighbours")
+        core = parent >= 0
+        labels = self.empty((H, W), torch.int32)
+        self._check(self.lib.rhccq_px_expand(self.ctx, self._p(rgb), H, W, int(radius), float(eps), float(spatial_weight), self._p(self._px_lut),
+                                             self._p(parent), self._p(labels)), "px_expand")
+        return (labels, core, count) if want_count else (labels, core)
+
     # -- quality metrics (comparison.py:30-80) ------------------------------------------------------
     def error_sums(self, a, b):
         """a, b: uint8[H,W,3] device -> int64[5]: per-channel sum of squared differences, sum |d|, max |d|."""

@@ -221,3 +221,21 @@ def _init_chain_cases(rh, O):
         want = O.kmeanspp_int(P[ii].astype(np.int64), k, rs)
         got = info["chosen"][info["koff"][i]:info["koff"][i + 1]]
         assert np.array_equal(got, want), (i, n, k, int(np.argmax(got != want)))
+
+
+@pytest.mark.parametrize("case", [(2, 6.0, 1.0, 5), (1, 3.0, 0.0, 3), (3, 10.0, 2.0, 12), (4, 25.0, 0.5, 1), (0, 1.0, 1.0, 1)])
+def test_pixel_space_dbscan_extension(rh, O, case):
+    """EXTENSION (no reference counterpart, named by BASELINE.json's north_star): fixed-radius neighbour pass over
+    (x, y, L, a, b) + union-find cluster expansion vs the brute-force restatement -- neighbour counts, core flags and
+    labels bit-identical (float32 operations in a fixed order on both sides)."""
+    import torch
+    from roibasedimagecompression_amd import synth
+    radius, eps, ws, min_pts = case
+    lut = rh.srgb_linear_lut()
+    for H, W, seed, kind in ((37, 53, 1, "photo"), (64, 130, 2, "poster"), (16, 64, 3, "photo"), (5, 3, 4, "photo")):
+        img = synth.photo(H, W, seed, sigma=3.0) if kind == "photo" else synth.poster(H, W, seed)
+        labels, core, count = rh.px_dbscan(torch.from_numpy(img).to(rh.device), radius, eps, ws, min_pts, want_count=True)
+        ol, oc, on = O.px_dbscan(img, radius, eps, ws, min_pts, lut)
+        assert np.array_equal(count.cpu().numpy(), on), (case, H, W)
+        assert np.array_equal(core.cpu().numpy(), oc), (case, H, W)
+        assert np.array_equal(labels.cpu().numpy(), ol), (case, H, W)
