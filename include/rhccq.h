@@ -219,7 +219,9 @@ int rhccq_ssim7_sums(rhccq_ctx* ctx, const uint8_t* a, const uint8_t* b, int32_t
 /* ---- EXTENSION (no reference counterpart; named by BASELINE.json's north_star only): pixel-space DBSCAN ----
  * Features (x, y, L, a, b); q is a neighbour of p when dx^2 + dy^2 <= radius^2 (radius 0..4) and
  * dL^2 + da^2 + db^2 + spatial_weight^2 (dx^2 + dy^2) <= eps^2 (float32, operation order fixed in
- * csrc/px_dbscan_ext.hip and oracle.px_dbscan).  lin_lut: device float[256], 8-bit sRGB -> linear.
+ * csrc/px_dbscan_ext.hip and oracle.px_dbscan).  lin_lut: device float[256 + 2048]: 8-bit sRGB -> linear, then
+ * 1024 pairs (f(i / 1024), f((i + 1) / 1024) - f(i / 1024)) of the Lab transfer function, interpolated linearly;
+ * see Rhccq.px_tables().
  * rhccq_px_neighbours (the "fixed-radius neighbour pass": 3 B read + 4 B written per pixel): parent_out[p] = p for
  * a core pixel (>= min_pts neighbours, itself included), -1 otherwise; count_out (may be NULL) = neighbour count.
  * rhccq_px_expand (the "region growing"): lock-free union-find over the core pixels, then

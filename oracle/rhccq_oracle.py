@@ -763,32 +763,24 @@ def decode_container(pkg):
 # --------------------------------------------------------------------------------------
 # EXTENSION (no reference counterpart; named by BASELINE.json's north_star only): pixel-space DBSCAN on
 # (x, y, L, a, b).  Brute-force restatement of csrc/px_dbscan_ext.hip's definition: every float32 operation is
-# written in the same order, so counts, core flags and labels must be bit-identical.
+# written in the same order (and both sides read the same two tables), so counts, core flags and labels must be
+# bit-identical.
 # --------------------------------------------------------------------------------------
-def px_cbrt(t):
-    t = np.asarray(t, np.float32)
-    i = t.view(np.int32) // np.int32(3) + np.int32(709921077)      # t > 0: floor division == C division
-    y = i.view(np.float32)
-    three = np.float32(3.0)
-    for _ in range(3):
-        y2 = y * y
-        num = y2 * y - t
-        den = three * y2
-        y = y - num / den
-    return y
-
-
-def px_lab(rgb, lut):
-    """float32 Lab planes of a uint8 image with the operation order of px_lab() in px_dbscan_ext.hip"""
+def px_lab(rgb, tables):
+    """float32 Lab planes of a uint8 image with the operation order of px_lab() in px_dbscan_ext.hip;
+    tables = float32[256 + 2048]: sRGB -> linear, then (f(i/1024), df) pairs interpolated linearly"""
     f = np.float32
-    r, g, b = lut[rgb[..., 0]], lut[rgb[..., 1]], lut[rgb[..., 2]]
-    X = ((f(0.4124564) * r + f(0.3575761) * g) + f(0.1804375) * b) / f(0.95047)
+    lin, fd = tables[:256], tables[256:].reshape(-1, 2)
+    r, g, b = lin[rgb[..., 0]], lin[rgb[..., 1]], lin[rgb[..., 2]]
+    X = ((f(0.4124564) * r + f(0.3575761) * g) + f(0.1804375) * b) * f(1.0521111)
     Y = (f(0.2126729) * r + f(0.7151522) * g) + f(0.0721750) * b
-    Z = ((f(0.0193339) * r + f(0.1191920) * g) + f(0.9503041) * b) / f(1.08883)
+    Z = ((f(0.0193339) * r + f(0.1191920) * g) + f(0.9503041) * b) * f(0.9184170)
 
     def fn(t):
-        big = t > f(0.008856)
-        return np.where(big, px_cbrt(np.where(big, t, f(1.0))), f(7.787) * t + f(0.13793103)).astype(np.float32)
+        u = t * f(1024.0)
+        i = np.minimum(u.astype(np.int32), 1023)
+        frac = u - i.astype(np.float32)
+        return fd[i, 0] + frac * fd[i, 1]
     fx, fy, fz = fn(X), fn(Y), fn(Z)
     return f(116.0) * fy - f(16.0), f(500.0) * (fx - fy), f(200.0) * (fy - fz)
 

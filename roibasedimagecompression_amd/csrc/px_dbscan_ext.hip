@@ -6,8 +6,10 @@
 //
 // Definition (the builder's own, integer labels bit-exact by construction):
 //   * features of pixel p: (x, y) and a float32 CIE-Lab computed with a fixed sequence of individually rounded
-//     float32 operations (8-bit sRGB -> linear through a 256-entry table supplied by the caller, XYZ by three dot
-//     products evaluated left to right, cube root by an integer seed + three Newton steps);
+//     float32 operations: 8-bit sRGB -> linear through a 256-entry table, XYZ by three dot products evaluated left
+//     to right and scaled by the reciprocal white point, and the Lab transfer function f(t) (cube root / linear toe)
+//     by linear interpolation in a 1025-point table of f(i / 1024) -- both tables come from the caller (computed in
+//     float64, rounded once), so the GPU and the restatement in oracle/ share them bit for bit;
 //   * q is a neighbour of p when dx^2 + dy^2 <= radius^2 and
 //       ((dL^2 + da^2) + db^2) + w(dx, dy) <= eps^2,   w = spatial_weight^2 * (dx^2 + dy^2)   (float32);
 //   * p is a core pixel when it has at least min_pts neighbours (itself included);
@@ -32,27 +34,24 @@ struct PxWindow {          // window offsets in a fixed order (dy major, dx mino
   float w[kPxMaxOff];
 };
 
-__device__ __forceinline__ float px_cbrt(float t) {      // t in (0.008856, ~1.1]; same operations as oracle.px_cbrt
-  int i = __float_as_int(t);
-  i = i / 3 + 709921077;
-  float y = __int_as_float(i);
-#pragma unroll
-  for (int it = 0; it < 3; ++it) {
-    const float y2 = y * y;
-    const float num = y2 * y - t;
-    const float den = 3.0f * y2;
-    y = y - num / den;
-  }
-  return y;
-}
-__device__ __forceinline__ float px_f(float t) { return t > 0.008856f ? px_cbrt(t) : 7.787f * t + 0.13793103f; }
+constexpr int kPxLin = 256, kPxFSteps = 1024, kPxTables = kPxLin + 2 * kPxFSteps;   // caller's table: lin[256], then (f, df)[1024]
 
-__device__ __forceinline__ void px_lab(const float* __restrict__ lut, unsigned r8, unsigned g8, unsigned b8, float& L, float& A, float& B) {
-  const float r = lut[r8], g = lut[g8], b = lut[b8];
-  const float X = ((0.4124564f * r + 0.3575761f * g) + 0.1804375f * b) / 0.95047f;
+// f(t) by linear interpolation: entry i holds f(i / 1024) and the float32 difference to f((i + 1) / 1024)
+__device__ __forceinline__ float px_f(const float* __restrict__ ftab, float t) {
+  const float u = t * 1024.0f;
+  const int i = min((int)u, kPxFSteps - 1);
+  const float frac = u - (float)i;
+  const float2 fd = *reinterpret_cast<const float2*>(ftab + 2 * i);
+  return fd.x + frac * fd.y;
+}
+
+__device__ __forceinline__ void px_lab(const float* __restrict__ tab, unsigned r8, unsigned g8, unsigned b8, float& L, float& A, float& B) {
+  const float r = tab[r8], g = tab[g8], b = tab[b8];
+  const float X = ((0.4124564f * r + 0.3575761f * g) + 0.1804375f * b) * 1.0521111f;     // 1 / 0.95047
   const float Y = (0.2126729f * r + 0.7151522f * g) + 0.0721750f * b;
-  const float Z = ((0.0193339f * r + 0.1191920f * g) + 0.9503041f * b) / 1.08883f;
-  const float fx = px_f(X), fy = px_f(Y), fz = px_f(Z);
+  const float Z = ((0.0193339f * r + 0.1191920f * g) + 0.9503041f * b) * 0.9184170f;     // 1 / 1.08883
+  const float* ftab = tab + kPxLin;
+  const float fx = px_f(ftab, X), fy = px_f(ftab, Y), fz = px_f(ftab, Z);
   L = 116.0f * fy - 16.0f;
   A = 500.0f * (fx - fy);
   B = 200.0f * (fy - fz);
@@ -63,6 +62,72 @@ struct PxTile {
 };
 
 // stage the tile + apron as Lab; pixels outside the image get L = +inf (never within eps of anything)
+// Staging for the neighbour pass: columns [x0 - 4, x0 + 68) in 18 quads of 4 pixels per row (x0 is a multiple of
+// 64), rows [y0 - R, y0 + 16 + R); LDS column index = x - x0 + 4.  A quad that lies inside the image and starts on
+// a 4-byte boundary is read as three dwords, and those reads are issued one tile ahead (px_prefetch) so that their
+// latency hides behind the window tests of the current tile; edge quads are read bytewise at conversion time.
+constexpr int kPxApron = 4, kPxQuads = (kPxTW + 2 * kPxApron) / 4, kPxQuadRounds = 2;   // <= 18 * 24 = 432 quads = 2 rounds of 256
+struct PxPrefetch { uint32_t w[kPxQuadRounds][3]; };
+
+template <int kR>
+__device__ __forceinline__ void px_quad_pos(int i, int y0, int x0, int& ly, int& lx, int& y, int& x) {
+  ly = i / kPxQuads;
+  const int qd = i - ly * kPxQuads;
+  lx = 4 * qd;
+  y = y0 + ly - kR;
+  x = x0 - kPxApron + 4 * qd;
+}
+__device__ __forceinline__ bool px_quad_fast(int y, int x, int H, int W) {
+  return y >= 0 && y < H && x >= 0 && x + 3 < W && ((((size_t)y * W + x) * 3) & 3) == 0;
+}
+
+template <int kR>
+__device__ __forceinline__ void px_prefetch(PxPrefetch& pr, const uint8_t* __restrict__ rgb, int H, int W, int y0, int x0) {
+  constexpr int n_quads = kPxQuads * (kPxTH + 2 * kR);
+#pragma unroll
+  for (int r = 0; r < kPxQuadRounds; ++r) {
+    const int i = threadIdx.x + r * 256;
+    int ly, lx, y, x;
+    px_quad_pos<kR>(i, y0, x0, ly, lx, y, x);
+    if (i < n_quads && px_quad_fast(y, x, H, W)) {
+      const uint32_t* src = reinterpret_cast<const uint32_t*>(rgb + ((size_t)y * W + x) * 3);
+      pr.w[r][0] = src[0]; pr.w[r][1] = src[1]; pr.w[r][2] = src[2];
+    }
+  }
+}
+
+template <int kR>
+__device__ __forceinline__ void px_stage_r(PxTile& t, const float* s_lut, const PxPrefetch& pr, const uint8_t* __restrict__ rgb, int H, int W,
+                                           int y0, int x0) {
+  constexpr int n_quads = kPxQuads * (kPxTH + 2 * kR);
+#pragma unroll
+  for (int r = 0; r < kPxQuadRounds; ++r) {
+    const int i = threadIdx.x + r * 256;
+    if (i >= n_quads) break;
+    int ly, lx, y, x;
+    px_quad_pos<kR>(i, y0, x0, ly, lx, y, x);
+    float L[4], A[4], B[4];
+#pragma unroll
+    for (int k = 0; k < 4; ++k) { L[k] = INFINITY; A[k] = 0.0f; B[k] = 0.0f; }
+    if (px_quad_fast(y, x, H, W)) {
+      const uint32_t w0 = pr.w[r][0], w1 = pr.w[r][1], w2 = pr.w[r][2];
+      px_lab(s_lut, w0 & 255u, (w0 >> 8) & 255u, (w0 >> 16) & 255u, L[0], A[0], B[0]);
+      px_lab(s_lut, w0 >> 24, w1 & 255u, (w1 >> 8) & 255u, L[1], A[1], B[1]);
+      px_lab(s_lut, (w1 >> 16) & 255u, w1 >> 24, w2 & 255u, L[2], A[2], B[2]);
+      px_lab(s_lut, (w2 >> 8) & 255u, (w2 >> 16) & 255u, w2 >> 24, L[3], A[3], B[3]);
+    } else if (y >= 0 && y < H) {
+#pragma unroll
+      for (int k = 0; k < 4; ++k) {
+        if (x + k < 0 || x + k >= W) continue;
+        const uint8_t* px = rgb + ((size_t)y * W + (x + k)) * 3;
+        px_lab(s_lut, px[0], px[1], px[2], L[k], A[k], B[k]);
+      }
+    }
+#pragma unroll
+    for (int k = 0; k < 4; ++k) { t.L[ly][lx + k] = L[k]; t.A[ly][lx + k] = A[k]; t.B[ly][lx + k] = B[k]; }
+  }
+}
+
 __device__ __forceinline__ void px_stage(PxTile& t, const float* s_lut, const uint8_t* __restrict__ rgb, int H, int W, int y0, int x0, int R) {
   const int lw = kPxTW + 2 * R, lh = kPxTH + 2 * R;
   for (int i = threadIdx.x; i < lw * lh; i += 256) {
@@ -83,30 +148,61 @@ __device__ __forceinline__ bool px_near(const PxTile& t, int ly, int lx, int qy,
   return d2 <= eps2;
 }
 
-__global__ __launch_bounds__(256) void px_neighbours_kernel(const uint8_t* __restrict__ rgb, int H, int W, int R, float eps2, int min_pts,
-                                                            PxWindow win, const float* __restrict__ lin_lut, int32_t* __restrict__ parent,
+template <int R>
+__global__ __launch_bounds__(256) void px_neighbours_kernel(const uint8_t* __restrict__ rgb, int H, int W, float eps2, float ws2, int min_pts,
+                                                            const float* __restrict__ lin_lut, int32_t* __restrict__ parent,
                                                             uint8_t* __restrict__ count_out) {
   __shared__ PxTile t;
-  __shared__ float s_lut[256];
-  s_lut[threadIdx.x] = lin_lut[threadIdx.x];
-  __syncthreads();
-  const int tiles_x = (W + kPxTW - 1) / kPxTW;
-  const int y0 = (blockIdx.x / tiles_x) * kPxTH, x0 = (blockIdx.x % tiles_x) * kPxTW;
-  px_stage(t, s_lut, rgb, H, W, y0, x0, R);
+  __shared__ __attribute__((aligned(16))) float s_lut[kPxTables];
+  for (int i = threadIdx.x; i < kPxTables; i += 256) s_lut[i] = lin_lut[i];
+  const int tiles_x = (W + kPxTW - 1) / kPxTW, n_tiles = tiles_x * ((H + kPxTH - 1) / kPxTH);
+  // persistent workgroups: the tables are read once per workgroup, and the pixels of the next tile are requested
+  // before the window tests of the current one
+  PxPrefetch pr;
+  if ((int)blockIdx.x < n_tiles) px_prefetch<R>(pr, rgb, H, W, ((int)blockIdx.x / tiles_x) * kPxTH, ((int)blockIdx.x % tiles_x) * kPxTW);
+  for (int tile = blockIdx.x; tile < n_tiles; tile += gridDim.x) {
+  __syncthreads();                                         // tables ready / previous tile's readers done
+  const int y0 = (tile / tiles_x) * kPxTH, x0 = (tile % tiles_x) * kPxTW;
+  px_stage_r<R>(t, s_lut, pr, rgb, H, W, y0, x0);
+  {
+    const int nt = tile + (int)gridDim.x;
+    if (nt < n_tiles) px_prefetch<R>(pr, rgb, H, W, (nt / tiles_x) * kPxTH, (nt % tiles_x) * kPxTW);
+  }
   __syncthreads();
   const int row = threadIdx.x >> 4, c4 = (threadIdx.x & 15) * 4;
   const int y = y0 + row;
-  if (y >= H) return;
+  if (y >= H) continue;
+  // a thread owns 4 consecutive pixels = two float2 pairs: the distance arithmetic runs on packed float32
+  // instructions (v_pk_add / v_pk_mul), element-wise identical to the scalar form
+  typedef float f2 __attribute__((ext_vector_type(2)));
+  const int ly = row + R, lx = c4 + kPxApron;
+  const f2 pL0 = {t.L[ly][lx], t.L[ly][lx + 1]}, pL1 = {t.L[ly][lx + 2], t.L[ly][lx + 3]};
+  const f2 pA0 = {t.A[ly][lx], t.A[ly][lx + 1]}, pA1 = {t.A[ly][lx + 2], t.A[ly][lx + 3]};
+  const f2 pB0 = {t.B[ly][lx], t.B[ly][lx + 1]}, pB1 = {t.B[ly][lx + 2], t.B[ly][lx + 3]};
+  int cnt[4] = {1, 1, 1, 1};                                // offset 0 is the pixel itself: distance 0 <= eps^2
+  // the window is known at compile time: the loops unroll into straight-line code with immediate LDS offsets
+#pragma unroll
+  for (int dy = -R; dy <= R; ++dy)
+#pragma unroll
+  for (int dx = -R; dx <= R; ++dx) {
+    if (dx * dx + dy * dy > R * R || (dx == 0 && dy == 0)) continue;
+    const int qy = ly + dy, qx = lx + dx;
+    const float w = ws2 * (float)(dx * dx + dy * dy);
+    const f2 qL0 = {t.L[qy][qx], t.L[qy][qx + 1]}, qL1 = {t.L[qy][qx + 2], t.L[qy][qx + 3]};
+    const f2 qA0 = {t.A[qy][qx], t.A[qy][qx + 1]}, qA1 = {t.A[qy][qx + 2], t.A[qy][qx + 3]};
+    const f2 qB0 = {t.B[qy][qx], t.B[qy][qx + 1]}, qB1 = {t.B[qy][qx + 2], t.B[qy][qx + 3]};
+    const f2 dL0 = pL0 - qL0, dL1 = pL1 - qL1, dA0 = pA0 - qA0, dA1 = pA1 - qA1, dB0 = pB0 - qB0, dB1 = pB1 - qB1;
+    const f2 e0 = ((dL0 * dL0 + dA0 * dA0) + dB0 * dB0) + w, e1 = ((dL1 * dL1 + dA1 * dA1) + dB1 * dB1) + w;
+    cnt[0] += e0.x <= eps2; cnt[1] += e0.y <= eps2; cnt[2] += e1.x <= eps2; cnt[3] += e1.y <= eps2;
+  }
 #pragma unroll
   for (int k = 0; k < 4; ++k) {
     const int x = x0 + c4 + k;
     if (x >= W) break;
-    const int ly = row + R, lx = c4 + k + R;
-    int cnt = 0;
-    for (int o = 0; o < win.n; ++o) cnt += px_near(t, ly, lx, ly + win.dy[o], lx + win.dx[o], win.w[o], eps2);
     const size_t p = (size_t)y * W + x;
-    parent[p] = cnt >= min_pts ? (int32_t)p : -1;
-    if (count_out) count_out[p] = (uint8_t)min(cnt, 255);
+    parent[p] = cnt[k] >= min_pts ? (int32_t)p : -1;
+    if (count_out) count_out[p] = (uint8_t)min(cnt[k], 255);
+  }
   }
 }
 
@@ -135,8 +231,8 @@ __device__ __forceinline__ void px_union(int32_t* parent, int a, int b) {
 __global__ __launch_bounds__(256) void px_union_kernel(const uint8_t* __restrict__ rgb, int H, int W, int R, float eps2, PxWindow win,
                                                        const float* __restrict__ lin_lut, int32_t* parent) {
   __shared__ PxTile t;
-  __shared__ float s_lut[256];
-  s_lut[threadIdx.x] = lin_lut[threadIdx.x];
+  __shared__ __attribute__((aligned(16))) float s_lut[kPxTables];
+  for (int i = threadIdx.x; i < kPxTables; i += 256) s_lut[i] = lin_lut[i];
   __syncthreads();
   const int tiles_x = (W + kPxTW - 1) / kPxTW;
   const int y0 = (blockIdx.x / tiles_x) * kPxTH, x0 = (blockIdx.x % tiles_x) * kPxTW;
@@ -174,8 +270,8 @@ __global__ __launch_bounds__(256) void px_label_kernel(const uint8_t* __restrict
                                                        const float* __restrict__ lin_lut, const int32_t* __restrict__ parent,
                                                        int32_t* __restrict__ labels) {
   __shared__ PxTile t;
-  __shared__ float s_lut[256];
-  s_lut[threadIdx.x] = lin_lut[threadIdx.x];
+  __shared__ __attribute__((aligned(16))) float s_lut[kPxTables];
+  for (int i = threadIdx.x; i < kPxTables; i += 256) s_lut[i] = lin_lut[i];
   __syncthreads();
   const int tiles_x = (W + kPxTW - 1) / kPxTW;
   const int y0 = (blockIdx.x / tiles_x) * kPxTH, x0 = (blockIdx.x % tiles_x) * kPxTW;
@@ -246,8 +342,19 @@ int rhccq_px_neighbours(rhccq_ctx* ctx, const uint8_t* rgb, int32_t H, int32_t W
   PxWindow win{};
   if (int e = make_window(ctx, radius, spatial_weight, &win)) return e;
   const int tiles = ((W + kPxTW - 1) / kPxTW) * ((H + kPxTH - 1) / kPxTH);
-  hipLaunchKernelGGL(px_neighbours_kernel, dim3(tiles), dim3(256), 0, ctx->stream, rgb, (int)H, (int)W, (int)radius, eps * eps, (int)min_pts, win,
-                     lin_lut, parent_out, count_out);
+  const dim3 grid(tiles < 1024 ? tiles : 1024), block(256);     // persistent workgroups (146 VGPRs: 3 waves per SIMD)
+  const float eps2 = eps * eps, ws2 = spatial_weight * spatial_weight;
+#define RHCCQ_PX_LAUNCH(RR)                                                                                                             \
+  hipLaunchKernelGGL(px_neighbours_kernel<RR>, grid, block, 0, ctx->stream, rgb, (int)H, (int)W, eps2, ws2, (int)min_pts, lin_lut, parent_out, \
+                     count_out)
+  switch (radius) {
+    case 0: RHCCQ_PX_LAUNCH(0); break;
+    case 1: RHCCQ_PX_LAUNCH(1); break;
+    case 2: RHCCQ_PX_LAUNCH(2); break;
+    case 3: RHCCQ_PX_LAUNCH(3); break;
+    default: RHCCQ_PX_LAUNCH(4); break;
+  }
+#undef RHCCQ_PX_LAUNCH
   RHCCQ_LAUNCH_CHECK(ctx);
   return 0;
 }

@@ -449,10 +449,16 @@ class Rhccq:
 
     # -- EXTENSION: pixel-space DBSCAN on (x, y, L, a, b) (no reference counterpart) ------------------------
     @staticmethod
-    def srgb_linear_lut():
-        """8-bit sRGB -> linear, float32[256] (float64 formula rounded once); shared with oracle.px_dbscan"""
+    def px_tables():
+        """float32[256 + 2048]: 8-bit sRGB -> linear, then 1024 pairs (f(i/1024), f((i+1)/1024) - f(i/1024)) of the CIE-Lab
+        transfer function (cube root above 0.008856, linear toe below); values evaluated in float64 and rounded once,
+        differences taken in float32; shared with oracle.px_dbscan"""
         v = np.arange(256, dtype=np.float64) / 255.0
-        return np.where(v <= 0.04045, v / 12.92, ((v + 0.055) / 1.055) ** 2.4).astype(np.float32)
+        lin = np.where(v <= 0.04045, v / 12.92, ((v + 0.055) / 1.055) ** 2.4).astype(np.float32)
+        t = np.arange(1025, dtype=np.float64) / 1024.0
+        f = np.where(t > 0.008856, np.cbrt(t), 7.787 * t + 16.0 / 116.0).astype(np.float32)
+        fd = np.stack([f[:-1], f[1:] - f[:-1]], axis=1).reshape(-1)
+        return np.concatenate([lin, fd]).astype(np.float32)
 
     def px_dbscan(self, rgb, radius, eps, spatial_weight, min_pts, want_count=False):
         """rgb uint8[H,W,3] device -> labels int32[H,W] (0 = noise, else 1 + smallest pixel index of the cluster),
@@ -460,7 +466,7 @@ class Rhccq:
         assert rgb.dtype == torch.uint8 and rgb.is_contiguous()
         H, W = int(rgb.shape[0]), int(rgb.shape[1])
         if getattr(self, "_px_lut", None) is None:
-            self._px_lut = self.dev(self.srgb_linear_lut())
+            self._px_lut = self.dev(self.px_tables())
         parent = self.empty((H, W), torch.int32)
         count = self.empty((H, W), torch.uint8) if want_count else None
         self._check(self.lib.rhccq_px_neighbours(self.ctx, self._p(rgb), H, W, int(radius), float(eps), float(spatial_weight), int(min_pts),
