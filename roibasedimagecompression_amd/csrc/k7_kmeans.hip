@@ -335,10 +335,16 @@ __global__ __launch_bounds__(kKmThreads) void kmeans_kernel(const uint32_t* __re
     __threadfence_block();
     __syncthreads();
     if (!any_changed) { strict = 1; break; }
-    if (tid == 0) {
+    if (wave == 0) {
+      // sum of the shifts in index order, as the oracle adds them: the wave loads 64 at a time (one coalesced
+      // access instead of k dependent ones by a single thread) and folds them through readlane, left to right
       double tot = 0.0;
-      for (int j = 0; j < k; ++j) tot = tot + shift[j];  // sequential, as the oracle
-      sh.flag = tot <= tol;
+      for (int j0 = 0; j0 < k; j0 += 64) {
+        const double v = j0 + lane < k ? shift[j0 + lane] : 0.0;
+        const int m = min(64, k - j0);
+        for (int l = 0; l < m; ++l) tot = tot + __shfl(v, l, 64);
+      }
+      if (lane == 0) sh.flag = tot <= tol;
     }
     __syncthreads();
     const int stop = sh.flag;
