@@ -163,11 +163,14 @@ int rhccq_mbk_init(rhccq_ctx* ctx, const uint32_t* keys, const rhccq_mbk_problem
  * double[sum k]; seed = 42 stream of counter_hash() */
 int rhccq_mbk_steps(rhccq_ctx* ctx, const uint32_t* keys, const rhccq_mbk_problem* probs_host,
                     int32_t n_prob, int64_t step0, int32_t n_steps, uint64_t seed, double* centres,
-                    double* weights, double* state, void* work, int64_t work_bytes, int32_t estep_mode);
+                    double* weights, double* state, void* work, int64_t work_bytes, int32_t estep_mode,
+                    int32_t estep_split);
 /* estep_mode: how the batch E-step finds each point's nearest centre -- identical results either way:
  * RHCCQ_ESTEP_TILES brute force over LDS tiles of centres (few problems in flight), RHCCQ_ESTEP_GRID centres
  * re-binned into a 32^3 grid every step and searched ring by ring (many problems in flight: a batch of frames),
- * RHCCQ_ESTEP_AUTO grid when the problems handed over hold >= 200 000 centres. */
+ * RHCCQ_ESTEP_AUTO grid when the problems handed over hold >= 200 000 centres.
+ * estep_split (tiled E-step only; 0 or 1, 2, 4, 8): threads sharing one batch point, each walking 1/split of a
+ * tile's centres -- shortens the per-thread chain when only a straggler problem is still running; same results. */
 #define RHCCQ_ESTEP_AUTO 0
 #define RHCCQ_ESTEP_TILES 1
 #define RHCCQ_ESTEP_GRID 2

@@ -657,20 +657,28 @@ constexpr int kTileC = 512;         // centres per workgroup in the batch E-step
 constexpr int kPtChunks = kBatch / 256;   // a workgroup takes 256 of the batch points
 
 // state[p][16] = {ewa, ewa_min, no_improvement, since_reassign, done, steps_done, have_ewa, have_min, n_zero_weight, ...}
+// kSplit threads share one batch point, each scanning a contiguous 1/kSplit of the tile's centres: with a single
+// straggler problem still running there are only ~160 workgroups for 256 CUs and a thread's serial walk over 512
+// centres (one wave per SIMD, ~8 cycles per dependent f64 instruction) is the whole step; splitting the walk keeps
+// the arithmetic and the first-arg-min order (lower slices win ties) and shortens the chain.
+template <int kSplit>
 __global__ __launch_bounds__(256) void mbk_batch_estep_kernel(const uint32_t* __restrict__ keys, const MbkP* __restrict__ probs,
                                                               const double* __restrict__ centres, const double* __restrict__ state,
                                                               long long step, unsigned long long seed, double* __restrict__ pdist,
                                                               int32_t* __restrict__ pidx, const long long* __restrict__ part_off) {
+  constexpr int kPts = 256 / kSplit, kSlice = kTileC / kSplit;
   const int p = blockIdx.y;
   const double done = state[p * 16 + 4];                 // independent table reads, issued together
   const MbkP P = probs[p];
   const long long po = part_off[p];
   if (done != 0.0) return;
   const int n_tiles = (int)((P.k + kTileC - 1) / kTileC);
-  const int tile = blockIdx.x / kPtChunks, chunk = blockIdx.x % kPtChunks;
+  const int tile = blockIdx.x / (kPtChunks * kSplit), chunk = blockIdx.x % (kPtChunks * kSplit);
   if (tile >= n_tiles) return;
   const int bs = (int)min((long long)1000, P.n);
   __shared__ double sc[kTileC * 4];
+  __shared__ double s_bd[kSplit > 1 ? 256 : 1];
+  __shared__ int s_bj[kSplit > 1 ? 256 : 1];
   const int j0 = tile * kTileC, nj = (int)min((long long)kTileC, P.k - j0);
   for (int i = threadIdx.x; i < nj * 4; i += blockDim.x) {
     const double v = centres[(P.koff + j0) * 4 + i];
@@ -679,17 +687,33 @@ __global__ __launch_bounds__(256) void mbk_batch_estep_kernel(const uint32_t* __
   __syncthreads();
   double* pd = pdist + po + (size_t)tile * kBatch;
   int32_t* pi = pidx + po + (size_t)tile * kBatch;
-  const int b = chunk * 256 + threadIdx.x;
+  const int pt = threadIdx.x % kPts, slice = threadIdx.x / kPts;
+  const int b = chunk * kPts + pt;
+  double bd = INFINITY;
+  int bj = 0x7fffffff;
   if (b < bs) {
     const unsigned long long src = bounded(counter_hash(seed, 2ull * (unsigned long long)step, (unsigned long long)b), (unsigned long long)P.n);
     const uint32_t kk = keys[P.off + src];
     const double x0 = (double)key_r(kk), x1 = (double)key_g(kk), x2 = (double)key_b(kk);
-    double bd = sc[3] + km64_dot(x0, x1, x2, sc[0], sc[1], sc[2]);
-    int bj = 0;
-    for (int j = 1; j < nj; ++j) {
+    const int ja = slice * kSlice, jb = min(ja + kSlice, nj);
+    for (int j = ja; j < jb; ++j) {
       const double d = sc[j * 4 + 3] + km64_dot(x0, x1, x2, sc[j * 4], sc[j * 4 + 1], sc[j * 4 + 2]);
       if (d < bd) { bd = d; bj = j; }
     }
+  }
+  if (kSplit > 1) {
+    s_bd[threadIdx.x] = bd;
+    s_bj[threadIdx.x] = bj;
+    __syncthreads();
+    if (slice == 0) {
+#pragma unroll
+      for (int q = 1; q < kSplit; ++q) {                  // ascending slices = ascending centre index: strict '<'
+        const double od = s_bd[q * kPts + pt];
+        if (od < bd) { bd = od; bj = s_bj[q * kPts + pt]; }
+      }
+    }
+  }
+  if (slice == 0 && b < bs) {
     pd[b] = bd;
     pi[b] = j0 + bj;
   }
@@ -1524,7 +1548,7 @@ int rhccq_mbk_init(rhccq_ctx* ctx, const uint32_t* keys, const rhccq_mbk_problem
 
 int rhccq_mbk_steps(rhccq_ctx* ctx, const uint32_t* keys, const rhccq_mbk_problem* probs, int32_t n_prob, int64_t step0,
                     int32_t n_steps, uint64_t seed, double* centres, double* weights, double* state, void* work, int64_t work_bytes,
-                    int32_t estep_mode) {
+                    int32_t estep_mode, int32_t estep_split) {
   if (!ctx || !keys || !probs || !centres || !weights || !state || !work || n_prob <= 0 || n_steps < 0 || step0 < 0)
     return rhccq_fail(ctx, RHCCQ_E_ARG, "mbk_steps: bad argument");
   WorkView v;
@@ -1537,6 +1561,8 @@ int rhccq_mbk_steps(rhccq_ctx* ctx, const uint32_t* keys, const rhccq_mbk_proble
   long long ksum = 0;
   for (int i = 0; i < n_prob; ++i) ksum += probs[i].k;
   if (estep_mode < RHCCQ_ESTEP_AUTO || estep_mode > RHCCQ_ESTEP_GRID) return rhccq_fail(ctx, RHCCQ_E_ARG, "mbk_steps: bad estep_mode");
+  if (estep_split != 0 && estep_split != 1 && estep_split != 2 && estep_split != 4 && estep_split != 8)
+    return rhccq_fail(ctx, RHCCQ_E_ARG, "mbk_steps: estep_split must be 0, 1, 2, 4 or 8");
   const bool use_grid = estep_mode == RHCCQ_ESTEP_GRID || (estep_mode == RHCCQ_ESTEP_AUTO && ksum >= 200000);
   for (int s = 0; s < n_steps; ++s) {
     const long long step = step0 + s;
@@ -1546,8 +1572,16 @@ int rhccq_mbk_steps(rhccq_ctx* ctx, const uint32_t* keys, const rhccq_mbk_proble
       hipLaunchKernelGGL(mbk_batch_estep_grid_kernel, dim3(250, n_prob), dim3(256), 0, ctx->stream, keys, v.probs, centres, state, step,
                          (unsigned long long)seed, v.cell_start, v.order, v.pdist, v.pidx, v.part_off);
     } else {
-      hipLaunchKernelGGL(mbk_batch_estep_kernel, dim3(max_tiles * kPtChunks, n_prob), dim3(256), 0, ctx->stream, keys, v.probs, centres, state, step,
-                         (unsigned long long)seed, v.pdist, v.pidx, v.part_off);
+#define RHCCQ_ESTEP_LAUNCH(SS)                                                                                                             \
+  hipLaunchKernelGGL(mbk_batch_estep_kernel<SS>, dim3(max_tiles * kPtChunks * SS, n_prob), dim3(256), 0, ctx->stream, keys, v.probs, centres, \
+                     state, step, (unsigned long long)seed, v.pdist, v.pidx, v.part_off)
+      switch (estep_split) {
+        case 8: RHCCQ_ESTEP_LAUNCH(8); break;
+        case 4: RHCCQ_ESTEP_LAUNCH(4); break;
+        case 2: RHCCQ_ESTEP_LAUNCH(2); break;
+        default: RHCCQ_ESTEP_LAUNCH(1); break;
+      }
+#undef RHCCQ_ESTEP_LAUNCH
       hipLaunchKernelGGL(mbk_fold_tiles_kernel, dim3((1000 + 15) / 16, n_prob), dim3(64), 0, ctx->stream, v.probs, (const double*)state, v.pdist, v.pidx,
                          v.part_off);
     }

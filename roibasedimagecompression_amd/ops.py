@@ -341,7 +341,7 @@ class Rhccq:
         return out[:k], sums[:k]
 
     # -- K8 -----------------------------------------------------------------------------------------
-    def minibatch_kmeans(self, key_list, k_list, return_info=False, poll_steps=64, return_device=False, timing=None, estep="auto"):
+    def minibatch_kmeans(self, key_list, k_list, return_info=False, poll_steps=64, return_device=False, timing=None, estep="auto", estep_split=0):
         """Batched MiniBatchKMeans(k, batch_size=1000, random_state=42).fit_predict labels in the
         canonical arithmetic of oracle.minibatch_kmeans_labels.  key_list items are numpy arrays or
         device int32 tensors (kept resident); labels come back as numpy arrays, or as device tensors
@@ -427,8 +427,11 @@ class Rhccq:
             # the grid E-step pays when many centres are in flight; once only stragglers are left the tiled
             # brute force has fewer and shorter launches per step
             mode = {"tiles": 1, "grid": 2}.get(estep) or (2 if int(k_arr[running].sum()) >= 200000 else 1)
+            # few workgroups left (a straggler problem): several threads share a batch point in the tiled E-step
+            wgs = int(((k_arr[running] + 511) // 512).sum()) * 4
+            split = estep_split or next((sp for sp in (1, 2, 4, 8) if wgs * sp >= 1536), 8)
             self._check(self.lib.rhccq_mbk_steps(self.ctx, self._p(keys), probs, n_prob, step, ns, SEED, self._p(centres),
-                                                 self._p(weights), self._p(state), self._p(work), wbytes, mode), "mbk_steps")
+                                                 self._p(weights), self._p(state), self._p(work), wbytes, mode, split), "mbk_steps")
             step += ns
             st = state.cpu().numpy()
             running = (st[:, 4] == 0) & (st[:, 5] < limit)

@@ -114,7 +114,7 @@ def test_cluster_means(rh, O):
     assert np.array_equal(O.unpack_rgb(means.cpu().numpy()), want.astype(np.uint8))
 
 
-@pytest.mark.parametrize("estep", ["tiles", "grid"])
+@pytest.mark.parametrize("estep", ["tiles", "tiles/2", "tiles/4", "tiles/8", "grid"])
 def test_minibatch_vs_oracle_bit_exact(rh, O, estep):
     """Both batch E-step variants (tiled brute force for few problems; per-step re-binned centre grid when a batch
     of frames puts many problems in flight) against the oracle: step count, centres and labels bit-exact."""
@@ -124,7 +124,8 @@ def test_minibatch_vs_oracle_bit_exact(rh, O, estep):
     rng = np.random.default_rng(2)
     P2 = np.unique(rng.integers(0, 256, (30000, 3)).astype(np.uint8), axis=0)
     cases = [(pal, int(np.ceil(len(pal) * 0.2 / 10))), (pal, int(np.ceil(len(pal) * 0.1 / 10))), (P2, 450)]
-    labs, info = rh.minibatch_kmeans([O.pack_rgb(P) for P, _ in cases], [k for _, k in cases], return_info=True, estep=estep)
+    labs, info = rh.minibatch_kmeans([O.pack_rgb(P) for P, _ in cases], [k for _, k in cases], return_info=True, estep=estep.split("/")[0],
+                                      estep_split=int(estep.split("/")[1]) if "/" in estep else 1)
     for i, ((P, k), l) in enumerate(zip(cases, labs)):
         ol, oi = O.minibatch_kmeans_labels(P, k, return_info=True)
         st = info["state"][i]
