@@ -22,6 +22,7 @@ import numpy as np
 import torch
 
 from .ops import INT_MAX, clustering_params, unpack_rgb
+from .hostsort import _stable_order, _unique_first_inverse
 from .palette import cluster_palettes
 
 __all__ = ["ClassSpec", "FrameEncoder"]
@@ -84,12 +85,12 @@ def _merge(comps, bbox):
     seqs, sel = [], []
     for c in reversed(comps):
         valid = np.nonzero((c.keys != 0) & (c.fp < _FP_NONE))[0]
-        v = valid[np.argsort(c.fp[valid])]                    # first positions of distinct entries are distinct
+        v = valid[_stable_order(c.fp[valid])]                 # first positions of distinct entries are distinct
         sel.append(v)
         seqs.append(c.keys[v])
     allk = np.concatenate(seqs) if seqs else np.zeros(0, np.uint32)
-    u, first, inv = np.unique(allk, return_index=True, return_inverse=True)
-    order = np.argsort(first, kind="stable")
+    u, first, inv = _unique_first_inverse(allk)
+    order = np.argsort(first)                                 # distinct values: any sort gives the same order
     gkeys = np.concatenate([np.zeros(1, np.uint32), u[order]])
     rank = np.empty(len(u), np.int64)
     rank[order] = np.arange(1, len(u) + 1)

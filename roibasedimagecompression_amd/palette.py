@@ -14,6 +14,7 @@ import math
 import numpy as np
 import torch
 
+from .hostsort import _stable_order
 from .ops import MINIBATCH_THRESHOLD, clustering_params, pack_rgb, unpack_rgb
 
 __all__ = ["cluster_palettes", "cluster_palette", "merge_components", "clustering_params"]
@@ -131,7 +132,7 @@ def cluster_palettes(rh, jobs):
         small_leaf[s] = sl
         n_small[s] = int(is_small.sum())
         if big.any():
-            order = np.argsort(lab, kind="stable")
+            order = _stable_order(lab)
             starts = np.concatenate([[0], np.cumsum(cnt)])
             for l in np.nonzero(big)[0]:                       # ascending label; ascending index inside
                 node = _Node(s, order[starts[l]:starts[l + 1]])
@@ -151,7 +152,7 @@ def cluster_palettes(rh, jobs):
         node_of = np.repeat(np.arange(len(run), dtype=np.int64), sizes)
         members = np.concatenate([nd.members for nd, _ in run])
         key = node_of * (int(cat.max()) + 1) + cat
-        order = np.argsort(key, kind="stable")                     # ascending label; ascending index inside
+        order = _stable_order(key) if int(key.max()) < (1 << 31) else np.argsort(key, kind="stable")   # ascending label; ascending index inside
         skey = key[order]
         starts = np.concatenate([[0], np.flatnonzero(skey[1:] != skey[:-1]) + 1, [len(skey)]])
         child_node = node_of[order[starts[:-1]]]
@@ -220,7 +221,7 @@ def cluster_palettes(rh, jobs):
         if split_leaves and len(np.unique(keys)) != P:
             # find_color_index (clustering.py:803-808): a split child maps only the FIRST palette row equal
             # to each of its colours; later duplicate rows stay unmapped (0)
-            order = np.argsort(keys, kind="stable")
+            order = _stable_order(keys)
             skeys = keys[order]
             for li, rel in enumerate(split_leaves):
                 tgt = nb[rel]
