@@ -11,6 +11,8 @@ once per process (by numpy itself) and the three draw kinds the path needs are r
   resident words by `rhccq_mt_uniforms`, so that neither the host nor PCIe sees them).
 
 tests/test_cabi_cpu.py::test_mt_replay_equals_numpy_randomstate pins the replay against RandomState itself."""
+import threading
+
 import numpy as np
 
 SEED = 42
@@ -19,15 +21,18 @@ SEED = 42
 class MtWords:
     def __init__(self, seed=SEED):
         self._rs = np.random.RandomState(seed)
+        self._lock = threading.Lock()                      # replays may run on several host threads
         self.words = np.zeros(0, np.uint32)
 
     def ensure(self, n):
         """raw words [0, n) as a uint32 array (grown geometrically; the generator object keeps its position)."""
         if len(self.words) < n:
-            grow = max(n - len(self.words), len(self.words), 1 << 20)
-            # full-range uint32 draws are the raw 32-bit outputs, one word each (rng == 0xFFFFFFFF branch)
-            more = self._rs.randint(0, 1 << 32, size=grow, dtype=np.uint32)
-            self.words = np.concatenate([self.words, more])
+            with self._lock:
+                if len(self.words) < n:
+                    grow = max(n - len(self.words), len(self.words), 1 << 20)
+                    # full-range uint32 draws are the raw 32-bit outputs, one word each (rng == 0xFFFFFFFF branch)
+                    more = self._rs.randint(0, 1 << 32, size=grow, dtype=np.uint32)
+                    self.words = np.concatenate([self.words, more])
         return self.words
 
     def randint(self, pos, n, size):

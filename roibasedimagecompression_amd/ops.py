@@ -29,6 +29,17 @@ MINIBATCH_THRESHOLD = 10000          # clustering.py:205
 SEED = 42                            # random_state=42 at every sklearn call site of the reference
 
 
+_DRAW_POOL = None
+
+
+def _draw_pool():
+    global _DRAW_POOL
+    if _DRAW_POOL is None:
+        from concurrent.futures import ThreadPoolExecutor
+        _DRAW_POOL = ThreadPoolExecutor(max_workers=min(8, os.cpu_count() or 1), thread_name_prefix="rhccq-draw")
+    return _DRAW_POOL
+
+
 def pack_rgb(rgb):
     rgb = np.asarray(rgb, dtype=np.uint8).reshape(-1, 3).astype(np.uint32)
     return (rgb[:, 0] << 16) | (rgb[:, 1] << 8) | rgb[:, 2]
@@ -108,6 +119,8 @@ def first_centre_index(n, u0):
         p = np.full(n, 1.0) / np.float64(n)
         cdf = np.cumsum(p)
         cdf /= cdf[-1]
+        if len(_first_cache) > 4096:                         # a stream of frames brings ever new (n, u0): keep it bounded
+            _first_cache.clear()
         _first_cache[key] = min(int(np.searchsorted(cdf, u0, side="right")), n - 1)
     return _first_cache[key]
 
@@ -364,7 +377,9 @@ class Rhccq:
         # sample indices on the host (vectorised rejection sampling), the k-means++ uniforms on the device
         mtw = self.mtw
         upos = []
-        for i, (n, k) in enumerate(zip(sizes, k_list)):
+
+        def draw(args):
+            n, k = args
             bs = min(1000, n)
             init_size = 3 * bs
             if init_size < k:
@@ -378,18 +393,24 @@ class Rhccq:
                 pos += used
             else:
                 init_idx = np.arange(n)
-            T = 2 + int(math.log(k))
             first = first_centre_index(init_size, mtw.double(pos))
-            pos += 2
+            return init_idx.astype(np.int32), first, pos + 2
+
+        todo = list(zip(sizes, k_list))
+        # the numpy passes of a replay release the GIL: the problems' draws run side by side (the GPU waits for them)
+        drawn = list(_draw_pool().map(draw, todo)) if n_prob > 1 else [draw(todo[0])]
+        for i, ((n, k), (init_idx, first, pos)) in enumerate(zip(todo, drawn)):
+            init_size = len(init_idx)
+            T = 2 + int(math.log(k))
             nu = max((k - 1) * T, 1)
             p = probs[i]
             p.off, p.n, p.k, p.koff = int(offs[i]), n, k, int(koff[i])
             p.init_off, p.init_n, p.rand_off, p.first, p.T = ioff, init_size, roff, first, T
-            init_list.append(init_idx.astype(np.int32))
+            init_list.append(init_idx)
             upos.append((pos, nu, roff))
             ioff += init_size
             roff += nu
-            max_steps = max(max_steps, (100 * n) // bs)
+            max_steps = max(max_steps, (100 * n) // min(1000, n))
         words = self._mt_words_dev(max(pos + 2 * nu for pos, nu, _ in upos))
         d_rand = self.empty((roff,), torch.float64)
         for pos, nu, ro in upos:
