@@ -22,6 +22,22 @@ class StreamEncoder:
         if batch < 1 or lanes < 1:
             raise ValueError("batch and lanes must be >= 1")
         self.device, self.batch, self.lanes = int(device), int(batch), int(lanes)
+        self._lane_state = [None] * self.lanes           # (stream, Rhccq, FrameEncoder) per lane, kept across run() calls
+
+    def _lane(self, i):
+        """the lane's HIP stream, context and encoder (created on first use, inside the lane's stream)"""
+        if self._lane_state[i] is None:
+            stream = torch.cuda.Stream(self.device)
+            with torch.cuda.stream(stream):
+                rh = Rhccq(self.device)                   # binds its context to this lane's stream
+            self._lane_state[i] = (stream, rh, FrameEncoder(rh))
+        return self._lane_state[i]
+
+    def close(self):
+        for st in self._lane_state:
+            if st is not None:
+                st[1].close()
+        self._lane_state = [None] * self.lanes
 
     def run(self, frames):
         """frames: sequence of (rgb uint8[H,W,3] device tensor, [ClassSpec, ...]).  Returns the per-frame
@@ -35,13 +51,11 @@ class StreamEncoder:
         errors = []
         torch.cuda.synchronize(self.device)
 
-        def lane():
+        def lane(i):
             try:
                 torch.cuda.set_device(self.device)
-                stream = torch.cuda.Stream(self.device)
+                stream, rh, enc = self._lane(i)
                 with torch.cuda.stream(stream):
-                    rh = Rhccq(self.device)                   # binds its context to this lane's stream
-                    enc = FrameEncoder(rh)
                     while not errors:
                         try:
                             j = todo.get_nowait()
@@ -50,11 +64,10 @@ class StreamEncoder:
                         b = batches[j]
                         results[j] = enc.encode_batch(b) if len(b) > 1 else [enc.encode(*b[0])]
                         stream.synchronize()
-                    rh.close()
             except BaseException as e:                        # surfaced to the caller below
                 errors.append(e)
 
-        threads = [threading.Thread(target=lane, name=f"rhccq-lane{i}") for i in range(min(self.lanes, max(len(batches), 1)))]
+        threads = [threading.Thread(target=lane, args=(i,), name=f"rhccq-lane{i}") for i in range(min(self.lanes, max(len(batches), 1)))]
         for t in threads:
             t.start()
         for t in threads:
