@@ -161,3 +161,21 @@ def test_mt_replay_equals_numpy_randomstate():
         assert np.array_equal(a, v1) and np.array_equal(b, v2), n
         assert m.double(pos) == u0
         assert np.array_equal(m.doubles(pos + 2, count), u)
+
+
+def test_hostsort_helpers_equal_numpy():
+    """hostsort._stable_order / _unique_first_inverse (one unstable sort of key<<32|position composites) against
+    np.argsort(kind="stable") / np.unique(return_index, return_inverse), duplicates included"""
+    from roibasedimagecompression_amd.hostsort import _stable_order, _unique_first_inverse
+    rng = np.random.default_rng(1)
+    for n in (0, 1, 2, 5, 1000, 70000):
+        k = rng.integers(0, 1 << 24, n).astype(np.uint32)
+        if n > 10:
+            k[::7] = k[3]
+        u, f, inv = np.unique(k, return_index=True, return_inverse=True)
+        u2, f2, inv2 = _unique_first_inverse(k)
+        assert np.array_equal(u, u2) and np.array_equal(f, f2) and np.array_equal(np.asarray(inv).reshape(-1), inv2), n
+        lab = rng.integers(0, 50, n)
+        assert np.array_equal(np.argsort(lab, kind="stable"), _stable_order(lab)), n
+        fp = rng.permutation(max(n, 1) * 3)[:n].astype(np.int64) + (1 << 30)
+        assert np.array_equal(np.argsort(fp, kind="stable"), _stable_order(fp)), n

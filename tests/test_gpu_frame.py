@@ -182,8 +182,13 @@ def test_stream_encoder_equals_frame_by_frame(rh):
         frames.append((torch.from_numpy(img).to(rh.device), specs))
     enc = FrameEncoder(rh)
     single = [enc.encode(rgb, specs) for rgb, specs in frames]
-    got = StreamEncoder(0, batch=2, lanes=2).run(frames)
-    assert len(got) == len(single)
+    se = StreamEncoder(0, batch=2, lanes=2)
+    got = se.run(frames)
+    again = se.run(frames[:3])                                   # lanes (streams, contexts) are reused across runs
+    se.close()
+    assert len(got) == len(single) and len(again) == 3
+    for a, b in zip(single, again):
+        assert np.array_equal(a["palette"], b["palette"]) and torch.equal(a["indices"], b["indices"])
     for a, b in zip(single, got):
         assert np.array_equal(a["palette"], b["palette"]) and a["indices_dtype"] == b["indices_dtype"]
         assert torch.equal(a["indices"], b["indices"])
