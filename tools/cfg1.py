@@ -19,3 +19,11 @@ for (H, W, tiles, qs) in ((512, 512, (8, 8), (20, 10)), (1080, 1920, (3, 4), (20
     torch.cuda.synchronize()
     dt = time.perf_counter() - t0
     print(f"{W}x{H} segs {nr}+{nn}: {dt*1e3:.1f} ms  {H*W/dt/1e6:.2f} Mpx/s  colours {len(out['palette'])}  uniq/seg max {int(out['n_unique'].max())}", {k: round(v*1e3,1) for k,v in enc.timings.items()})
+    if "--profile" in sys.argv:
+        import cProfile, pstats
+        pr = cProfile.Profile()
+        pr.enable()
+        enc.encode(rgb, specs)
+        torch.cuda.synchronize()
+        pr.disable()
+        pstats.Stats(pr).sort_stats("tottime").print_stats(12)
