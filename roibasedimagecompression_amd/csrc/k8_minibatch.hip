@@ -774,6 +774,7 @@ struct UpdShared {
   double per[kBatch];
   int hkey[kHashSlots];
   unsigned hsum[kHashSlots][4];
+  double hold[kHashSlots][4];      // the touched centre as it was read for the labels: c0, c1, c2, weight
   unsigned long long hk[kBatch];   // reassignment hash keys
   int perm[kBatch];
   int hist[kHistBins];
@@ -855,14 +856,15 @@ __global__ __launch_bounds__(kUpdThreads) void mbk_update_kernel(const uint32_t*
     sh.hsum[i][0] = sh.hsum[i][1] = sh.hsum[i][2] = sh.hsum[i][3] = 0;
   }
   // ---- labels of the batch (the E-step kernels leave the folded arg-min in the slot of tile 0) ------------
-  double per = 0.0;
+  double per = 0.0, cb0 = 0.0, cb1 = 0.0, cb2 = 0.0, wb = 0.0;
   if (tid < bs) {
     const int bj = pidx[po + tid];
     const unsigned long long src = bounded(counter_hash(seed, 2ull * (unsigned long long)step, (unsigned long long)tid), (unsigned long long)n);
     const uint32_t kk = keys[P.off + src];
     sh.lab[tid] = bj;
     sh.bkey[tid] = kk;
-    const double d0 = (double)key_r(kk) - C[bj * 4], d1 = (double)key_g(kk) - C[bj * 4 + 1], d2 = (double)key_b(kk) - C[bj * 4 + 2];
+    cb0 = C[bj * 4]; cb1 = C[bj * 4 + 1]; cb2 = C[bj * 4 + 2]; wb = W[bj];
+    const double d0 = (double)key_r(kk) - cb0, d1 = (double)key_g(kk) - cb1, d2 = (double)key_b(kk) - cb2;
     per = (d0 * d0 + d1 * d1) + d2 * d2;
   }
   sh.per[tid] = per;
@@ -908,6 +910,9 @@ __global__ __launch_bounds__(kUpdThreads) void mbk_update_kernel(const uint32_t*
       if (cur == j) break;
       h = (h + 1) & (kHashSlots - 1);
     }
+    // the centre and its weight were fetched for the labels: park them in the slot (every member of the cluster
+    // writes the same four values), so that the update below does not go back to cold global memory
+    sh.hold[h][0] = cb0; sh.hold[h][1] = cb1; sh.hold[h][2] = cb2; sh.hold[h][3] = wb;
     const uint32_t kk = sh.bkey[tid];
     atomicAdd(&sh.hsum[h][0], key_r(kk));
     atomicAdd(&sh.hsum[h][1], key_g(kk));
@@ -917,26 +922,16 @@ __global__ __launch_bounds__(kUpdThreads) void mbk_update_kernel(const uint32_t*
   __syncthreads();
   USTAMP(2);
   {
-    // kHashSlots / kUpdThreads = 2 slots per thread: both centres' loads are issued before either is used
     static_assert(kHashSlots == 2 * kUpdThreads, "apply loop is unrolled for two slots per thread");
-    int jj[2];
-    double w0[2], cc[2][3];
 #pragma unroll
     for (int q = 0; q < 2; ++q) {
-      jj[q] = sh.hkey[tid + q * kUpdThreads];
-      const int j = max(jj[q], 0);
-      w0[q] = W[j];
-      cc[q][0] = C[j * 4]; cc[q][1] = C[j * 4 + 1]; cc[q][2] = C[j * 4 + 2];
-    }
-#pragma unroll
-    for (int q = 0; q < 2; ++q) {
-      const int j = jj[q], h = tid + q * kUpdThreads;
+      const int h = tid + q * kUpdThreads, j = sh.hkey[h];
       if (j < 0) continue;
-      const double w = w0[q], wn = w + (double)sh.hsum[h][3];
+      const double w = sh.hold[h][3], wn = w + (double)sh.hsum[h][3];
       const double alpha = 1.0 / wn;
-      const double c0 = (cc[q][0] * w + (double)sh.hsum[h][0]) * alpha;
-      const double c1 = (cc[q][1] * w + (double)sh.hsum[h][1]) * alpha;
-      const double c2 = (cc[q][2] * w + (double)sh.hsum[h][2]) * alpha;
+      const double c0 = (sh.hold[h][0] * w + (double)sh.hsum[h][0]) * alpha;
+      const double c1 = (sh.hold[h][1] * w + (double)sh.hsum[h][1]) * alpha;
+      const double c2 = (sh.hold[h][2] * w + (double)sh.hsum[h][2]) * alpha;
       C[j * 4] = c0; C[j * 4 + 1] = c1; C[j * 4 + 2] = c2;
       C[j * 4 + 3] = km64_csq(c0, c1, c2);
       W[j] = wn;
