@@ -402,25 +402,29 @@ def _mb_dist(Xb, C):
 
 def minibatch_kmeans_labels(points, k, seed=42, batch_size=1000, max_iter=100,
                             max_no_improvement=10, reassignment_ratio=0.01, return_info=False,
-                            assign=None):
-    """Restatement of sklearn 1.7.2 MiniBatchKMeans.fit (cluster/_kmeans.py) with the
-    canonical choices that make it reproducible on a GPU:
+                            assign=None, max_steps=None):
+    """Restatement of sklearn 1.7.2 MiniBatchKMeans(k, batch_size=1000, random_state=42, n_init='auto').fit
+    (cluster/_kmeans.py; reference call site clustering.py:207-218), operation for operation, on integer colours:
 
-      * init: validation_indices and init_indices are drawn from the MT19937 stream exactly as
-        sklearn does (randint(0,n,init_size) twice); the init sample is then ordered by
-        (Morton code of the colour, index) -- deviation: sklearn keeps draw order; Z-order makes 64
-        consecutive samples a compact box, which is what lets the GPU prune exactly -- and greedy
-        k-means++ runs on it in exact integers;
-      * step s draws its batch as idx_b = bounded(counter_hash(seed, 2*s, b), n), b < batch;
-      * E-step distance as in KMeans (csq_j + (-2 * fma-chain dot)) on raw 0..255 coordinates, first arg-min;
-      * centre update c = (c*w + S_int) * (1/(w+cnt)) with S_int the exact integer sum of the
-        batch members (order independent);
-      * reassignment (sklearn _mini_batch_step): candidates w < ratio*max(w); if more than
-        batch/2, keep the batch/2 smallest by (w, index) [sklearn: unstable argsort]; the i-th
-        candidate (ascending index) takes batch row perm[i], perm = batch positions ordered by
-        (counter_hash(seed, 2*s+1, b), b) [sklearn: RandomState.choice(replace=False)];
-      * batch inertia = sum_i ((x0-c0)^2 + (x1-c1)^2) + (x2-c2)^2 over the batch, added with the
-        fixed 1024-leaf binary tree of tree_sum_1024(); early stopping: sklearn's EWA rule verbatim.
+      * RandomState(seed) is consumed exactly as sklearn consumes it: validation_indices = randint(0, n, init_size)
+        (used for the stream position only: with n_init = 1 the validation inertia decides nothing), init_indices =
+        randint(0, n, init_size), k-means++ over the init sample IN DRAW ORDER (choice(p=uniform) for the first centre,
+        uniform(size=T) per further centre, exact integer distances -- kmeanspp_int), then per step
+        randint(0, n, batch) and, when centres are reassigned, choice(batch, replace=False, size=n_reassign)
+        (legacy permutation(batch)[:size]);
+      * E-step: sklearn's chunked dgemm expression csq_j + (-2 * fma-chain dot) on raw 0..255 coordinates, first arg-min
+        (km64_estep);
+      * batch inertia (_inertia_dense): sum_i ((0 + d0^2) + d1^2) + d2^2 added SEQUENTIALLY in batch order -- what sklearn
+        evaluates with one OpenMP thread (with more threads its partial sums are combined in arrival order: the last bits
+        are not reproducible there; they only matter for the '<' of the EWA early-stopping rule);
+      * centre update (_minibatch_update_dense / update_center_dense): per touched centre c*w, then += x for its batch
+        members in batch order, w += count, c *= 1/w -- each operation rounded once, in that order;
+      * reassignment (_mini_batch_step): to_reassign = w < ratio*max(w); when more than batch/2 qualify sklearn keeps
+        np.argsort(w)[:batch/2] -- an UNSTABLE sort over massively tied counts whose tie order depends on numpy's
+        SIMD sort kernel for the host CPU.  CANONICAL CHOICE (the only one left in this function): the stable order
+        (w asc, index asc).  tests/golden/make_golden.py pins everything else bit for bit by running sklearn itself with
+        that one np.argsort call forced to kind='stable';
+      * early stopping: sklearn's EWA rule verbatim (tol = 0 => no centre-shift test).
     Returns labels int32[n] from a full E-step over all points (first arg-min)."""
     P = np.asarray(points, dtype=np.int64).reshape(-1, 3)
     n = len(P)
@@ -433,8 +437,7 @@ def minibatch_kmeans_labels(points, k, seed=42, batch_size=1000, max_iter=100,
     init_size = min(init_size, n)
     rs.randint(0, n, init_size)                        # validation_indices (stream position only)
     init_indices = rs.randint(0, n, init_size) if init_size < n else np.arange(n)
-    init_indices = init_indices[np.lexsort((init_indices, morton3(pack_rgb(P[init_indices]))))]
-    cidx = kmeanspp_int(P[init_indices], k, rs)
+    cidx = kmeanspp_int(P[init_indices], k, rs)        # sklearn's draw order
     C = X[init_indices[cidx]].copy()
     W = np.zeros(k, np.float64)
     ewa = None
@@ -442,44 +445,53 @@ def minibatch_kmeans_labels(points, k, seed=42, batch_size=1000, max_iter=100,
     no_impr = 0
     since = 0
     n_steps = (max_iter * n) // bs
+    if max_steps is not None:
+        n_steps = min(n_steps, max_steps)
     steps_done = 0
+    n_reassigned = 0
     for s in range(n_steps):
         steps_done = s + 1
-        bidx = _bounded(counter_hash(seed, 2 * s, np.arange(bs)), n).astype(np.int64)
+        bidx = rs.randint(0, n, bs)
         Xb = X[bidx]
-        Pb = P[bidx]
         since += bs
         do_reassign = bool((W == 0).any() or since >= 10 * k)
         if do_reassign:
             since = 0
         lab = km64_estep(Xb, C)
         dd = Xb - C[lab]
-        per = (dd[:, 0] * dd[:, 0] + dd[:, 1] * dd[:, 1]) + dd[:, 2] * dd[:, 2]
-        inertia = tree_sum_1024(per)                    # fixed binary tree, GPU-reproducible
-        cnt = np.bincount(lab, minlength=k).astype(np.int64)
-        Sb = np.zeros((k, 3), np.int64)
-        np.add.at(Sb, lab, Pb)
+        per = ((0.0 + dd[:, 0] * dd[:, 0]) + dd[:, 1] * dd[:, 1]) + dd[:, 2] * dd[:, 2]
+        inertia = np.add.accumulate(per)[-1]            # strictly sequential sum, batch order
+        # update_center_dense, members in batch order: rank r of a batch row = number of earlier rows with its label
+        order = np.argsort(lab, kind="stable")
+        sl = lab[order]
+        start = np.flatnonzero(np.concatenate([[True], sl[1:] != sl[:-1]]))
+        seg_len = np.diff(np.concatenate([start, [len(sl)]]))
+        rank = np.arange(len(sl)) - np.repeat(start, seg_len)
+        touched = sl[start]
         Cn = C.copy()
-        t = cnt > 0
-        Wn = W.copy()
-        Wn[t] = W[t] + cnt[t].astype(np.float64)
-        alpha = 1.0 / Wn[t]
-        Cn[t] = (C[t] * W[t, None] + Sb[t].astype(np.float64)) * alpha[:, None]
-        W = Wn
+        acc = C[touched] * W[touched, None]
+        for r in range(int(seg_len.max())):
+            m = rank == r
+            rows = order[m]                              # one row per centre that has an r-th member
+            tpos = np.searchsorted(touched, lab[rows])
+            acc[tpos] = acc[tpos] + Xb[rows]
+        W[touched] = W[touched] + seg_len.astype(np.float64)
+        alpha = 1.0 / W[touched]
+        Cn[touched] = acc * alpha[:, None]
         if do_reassign and reassignment_ratio > 0:
             to_re = W < reassignment_ratio * W.max()
             if to_re.sum() > 0.5 * bs:
-                order = np.lexsort((np.arange(k), W))            # (w asc, index asc)
-                to_re[order[int(0.5 * bs):]] = False
+                keep = np.argsort(W, kind="stable")[int(0.5 * bs):]     # canonical: stable (sklearn: default quicksort)
+                to_re[keep] = False
             nre = int(to_re.sum())
             if nre:
-                keys = counter_hash(seed, 2 * s + 1, np.arange(bs))
-                perm = np.lexsort((np.arange(bs), keys))
-                Cn[to_re] = Xb[perm[:nre]]
+                new_centers = rs.choice(bs, replace=False, size=nre)
+                Cn[to_re] = Xb[new_centers]
+                n_reassigned += nre
             W[to_re] = np.min(W[~to_re])
         C = Cn
         # _mini_batch_convergence
-        binert = inertia / np.float64(bs)
+        binert = inertia / bs
         if s + 1 == 1:
             continue
         if ewa is None:
@@ -500,8 +512,18 @@ def minibatch_kmeans_labels(points, k, seed=42, batch_size=1000, max_iter=100,
     else:
         labels = assign(X, C)
     if return_info:
-        return labels, {"n_steps": steps_done, "centers": C, "weights": W}
+        return labels, {"n_steps": steps_done, "centers": C, "weights": W, "init_indices": init_indices, "picks": cidx,
+                        "n_reassigned": n_reassigned, "mt_pos": mt_position(rs)}
     return labels
+
+
+def mt_position(rs):
+    """number of raw 32-bit MT19937 words a RandomState has consumed so far, assuming <= 2^31 (diagnostic: the GPU path
+    reports its stream cursor, tests compare).  Derived from the generator state by replaying a twin from the seed is
+    not possible in general, so this simply returns the in-block position; callers that need the absolute cursor
+    count words themselves."""
+    st = rs.get_state()
+    return int(st[2])
 
 
 # --------------------------------------------------------------------------------------

@@ -1,16 +1,20 @@
 // K8: the MiniBatchKMeans branch the reference takes for palettes of >= 10 000 colours
 // (encoder/compression/clustering.py:207-230; sklearn 1.7.2 MiniBatchKMeans(n_clusters, batch_size=1000,
-// random_state=42, n_init='auto')).  Tier B parity: the algorithm is sklearn's, the random stream of the
-// mini-batch loop and the tie-breaking of its argsort are the canonical, reproducible ones of
-// oracle/rhccq_oracle.py::minibatch_kmeans_labels, which these kernels reproduce bit-for-bit.
+// random_state=42, n_init='auto')).  These kernels follow sklearn's fit operation for operation -- the
+// RandomState(42) stream (randint batches, choice() reassignment rows, k-means++ uniforms) is replayed on the
+// device from its raw MT19937 words, k-means++ runs over the init sample in DRAW order, centre updates add the
+// batch members in batch order -- so that the result equals sklearn's bit for bit, except for ONE canonical
+// choice: np.argsort's unstable tie order in the low-count reassignment is replaced by the stable order
+// (oracle/rhccq_oracle.py::minibatch_kmeans_labels; pinned against sklearn itself in tests/golden/).
 //
 // MI355X design
-//   init   greedy k-means++ over the (sorted) init sample in EXACT integers.  The chain of k picks is
-//          sequential, so one 1024-thread workgroup owns a problem; samples are grouped in blocks of 64
-//          consecutive (key-sorted => spatially coherent) samples with a bounding box and the block's
-//          max / sum of closest distances, and a candidate only visits blocks whose box is nearer than
-//          that max (exact pruning: the skipped samples cannot change).  One wave per candidate,
-//          64 boxes tested per wave step (ballot), 64 samples of a hit block evaluated per step.
+//   init   greedy k-means++ over the init sample in EXACT integers.  The chain of k picks is sequential, so one
+//          1024-thread workgroup owns a problem.  Two orders of the same samples are kept: the DRAW order
+//          (sklearn's: the cumulative-sum search for candidates runs over per-block sums of it) and, purely as
+//          an internal pruning index, the Morton order of the colours: blocks of 64 Morton-consecutive samples
+//          have a tight bounding box and carry the max of their closest distances, and a candidate only
+//          visits blocks whose box is nearer than that max (exact pruning: the skipped samples cannot
+//          change).  A committed improvement is scattered to the draw-order copy and its block sums.
 //   steps  per step two launches for all problems: (A) brute-force E-step of the 1000-point batch
 //          against all centres, centres tiled 64 per workgroup through LDS, partial arg-mins written per
 //          tile; (B) one workgroup per problem reduces the partials in tile order (first arg-min),
@@ -27,14 +31,6 @@ namespace rhccq {
 // ------------------------------------------------------------------------------------------------
 // shared helpers
 // ------------------------------------------------------------------------------------------------
-__device__ __forceinline__ unsigned long long counter_hash(unsigned long long seed, unsigned long long stream, unsigned long long counter) {
-  unsigned long long z = seed * 0x9E3779B97F4A7C15ull + stream * 0xD1B54A32D192ED03ull + counter * 0x2545F4914F6CDD1Dull;
-  z = (z ^ (z >> 30)) * 0xBF58476D1CE4E5B9ull;
-  z = (z ^ (z >> 27)) * 0x94D049BB133111EBull;
-  return z ^ (z >> 31);
-}
-__device__ __forceinline__ unsigned long long bounded(unsigned long long z, unsigned long long n) { return ((z >> 32) * n) >> 32; }
-
 struct MbkP {  // device copy of rhccq_mbk_problem
   long long off, n, k, koff, init_off, init_n, rand_off;
   int first, T;
@@ -99,23 +95,24 @@ __device__ __forceinline__ unsigned box_dist2(const CandP& c, uint32_t xr, uint3
   return box_axis2(xr, c.r, box_axis2(xg, c.g, box_axis2(xb, c.b, 0u)));
 }
 
-// per problem scratch layout: samp[np] (uint2 = {key, closest}) and, when the tables do not fit LDS,
-// xr[nb] xg[nb] xb[nb] bmax[nb] bsum[nb] sxr[nsb] sxg[nsb] sxb[nsb] sbmax[nsb] sbsum[nsb]
+// per problem scratch layout: samp[np] (uint2 = {key, closest}, Morton order), dsamp[np] (the same pairs in
+// sklearn's draw order), mperm[np] (Morton position -> draw position) and, when the tables do not fit LDS,
+// xr[nb] xg[nb] xb[nb] bmax[nb] dsum[nb] sxr[nsb] sxg[nsb] sxb[nsb] sbmax[nsb] dssum[nsb]
 //   nb = ceil(init_n / 64) blocks of 64 samples, np = nb * 64, nsb = ceil(nb / 16) super-blocks
 constexpr int kInitLdsBlocks = 4096;   // tables in LDS up to 262144 init samples (80 KB + 5 KB)
 constexpr int kInitLdsSuper = kInitLdsBlocks / 16;
 
 struct InitTables {
-  uint32_t* xr;     // per block: bounding box, one (lo, -hi) i16 pair per channel
+  uint32_t* xr;     // per MORTON block: bounding box, one (lo, -hi) i16 pair per channel
   uint32_t* xg;
   uint32_t* xb;
-  uint32_t* bmax;   // max closest distance in the block
-  uint32_t* bsum;   // sum of closest distances in the block
-  uint32_t* sxr;    // per super-block (16 blocks): box, max of bmax (may lag high), exact sum of bsum
+  uint32_t* bmax;   // max closest distance in the Morton block
+  uint32_t* dsum;   // per DRAW block (64 consecutive draws): exact sum of closest distances
+  uint32_t* sxr;    // per Morton super-block (16 blocks): box, max of bmax (may lag high)
   uint32_t* sxg;
   uint32_t* sxb;
   uint32_t* sbmax;
-  uint32_t* sbsum;
+  uint32_t* dssum;  // per DRAW super-block (16 draw blocks): exact sum of dsum
 };
 
 #ifdef RHCCQ_STAMPS   // diagnostic build only (tools/stamps.py): per-phase cycle shares of the init chain
@@ -214,20 +211,25 @@ __device__ __forceinline__ void enumerate_hits(const CandP& ck, int nb, int nsb,
   }
 }
 
-// lower closest[] of block b against centre ck (samples already in `sv`); refresh bmax / bsum / sbsum; note
-// the super-block as touched
-__device__ __forceinline__ void commit_block(int b, uint32_t ck, uint2 sv, uint2* samp, const InitTables& tb, int* touch, int* n_touch,
-                                             int touch_cap) {
+// lower closest[] of Morton block b against centre ck (samples already in `sv`, their draw positions in `dpos`);
+// refresh bmax and the draw-order sums; note the super-block as touched
+__device__ __forceinline__ void commit_block(int b, uint32_t ck, uint2 sv, uint32_t dpos, uint2* samp, uint2* dsamp, const InitTables& tb,
+                                             int* touch, int* n_touch, int touch_cap) {
   const int lane = threadIdx.x & 63;
   const unsigned d = (unsigned)dist2_keys(ck, sv.x);
   unsigned c2 = sv.y;
-  if (d < c2) { c2 = d; samp[(b << 6) + lane].y = d; }
-  const unsigned dm = wave_max_u32(c2), ds = wave_sum_u32(c2);
+  if (d < c2) {
+    // the improvement goes to both copies of the sample and to the draw-order sums the candidate search reads
+    const unsigned delta = c2 - d;
+    c2 = d;
+    samp[(b << 6) + lane].y = d;
+    dsamp[dpos].y = d;
+    atomicSub(&tb.dsum[dpos >> 6], delta);
+    atomicSub(&tb.dssum[dpos >> 10], delta);
+  }
+  const unsigned dm = wave_max_u32(c2);
   if (lane == 0) {
-    const unsigned old = tb.bsum[b];
     tb.bmax[b] = dm;
-    tb.bsum[b] = ds;
-    if (old != ds) atomicSub(&tb.sbsum[b >> 4], old - ds);
     const int slot = atomicAdd(n_touch, 1);
     if (slot < touch_cap) touch[slot] = b >> 4;
   }
@@ -239,8 +241,8 @@ constexpr int kMaxTouch = 1024;
 constexpr int kEvalItems = 8;             // (candidate, block) items a wave keeps in flight per round of the evaluation
 
 __device__ __forceinline__ void init_body(const uint32_t* __restrict__ keys, const MbkP& P, const int32_t* __restrict__ init_idx,
-                                          const double* __restrict__ rand, double* __restrict__ centres, int32_t* __restrict__ cho,
-                                          uint2* samp, InitTables tb, InitShared& sh, double* s_u /* [2][kTMaxI] */, int* s_touch,
+                                          const int32_t* __restrict__ perm, const double* __restrict__ rand, double* __restrict__ centres,
+                                          int32_t* __restrict__ cho, uint2* samp, uint2* dsamp, uint32_t* mperm, InitTables tb, InitShared& sh, double* s_u /* [2][kTMaxI] */, int* s_touch,
                                           uint32_t* s_items /* nullptr: no work list (tables in global memory) */, uint32_t* s_hits,
                                           int max_items) {
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
@@ -249,9 +251,14 @@ __device__ __forceinline__ void init_body(const uint32_t* __restrict__ keys, con
   // ---- gather the sample, first centre, block tables -----------------------------------------------
   const uint32_t kf = keys[P.off + init_idx[P.init_off + P.first]];
   for (int i = tid; i < np; i += kInitThreads) {
-    const int src = i < n ? i : n - 1;                  // padding repeats the last sample with closest = 0
-    const uint32_t kk = keys[P.off + init_idx[P.init_off + src]];
-    samp[i] = make_uint2(kk, i < n ? (unsigned)dist2_keys(kk, kf) : 0u);
+    // Morton position i holds the sample drawn at position d = perm[i]; padding (i >= n) repeats the last
+    // Morton sample with closest = 0 and sits at the unused draw positions n .. np-1
+    const int d = i < n ? perm[P.init_off + i] : i;
+    const uint32_t kk = keys[P.off + init_idx[P.init_off + (i < n ? d : perm[P.init_off + n - 1])]];
+    const uint2 sv = make_uint2(kk, i < n ? (unsigned)dist2_keys(kk, kf) : 0u);
+    samp[i] = sv;
+    dsamp[d] = sv;
+    mperm[i] = (uint32_t)d;
   }
   __syncthreads();
   for (int b = wave; b < nb; b += kInitWaves) {
@@ -263,13 +270,14 @@ __device__ __forceinline__ void init_body(const uint32_t* __restrict__ keys, con
       g0 = min(g0, (unsigned)__shfl_down(g0, o, 64)); g1 = max(g1, (unsigned)__shfl_down(g1, o, 64));
       b0 = min(b0, (unsigned)__shfl_down(b0, o, 64)); b1 = max(b1, (unsigned)__shfl_down(b1, o, 64));
     }
-    const unsigned dm = wave_max_u32(sv.y), ds = wave_sum_u32(sv.y);   // <= 64 * 195075 fits 32 bits
+    const unsigned dm = wave_max_u32(sv.y);
+    const unsigned ds = wave_sum_u32(dsamp[(b << 6) + lane].y);        // draw block b; <= 64 * 195075 fits 32 bits
     if (lane == 0) {
       tb.xr[b] = box_pair(r0, r1);
       tb.xg[b] = box_pair(g0, g1);
       tb.xb[b] = box_pair(b0, b1);
       tb.bmax[b] = dm;
-      tb.bsum[b] = ds;
+      tb.dsum[b] = ds;
     }
   }
   __syncthreads();
@@ -282,13 +290,13 @@ __device__ __forceinline__ void init_body(const uint32_t* __restrict__ keys, con
       r0 = min(r0, pair_lo(xr)); g0 = min(g0, pair_lo(xg)); b0 = min(b0, pair_lo(xb));
       r1 = max(r1, pair_hi(xr)); g1 = max(g1, pair_hi(xg)); b1 = max(b1, pair_hi(xb));
       m = max(m, tb.bmax[b]);
-      sum += tb.bsum[b];                                // <= 16 * 64 * 195075 < 2^32
+      sum += tb.dsum[b];                                // <= 16 * 64 * 195075 < 2^32
     }
     tb.sxr[sb] = box_pair((unsigned)r0, (unsigned)r1);
     tb.sxg[sb] = box_pair((unsigned)g0, (unsigned)g1);
     tb.sxb[sb] = box_pair((unsigned)b0, (unsigned)b1);
     tb.sbmax[sb] = m;
-    tb.sbsum[sb] = sum;
+    tb.dssum[sb] = sum;
     psum += sum;
   }
   psum = block_sum<unsigned long long>(psum, sh.red64);
@@ -317,14 +325,15 @@ __device__ __forceinline__ void init_body(const uint32_t* __restrict__ keys, con
     if (wave < T) {
       const int t = wave;
       const double r = u[t] * (double)pot;
-      // np.searchsorted(cumsum(closest), r, 'left') through super-block / block / sample sums (all exact)
+      // np.searchsorted(cumsum(closest), r, 'left') over the DRAW order, through its super-block / block / sample
+      // sums (all exact integers, so the grouping does not matter)
       int cand = r <= 0.0 ? 0 : n - 1;
       uint32_t ck = 0;
       bool found = false;
       {
         unsigned long long loc = 0;
         const int s0 = lane * persb;
-        for (int i = 0; i < persb; ++i) loc += (s0 + i < nsb) ? tb.sbsum[s0 + i] : 0u;
+        for (int i = 0; i < persb; ++i) loc += (s0 + i < nsb) ? tb.dssum[s0 + i] : 0u;
         // persb <= 21 super-blocks of < 2e8 each keep a lane's sum below 2^32 (kInitLdsSuper / 64 = 4 in LDS)
         const unsigned long long inc = loc < 0x100000000ull && persb <= 21 ? wave_incscan_limbs((unsigned)loc) : wave_incscan_u64(loc);
         const unsigned long long exc = inc - loc;
@@ -334,7 +343,7 @@ __device__ __forceinline__ void init_body(const uint32_t* __restrict__ keys, con
           unsigned long long cum = exc;
           int sb = s0;
           for (int i = 0; i < persb - 1; ++i) {          // walk inside the owning lane's chunk
-            const unsigned v = (sb < nsb) ? tb.sbsum[sb] : 0u;
+            const unsigned v = (sb < nsb) ? tb.dssum[sb] : 0u;
             if ((double)(cum + v) >= r) break;
             cum += v;
             ++sb;
@@ -344,7 +353,7 @@ __device__ __forceinline__ void init_body(const uint32_t* __restrict__ keys, con
                 (unsigned)__builtin_amdgcn_readlane((int)(unsigned)cum, src);
           // level 2: the 16 blocks of the super-block
           const int b2 = sb * 16 + (lane & 15);
-          const unsigned long long v2 = (lane < 16 && b2 < nb) ? tb.bsum[b2] : 0u;
+          const unsigned long long v2 = (lane < 16 && b2 < nb) ? tb.dsum[b2] : 0u;
           const unsigned long long inc2 = wave_incscan_u32((unsigned)v2);     // 16 blocks x < 1.25e7 fits 32 bits
           const unsigned long long m2 = __ballot(lane < 16 && v2 > 0 && (double)(cum + inc2 - v2) < r && r <= (double)(cum + inc2));
           if (m2) {
@@ -353,7 +362,7 @@ __device__ __forceinline__ void init_body(const uint32_t* __restrict__ keys, con
             const unsigned long long cum2 = cum + (unsigned)__builtin_amdgcn_readlane((int)(unsigned)(inc2 - v2), l2);
             // level 3: the 64 samples of the block
             const int i = (b << 6) + lane;
-            const uint2 sv = samp[i];
+            const uint2 sv = dsamp[i];
             const unsigned long long inc3 = wave_incscan_u32(i < n ? sv.y : 0u);   // 64 x 195075 fits 32 bits
             const unsigned long long m3 = __ballot(i < n && (double)(cum2 + inc3) >= r);
             const int l3 = m3 ? __ffsll((long long)m3) - 1 : min(63, n - 1 - (b << 6));
@@ -363,7 +372,7 @@ __device__ __forceinline__ void init_body(const uint32_t* __restrict__ keys, con
           }
         }
       }
-      if (!found) ck = samp[cand].x;
+      if (!found) ck = dsamp[cand].x;
       STAMP(0);
       if (lane == 0) {
         sh.cand[t] = cand;
@@ -560,7 +569,7 @@ __device__ __forceinline__ void init_body(const uint32_t* __restrict__ keys, con
           const int l = __ffsll((long long)m) - 1;
           m &= m - 1;
           const int b = (int)((uint32_t)__shfl((int)itx, l, 64) & 0xffffffu);
-          commit_block(b, kb, samp[(b << 6) + lane], samp, tb, touch_w, n_touch_w, kMaxTouch);
+          commit_block(b, kb, samp[(b << 6) + lane], mperm[(b << 6) + lane], samp, dsamp, tb, touch_w, n_touch_w, kMaxTouch);
         }
       }
     } else {
@@ -580,7 +589,7 @@ __device__ __forceinline__ void init_body(const uint32_t* __restrict__ keys, con
             const int p = __ffsll((long long)mb) - 1;
             mb &= mb - 1;
             const int bb = sx * 16 + p;
-            commit_block(bb, kb, samp[(bb << 6) + lane], samp, tb, touch_w, n_touch_w, kMaxTouch);
+            commit_block(bb, kb, samp[(bb << 6) + lane], mperm[(bb << 6) + lane], samp, dsamp, tb, touch_w, n_touch_w, kMaxTouch);
           }
         }
       }
@@ -612,7 +621,7 @@ __device__ __forceinline__ void init_body(const uint32_t* __restrict__ keys, con
     for (int i = 0; i < 16; ++i) g_init_stamps[i] += _acc[i];
 #endif
   for (int j = tid; j < k; j += kInitThreads) {
-    const uint32_t kk = samp[cho[j]].x;
+    const uint32_t kk = dsamp[cho[j]].x;
     const double c0 = (double)key_r(kk), c1 = (double)key_g(kk), c2 = (double)key_b(kk);
     double* C = centres + (P.koff + j) * 4;
     C[0] = c0; C[1] = c1; C[2] = c2; C[3] = km64_csq(c0, c1, c2);
@@ -620,8 +629,9 @@ __device__ __forceinline__ void init_body(const uint32_t* __restrict__ keys, con
 }
 
 __global__ __launch_bounds__(kInitThreads) void mbk_init_kernel(const uint32_t* __restrict__ keys, const MbkP* __restrict__ probs,
-                                                                const int32_t* __restrict__ init_idx, const double* __restrict__ rand,
-                                                                double* __restrict__ centres, int32_t* __restrict__ chosen,
+                                                                const int32_t* __restrict__ init_idx, const int32_t* __restrict__ perm,
+                                                                const double* __restrict__ rand, double* __restrict__ centres,
+                                                                int32_t* __restrict__ chosen,
                                                                 uint32_t* scratch, const long long* __restrict__ scratch_off,
                                                                 int lds_blocks, int max_items) {
   __shared__ InitShared sh;
@@ -633,18 +643,20 @@ __global__ __launch_bounds__(kInitThreads) void mbk_init_kernel(const uint32_t* 
   const MbkP P = probs[blockIdx.x];
   const int nb = ((int)P.init_n + 63) >> 6, np = nb << 6, nsb = (nb + 15) >> 4;
   uint2* samp = reinterpret_cast<uint2*>(scratch + scratch_off[blockIdx.x]);
+  uint2* dsamp = samp + np;
+  uint32_t* mperm = reinterpret_cast<uint32_t*>(dsamp + np);
   InitTables tb;
   if (nb <= lds_blocks) {
     tb.xr = s_tab; tb.xg = s_tab + kInitLdsBlocks; tb.xb = s_tab + 2 * kInitLdsBlocks;
-    tb.bmax = s_tab + 3 * kInitLdsBlocks; tb.bsum = s_tab + 4 * kInitLdsBlocks;
+    tb.bmax = s_tab + 3 * kInitLdsBlocks; tb.dsum = s_tab + 4 * kInitLdsBlocks;
     tb.sxr = s_tab + 5 * kInitLdsBlocks; tb.sxg = tb.sxr + kInitLdsSuper; tb.sxb = tb.sxg + kInitLdsSuper;
-    tb.sbmax = tb.sxb + kInitLdsSuper; tb.sbsum = tb.sbmax + kInitLdsSuper;
-    init_body(keys, P, init_idx, rand, centres, chosen + P.koff, samp, tb, sh, s_u, s_touch, s_items, s_hits, max_items);
+    tb.sbmax = tb.sxb + kInitLdsSuper; tb.dssum = tb.sbmax + kInitLdsSuper;
+    init_body(keys, P, init_idx, perm, rand, centres, chosen + P.koff, samp, dsamp, mperm, tb, sh, s_u, s_touch, s_items, s_hits, max_items);
   } else {
-    uint32_t* g = reinterpret_cast<uint32_t*>(samp + np);
-    tb.xr = g; tb.xg = g + nb; tb.xb = g + 2 * nb; tb.bmax = g + 3 * nb; tb.bsum = g + 4 * nb;
-    tb.sxr = g + 5 * nb; tb.sxg = tb.sxr + nsb; tb.sxb = tb.sxg + nsb; tb.sbmax = tb.sxb + nsb; tb.sbsum = tb.sbmax + nsb;
-    init_body(keys, P, init_idx, rand, centres, chosen + P.koff, samp, tb, sh, s_u, s_touch, nullptr, nullptr, 0);
+    uint32_t* g = mperm + np;
+    tb.xr = g; tb.xg = g + nb; tb.xb = g + 2 * nb; tb.bmax = g + 3 * nb; tb.dsum = g + 4 * nb;
+    tb.sxr = g + 5 * nb; tb.sxg = tb.sxr + nsb; tb.sxb = tb.sxg + nsb; tb.sbmax = tb.sxb + nsb; tb.dssum = tb.sbmax + nsb;
+    init_body(keys, P, init_idx, perm, rand, centres, chosen + P.koff, samp, dsamp, mperm, tb, sh, s_u, s_touch, nullptr, nullptr, 0);
   }
 }
 
@@ -664,7 +676,7 @@ constexpr int kPtChunks = kBatch / 256;   // a workgroup takes 256 of the batch 
 template <int kSplit>
 __global__ __launch_bounds__(256) void mbk_batch_estep_kernel(const uint32_t* __restrict__ keys, const MbkP* __restrict__ probs,
                                                               const double* __restrict__ centres, const double* __restrict__ state,
-                                                              long long step, unsigned long long seed, double* __restrict__ pdist,
+                                                              const uint32_t* __restrict__ bkeys, double* __restrict__ pdist,
                                                               int32_t* __restrict__ pidx, const long long* __restrict__ part_off) {
   constexpr int kPts = 256 / kSplit, kSlice = kTileC / kSplit;
   const int p = blockIdx.y;
@@ -692,8 +704,7 @@ __global__ __launch_bounds__(256) void mbk_batch_estep_kernel(const uint32_t* __
   double bd = INFINITY;
   int bj = 0x7fffffff;
   if (b < bs) {
-    const unsigned long long src = bounded(counter_hash(seed, 2ull * (unsigned long long)step, (unsigned long long)b), (unsigned long long)P.n);
-    const uint32_t kk = keys[P.off + src];
+    const uint32_t kk = bkeys[(size_t)p * kBatch + b];       // colour of batch row b (drawn by the previous update)
     const double x0 = (double)key_r(kk), x1 = (double)key_g(kk), x2 = (double)key_b(kk);
     const int ja = slice * kSlice, jb = min(ja + kSlice, nj);
     for (int j = ja; j < jb; ++j) {
@@ -767,22 +778,29 @@ constexpr int kUpdWaves = kUpdThreads / 64;
 constexpr int kHashSlots = 2048;
 constexpr int kHistBins = 2048;
 constexpr int kStateStride = 16;    // doubles per problem, see rhccq_mbk_steps
+constexpr int kMemCap = 8;          // batch members listed per touched centre; beyond, the centre's thread scans the batch
+constexpr int kStageWords = 2048;   // MT19937 words staged in LDS for the shuffle replay (expected need: ~1 400)
+constexpr int kDrawWords = 4;       // words per thread and round of the randint replay (4 096 per round)
+constexpr long long kWordsMargin = 16384;   // words a step may consume at most (randint ~2 000, shuffle ~1 400 expected)
 
 struct UpdShared {
-  int lab[kBatch];
+  int lab[kBatch];                 // labels of the batch; later the indices of the next batch
   uint32_t bkey[kBatch];
   double per[kBatch];
   int hkey[kHashSlots];
-  unsigned hsum[kHashSlots][4];
+  int hcnt[kHashSlots];
+  unsigned short hmem[kHashSlots][kMemCap];
   double hold[kHashSlots][4];      // the touched centre as it was read for the labels: c0, c1, c2, weight
-  unsigned long long hk[kBatch];   // reassignment hash keys
-  int perm[kBatch];
+  int perm[kBatch];                // reassignment: permutation(batch)[:n_reassign]
+  unsigned short jswap[kBatch];    // the shuffle's j_i
+  uint32_t stage[kStageWords];
   int hist[kHistBins];
   double dred[kUpdWaves];
   int ired[kUpdWaves + 1];
   int weq[kUpdWaves], wsel[kUpdWaves];
   double sel_w;
   int take;
+  long long cursor;
 };
 
 __device__ __forceinline__ double block_max_d(double v, UpdShared& sh) {
@@ -817,6 +835,145 @@ __device__ __forceinline__ bool reassign_sel(double w, double thr, bool capped, 
   return w == sel_w && eq_rank < take;
 }
 
+// ---- numpy's legacy RandomState, replayed from its raw MT19937 words (resident on the device, mt.py) ----------
+// RandomState.randint(0, rng + 1, count) at word `cursor` (_bounded_integers.pyx, legacy use_masked path): candidates
+// `word & mask` (mask = smallest 2^b - 1 >= rng), one word each, kept when <= rng.  All threads of the workgroup:
+// thread t looks at kDrawWords consecutive words per round, a block scan orders the survivors.  out[0 .. count) (LDS)
+// receives the values in draw order.  Returns the cursor behind the last consumed word (-1: the table is exhausted).
+__device__ __forceinline__ long long replay_randint(const uint32_t* __restrict__ words, long long n_words, long long cursor, unsigned rng,
+                                                    int count, int* out, int* ired, long long* s_cursor) {
+  const int tid = threadIdx.x;
+  if (rng == 0u) {                                       // numpy draws nothing for a one-value range
+    for (int i = tid; i < count; i += kUpdThreads) out[i] = 0;
+    __syncthreads();
+    return cursor;
+  }
+  const uint32_t mask = 0xffffffffu >> __clz(rng);
+  int produced = 0;
+  while (true) {
+    if (cursor + (long long)kUpdThreads * kDrawWords > n_words) return -1;
+    const long long base = cursor + (long long)tid * kDrawWords;
+    uint32_t v[kDrawWords];
+    int cnt = 0;
+#pragma unroll
+    for (int q = 0; q < kDrawWords; ++q) {
+      v[q] = words[base + q] & mask;
+      cnt += v[q] <= rng;
+    }
+    int tot;
+    int pos = produced + block_exscan<int>(cnt, ired, &tot);
+#pragma unroll
+    for (int q = 0; q < kDrawWords; ++q) {
+      if (v[q] <= rng) {
+        if (pos < count) {
+          out[pos] = (int)v[q];
+          if (pos == count - 1) *s_cursor = base + q + 1;
+        }
+        ++pos;
+      }
+    }
+    __syncthreads();
+    if (produced + tot >= count) return *s_cursor;
+    produced += tot;
+    cursor += (long long)kUpdThreads * kDrawWords;
+  }
+}
+
+// RandomState.permutation(bs)[:n_take] -- what choice(bs, replace=False, size=n_take) returns (mtrand.pyx legacy):
+// shuffle of arange(bs), `for i in reversed(range(1, bs)): j = random_interval(i); swap(x[i], x[j])`, random_interval(i)
+// = masked rejection (mask = smallest 2^b - 1 >= i) on one 32-bit word per attempt.
+//   phase A (wave 0): the j_i and the cursor behind the last word.  The word a lane looks at is fixed (every attempt
+//     consumes one), only the i it faces depends on the rejections before it: lane t first assumes none, the first
+//     lane that then rejects is a true rejection, the lanes behind it move up by one, and so on -- one ballot per
+//     rejection, 64 words per window;
+//   phase B: thread r < n_take follows position r backwards through the swaps (i = 1 .. bs-1) to the arange entry
+//     that ends there.
+// `stage` holds the words [stage_base, stage_base + kStageWords) (loaded by the whole workgroup beforehand).
+__device__ __forceinline__ long long replay_permutation(const uint32_t* __restrict__ words, long long n_words, long long cursor, int bs,
+                                                        int n_take, UpdShared& sh, long long stage_base) {
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  if (wave == 0) {
+    int i_cur = bs - 1;
+    long long c = cursor;
+    bool fail = false;
+    while (i_cur >= 1) {
+      if (c + 64 > n_words) { fail = true; break; }
+      const long long wi = c + lane, so = wi - stage_base;
+      const uint32_t w = (so >= 0 && so < kStageWords) ? sh.stage[so] : words[wi];
+      const unsigned long long below = (1ull << lane) - 1ull;
+      unsigned long long rejm = 0ull;                    // confirmed rejections of this window
+      int known = 0;                                     // lanes below `known` are settled
+      int i_t;
+      uint32_t m;
+      bool valid;
+      while (true) {
+        i_t = i_cur - lane + __popcll(rejm & below);
+        valid = i_t >= 1;
+        m = valid ? (0xffffffffu >> __clz((unsigned)i_t)) : 0u;
+        unsigned long long nm = __ballot(valid && (w & m) > (unsigned)i_t);
+        nm &= known >= 64 ? 0ull : ~((1ull << known) - 1ull);
+        if (!nm) break;
+        const int t1 = __ffsll((long long)nm) - 1;
+        rejm |= 1ull << t1;
+        known = t1 + 1;
+      }
+      const bool acc = valid && !((rejm >> lane) & 1ull);
+      if (acc) sh.jswap[i_t] = (unsigned short)(w & m);
+      const unsigned long long am = __ballot(acc);
+      const int n_acc = __popcll(am);
+      if (i_cur - n_acc < 1) {                           // the shuffle ends inside this window: behind the lane that drew j_1
+        c += 64 - __clzll((long long)am);
+        i_cur = 0;
+      } else {
+        c += 64;
+        i_cur -= n_acc;
+      }
+    }
+    if (lane == 0) sh.cursor = fail ? -1ll : c;
+  }
+  __syncthreads();
+  const long long out = sh.cursor;
+  if (out >= 0 && tid < n_take) {
+    int pos = tid;
+    for (int i = 1; i < bs; ++i) {
+      const int j = sh.jswap[i];
+      pos = pos == i ? j : (pos == j ? i : pos);
+    }
+    sh.perm[tid] = pos;
+  }
+  __syncthreads();
+  return out;
+}
+
+// the batch of the next step: rows = randint(0, n, bs), their colours -> bkeys (what the E-step kernels read)
+__device__ __forceinline__ long long draw_batch(const uint32_t* __restrict__ keys, const MbkP& P, const uint32_t* __restrict__ words,
+                                                long long n_words, long long cursor, uint32_t* __restrict__ bkeys_p, int* out, int* ired,
+                                                long long* s_cursor) {
+  const int bs = (int)min((long long)1000, P.n);
+  const long long c = replay_randint(words, n_words, cursor, (unsigned)(P.n - 1), bs, out, ired, s_cursor);
+  if (c < 0) return c;
+  for (int b = threadIdx.x; b < bs; b += kUpdThreads) bkeys_p[b] = keys[P.off + out[b]];
+  return c;
+}
+
+// first batch of every problem (state[10] == 0: not drawn yet)
+__global__ __launch_bounds__(kUpdThreads) void mbk_draw0_kernel(const uint32_t* __restrict__ keys, const MbkP* __restrict__ probs,
+                                                                 double* __restrict__ state, const uint32_t* __restrict__ words,
+                                                                 long long n_words, uint32_t* __restrict__ bkeys) {
+  __shared__ int s_out[kBatch];
+  __shared__ int s_red[kUpdWaves + 1];
+  __shared__ long long s_cursor;
+  const int p = blockIdx.x;
+  double* st = state + p * kStateStride;
+  if (st[10] != 0.0 || st[4] != 0.0) return;
+  const MbkP P = probs[p];
+  const long long c = draw_batch(keys, P, words, n_words, (long long)st[9], bkeys + (size_t)p * kBatch, s_out, s_red, &s_cursor);
+  if (threadIdx.x == 0) {
+    if (c < 0) st[4] = 3.0;                              // word table exhausted: the host extends it and clears the flag
+    else { st[9] = (double)c; st[10] = 1.0; }
+  }
+}
+
 #ifdef RHCCQ_STAMPS
 __device__ unsigned long long g_upd_stamps[16];
 #define USTAMP(slot) do { if (tid == 0 && p == 0) { const unsigned long long _t = clock64(); atomicAdd(&g_upd_stamps[slot], _t - _ul); _ul = _t; } } while (0)
@@ -824,16 +981,20 @@ __device__ unsigned long long g_upd_stamps[16];
 #define USTAMP(slot) do {} while (0)
 #endif
 
+// One mini-batch step after its E-step (sklearn _mini_batch_step + _mini_batch_convergence), one workgroup per problem.
+// state[p][16] = {ewa, ewa_min, no_improvement, since_reassign, done (1 converged, 2 out of steps, 3 word table exhausted),
+//                 steps_done, have_ewa, have_min, n_zero_weight_centres, MT cursor (raw words consumed so far), batch_drawn, ...}
 __global__ __launch_bounds__(kUpdThreads) void mbk_update_kernel(const uint32_t* __restrict__ keys, const MbkP* __restrict__ probs,
                                                                  double* __restrict__ centres, double* __restrict__ weights,
-                                                                 double* __restrict__ state, long long step, unsigned long long seed,
+                                                                 double* __restrict__ state, const uint32_t* __restrict__ words,
+                                                                 long long n_words, uint32_t* __restrict__ bkeys,
                                                                  const double* __restrict__ pdist, const int32_t* __restrict__ pidx,
                                                                  const long long* __restrict__ part_off) {
   __shared__ UpdShared sh;
   const int p = blockIdx.x, tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
   double* st = state + p * kStateStride;
   // independent table reads issued together: the kernel is a chain of dependent accesses, every cold miss counts
-  const double st_done = st[4], st_since = st[3], st_nzero = st[8];
+  const double st_done = st[4], st_since = st[3], st_nzero = st[8], st_steps = st[5], st_cursor = st[9];
   const MbkP P = probs[p];
   const long long po = part_off[p];
   if (st_done != 0.0) return;
@@ -841,8 +1002,14 @@ __global__ __launch_bounds__(kUpdThreads) void mbk_update_kernel(const uint32_t*
   const long long n = P.n;
   const int bs = (int)min((long long)1000, n);
   const long long n_steps_max = (100 * n) / bs;
+  const long long step = (long long)st_steps;
+  long long cursor = (long long)st_cursor;
   if (step >= n_steps_max) {
     if (tid == 0) st[4] = 2.0;                           // ran out of steps
+    return;
+  }
+  if (cursor + kWordsMargin > n_words) {                 // before anything is modified: the host extends the table and resumes
+    if (tid == 0) st[4] = 3.0;
     return;
   }
 #ifdef RHCCQ_STAMPS
@@ -851,53 +1018,43 @@ __global__ __launch_bounds__(kUpdThreads) void mbk_update_kernel(const uint32_t*
 #endif
   double* C = centres + P.koff * 4;
   double* W = weights + P.koff;
-  for (int i = tid; i < kHashSlots; i += kUpdThreads) {
-    sh.hkey[i] = -1;
-    sh.hsum[i][0] = sh.hsum[i][1] = sh.hsum[i][2] = sh.hsum[i][3] = 0;
-  }
-  // ---- labels of the batch (the E-step kernels leave the folded arg-min in the slot of tile 0) ------------
-  double per = 0.0, cb0 = 0.0, cb1 = 0.0, cb2 = 0.0, wb = 0.0;
-  if (tid < bs) {
-    const int bj = pidx[po + tid];
-    const unsigned long long src = bounded(counter_hash(seed, 2ull * (unsigned long long)step, (unsigned long long)tid), (unsigned long long)n);
-    const uint32_t kk = keys[P.off + src];
-    sh.lab[tid] = bj;
-    sh.bkey[tid] = kk;
-    cb0 = C[bj * 4]; cb1 = C[bj * 4 + 1]; cb2 = C[bj * 4 + 2]; wb = W[bj];
-    const double d0 = (double)key_r(kk) - cb0, d1 = (double)key_g(kk) - cb1, d2 = (double)key_b(kk) - cb2;
-    per = (d0 * d0 + d1 * d1) + d2 * d2;
-  }
-  sh.per[tid] = per;
-  USTAMP(0);
+  uint32_t* bkeys_p = bkeys + (size_t)p * kBatch;
   // reassignment decision uses the weights BEFORE this step's update (sklearn _random_reassign):
   // st[8] = number of zero-weight centres, maintained by the reassignment sweep (it can only be non-zero
   // while every step reassigns)
   double since = st_since + (double)bs;
   const bool do_reassign = st_nzero > 0.0 || since >= 10.0 * (double)k;
   if (do_reassign) since = 0.0;
-  // ---- batch inertia: the fixed 1024-leaf tree of the canonical spec (level s adds leaf i + s to leaf i,
-  // s = 512 ... 1), evaluated by ONE wave: lane i first folds its 16 leaves i + 64 h over the four high levels in
-  // registers, then the six low levels run on shuffles -- same additions in the same order, one barrier instead
-  // of ten (a barrier of 16 waves costs ~1 000 cycles here)
+  if (do_reassign) {                                     // the words a shuffle would read: requested now, needed much later
+    for (int i = tid; i < kStageWords; i += kUpdThreads) sh.stage[i] = words[cursor + i];
+  }
+  for (int i = tid; i < kHashSlots; i += kUpdThreads) { sh.hkey[i] = -1; sh.hcnt[i] = 0; }
+  // ---- labels of the batch (the E-step kernels leave the folded arg-min in the slot of tile 0) ------------
+  double per = 0.0, cb0 = 0.0, cb1 = 0.0, cb2 = 0.0, wb = 0.0;
+  if (tid < bs) {
+    const int bj = pidx[po + tid];
+    const uint32_t kk = bkeys_p[tid];
+    sh.lab[tid] = bj;
+    sh.bkey[tid] = kk;
+    cb0 = C[bj * 4]; cb1 = C[bj * 4 + 1]; cb2 = C[bj * 4 + 2]; wb = W[bj];
+    // sklearn _euclidean_dense_dense for 3 features: result = 0; result += d*d per feature (0 + x is exact)
+    const double d0 = (double)key_r(kk) - cb0, d1 = (double)key_g(kk) - cb1, d2 = (double)key_b(kk) - cb2;
+    per = (d0 * d0 + d1 * d1) + d2 * d2;
+  }
+  sh.per[tid] = per;
+  USTAMP(0);
   __syncthreads();
+  // ---- batch inertia (_inertia_dense with one thread): the per-sample terms added in batch order, one after the
+  // other.  The last thread of the workgroup (a batch has 1 000 rows: it has no row of its own) walks them while the
+  // other waves build the member lists.
   double inertia = 0.0;
-  if (wave == 0) {
-    double v[16];
-#pragma unroll
-    for (int h = 0; h < 16; ++h) v[h] = sh.per[lane + 64 * h];
-#pragma unroll
-    for (int h = 0; h < 8; ++h) v[h] = v[h] + v[h + 8];          // s = 512
-#pragma unroll
-    for (int h = 0; h < 4; ++h) v[h] = v[h] + v[h + 4];          // s = 256
-#pragma unroll
-    for (int h = 0; h < 2; ++h) v[h] = v[h] + v[h + 2];          // s = 128
-    double t = v[0] + v[1];                                      // s = 64
-#pragma unroll
-    for (int o = 32; o > 0; o >>= 1) t = t + __shfl_down(t, o, 64);   // s = 32 ... 1: lane i adds lane i + s
-    inertia = t;                                                 // valid in lane 0 == thread 0, its only reader
+  if (tid == kUpdThreads - 1) {
+#pragma unroll 8
+    for (int b = 0; b < bs; ++b) inertia = inertia + sh.per[b];
+    sh.dred[0] = inertia;                                // read by thread 0 after the next barriers
   }
   USTAMP(1);
-  // ---- exact integer member sums per touched centre (LDS hash) -------------------------------------
+  // ---- members of every touched centre (LDS hash keyed by centre) -------------------------------------
   if (tid < bs) {
     const int j = sh.lab[tid];
     unsigned h = ((unsigned)j * 2654435761u) >> 21;     // 11 bits
@@ -913,25 +1070,45 @@ __global__ __launch_bounds__(kUpdThreads) void mbk_update_kernel(const uint32_t*
     // the centre and its weight were fetched for the labels: park them in the slot (every member of the cluster
     // writes the same four values), so that the update below does not go back to cold global memory
     sh.hold[h][0] = cb0; sh.hold[h][1] = cb1; sh.hold[h][2] = cb2; sh.hold[h][3] = wb;
-    const uint32_t kk = sh.bkey[tid];
-    atomicAdd(&sh.hsum[h][0], key_r(kk));
-    atomicAdd(&sh.hsum[h][1], key_g(kk));
-    atomicAdd(&sh.hsum[h][2], key_b(kk));
-    atomicAdd(&sh.hsum[h][3], 1u);
+    const int pos = atomicAdd(&sh.hcnt[h], 1);
+    if (pos < kMemCap) sh.hmem[h][pos] = (unsigned short)tid;
   }
   __syncthreads();
+  const double inertia_all = sh.dred[0];
   USTAMP(2);
+  // ---- update_center_dense: c*w, += x for the members IN BATCH ORDER, w += count, c *= 1/w (each rounded once) ----
   {
     static_assert(kHashSlots == 2 * kUpdThreads, "apply loop is unrolled for two slots per thread");
 #pragma unroll
     for (int q = 0; q < 2; ++q) {
       const int h = tid + q * kUpdThreads, j = sh.hkey[h];
       if (j < 0) continue;
-      const double w = sh.hold[h][3], wn = w + (double)sh.hsum[h][3];
+      const int cnt = sh.hcnt[h];
+      const double w = sh.hold[h][3];
+      double a0 = sh.hold[h][0] * w, a1 = sh.hold[h][1] * w, a2 = sh.hold[h][2] * w;
+      if (cnt <= kMemCap) {
+        int prev = -1;
+        for (int i = 0; i < cnt; ++i) {                  // next member in ascending batch row
+          int best = 0x7fffffff;
+#pragma unroll
+          for (int m = 0; m < kMemCap; ++m) {
+            const int r = m < cnt ? (int)sh.hmem[h][m] : 0x7fffffff;
+            if (r > prev && r < best) best = r;
+          }
+          prev = best;
+          const uint32_t kk = sh.bkey[best];
+          a0 = a0 + (double)key_r(kk); a1 = a1 + (double)key_g(kk); a2 = a2 + (double)key_b(kk);
+        }
+      } else {                                           // many members (small k): walk the batch
+        for (int b = 0; b < bs; ++b) {
+          if (sh.lab[b] != j) continue;
+          const uint32_t kk = sh.bkey[b];
+          a0 = a0 + (double)key_r(kk); a1 = a1 + (double)key_g(kk); a2 = a2 + (double)key_b(kk);
+        }
+      }
+      const double wn = w + (double)cnt;
       const double alpha = 1.0 / wn;
-      const double c0 = (sh.hold[h][0] * w + (double)sh.hsum[h][0]) * alpha;
-      const double c1 = (sh.hold[h][1] * w + (double)sh.hsum[h][1]) * alpha;
-      const double c2 = (sh.hold[h][2] * w + (double)sh.hsum[h][2]) * alpha;
+      const double c0 = a0 * alpha, c1 = a1 * alpha, c2 = a2 * alpha;
       C[j * 4] = c0; C[j * 4 + 1] = c1; C[j * 4 + 2] = c2;
       C[j * 4 + 3] = km64_csq(c0, c1, c2);
       W[j] = wn;
@@ -963,6 +1140,8 @@ __global__ __launch_bounds__(kUpdThreads) void mbk_update_kernel(const uint32_t*
       }
     }
     cnt = block_sum_i(cnt, sh);
+    // more than batch/2 candidates: sklearn keeps np.argsort(weights)[:batch/2] -- an unstable sort over tied counts;
+    // CANONICAL: the stable order (weight, index), the one choice of this path that is not sklearn's own
     const bool capped = cnt > 0.5 * (double)bs;
     double sel_w = thr;
     int take = 0;
@@ -1028,53 +1207,49 @@ __global__ __launch_bounds__(kUpdThreads) void mbk_update_kernel(const uint32_t*
     int rbase = 0, n_re = 0;
     for (int w = 0; w < kUpdWaves; ++w) { if (w < wave) rbase += sh.wsel[w]; n_re += sh.wsel[w]; }
     if (n_re > 0) {
-      // perm = batch positions ordered by (hash key, position)
-      if (tid < bs) sh.hk[tid] = counter_hash(seed, 2ull * (unsigned long long)step + 1ull, (unsigned long long)tid);
-      __syncthreads();
-      if (tid < bs) {
-        const unsigned long long me = sh.hk[tid];
-        int rank = 0;
-        for (int b = 0; b < bs; ++b) {
-          const unsigned long long o = sh.hk[b];
-          rank += (o < me) || (o == me && b < tid);
+      // new_centers = random_state.choice(batch, replace=False, size=n_reassigns): rows of the batch
+      cursor = replay_permutation(words, n_words, cursor, bs, n_re, sh, (long long)st_cursor);
+    }
+    if (cursor >= 0) {
+      // sweep 3: apply; count the centres whose weight is still zero afterwards
+      int nzero = 0, r_run = rbase;
+      eq_run = eq_base;
+      for (int jb = j0; jb < j1; jb += 64) {
+        const int j = jb + lane;
+        const double w = j < j1 ? W[j] : INFINITY;
+        const bool is_eq = capped && (w < thr) && (w == sel_w);
+        const unsigned long long meq = __ballot(is_eq);
+        const int rank = eq_run + __popcll(meq & ((1ull << lane) - 1ull));
+        const bool sel = j < j1 && reassign_sel(w, thr, capped, sel_w, take, rank);
+        const unsigned long long msel = __ballot(sel);
+        double wf = w;
+        if (sel) {
+          // centers_new[to_reassign] = X[new_centers]: the i-th reassigned centre (ascending index) takes batch row perm[i]
+          const uint32_t kk = sh.bkey[sh.perm[r_run + __popcll(msel & ((1ull << lane) - 1ull))]];
+          const double c0 = (double)key_r(kk), c1 = (double)key_g(kk), c2 = (double)key_b(kk);
+          C[j * 4] = c0; C[j * 4 + 1] = c1; C[j * 4 + 2] = c2;
+          C[j * 4 + 3] = km64_csq(c0, c1, c2);
+          W[j] = wmin;
+          wf = wmin;
         }
-        sh.perm[rank] = tid;
+        nzero += (j < j1) && (wf == 0.0);
+        eq_run += __popcll(meq);
+        r_run += __popcll(msel);
       }
-      __syncthreads();
+      nzero = block_sum_i(nzero, sh);
+      if (tid == 0) st[8] = (double)nzero;
     }
-    // sweep 3: apply; count the centres whose weight is still zero afterwards
-    int nzero = 0, r_run = rbase;
-    eq_run = eq_base;
-    for (int jb = j0; jb < j1; jb += 64) {
-      const int j = jb + lane;
-      const double w = j < j1 ? W[j] : INFINITY;
-      const bool is_eq = capped && (w < thr) && (w == sel_w);
-      const unsigned long long meq = __ballot(is_eq);
-      const int rank = eq_run + __popcll(meq & ((1ull << lane) - 1ull));
-      const bool sel = j < j1 && reassign_sel(w, thr, capped, sel_w, take, rank);
-      const unsigned long long msel = __ballot(sel);
-      double wf = w;
-      if (sel) {
-        const uint32_t kk = sh.bkey[sh.perm[r_run + __popcll(msel & ((1ull << lane) - 1ull))]];
-        const double c0 = (double)key_r(kk), c1 = (double)key_g(kk), c2 = (double)key_b(kk);
-        C[j * 4] = c0; C[j * 4 + 1] = c1; C[j * 4 + 2] = c2;
-        C[j * 4 + 3] = km64_csq(c0, c1, c2);
-        W[j] = wmin;
-        wf = wmin;
-      }
-      nzero += (j < j1) && (wf == 0.0);
-      eq_run += __popcll(meq);
-      r_run += __popcll(msel);
-    }
-    nzero = block_sum_i(nzero, sh);
-    if (tid == 0) st[8] = (double)nzero;
   }
   USTAMP(4);
+  // ---- the next step's batch: minibatch_indices = random_state.randint(0, n_samples, batch_size) ------------
+  if (cursor >= 0) cursor = draw_batch(keys, P, words, n_words, cursor, bkeys_p, sh.lab, sh.ired, &sh.cursor);
   // ---- sklearn _mini_batch_convergence (EWA early stopping) -------------------------------------------
   if (tid == 0) {
     st[3] = since;
     st[5] = (double)(step + 1);
-    const double binert = inertia / (double)bs;
+    if (cursor < 0) st[4] = 3.0;                         // cannot happen within kWordsMargin; the step itself is complete
+    else st[9] = (double)cursor;
+    const double binert = inertia_all / (double)bs;
     if (step + 1 != 1) {
       double ewa;
       if (st[6] == 0.0) { ewa = binert; st[6] = 1.0; }
@@ -1267,7 +1442,7 @@ __device__ __forceinline__ void grid_scan_shell(int r_lo, int r_hi, int cx, int 
 // writes the same (distance, label) the tiled kernel + tile reduction produce, into tile 0 of the partials
 __global__ __launch_bounds__(256) void mbk_batch_estep_grid_kernel(const uint32_t* __restrict__ keys, const MbkP* __restrict__ probs,
                                                                    const double* __restrict__ centres, const double* __restrict__ state,
-                                                                   long long step, unsigned long long seed, const uint32_t* __restrict__ cell_start,
+                                                                   const uint32_t* __restrict__ bkeys, const uint32_t* __restrict__ cell_start,
                                                                    const uint32_t* __restrict__ order, double* __restrict__ pdist,
                                                                    int32_t* __restrict__ pidx, const long long* __restrict__ part_off) {
   const int p = blockIdx.y;
@@ -1276,8 +1451,7 @@ __global__ __launch_bounds__(256) void mbk_batch_estep_grid_kernel(const uint32_
   const int bs = (int)min((long long)1000, P.n);
   const int b = blockIdx.x * 4 + (threadIdx.x >> 6);     // one wave per batch point
   if (b >= bs) return;
-  const unsigned long long src = bounded(counter_hash(seed, 2ull * (unsigned long long)step, (unsigned long long)b), (unsigned long long)P.n);
-  const uint32_t kk = keys[P.off + src];
+  const uint32_t kk = bkeys[(size_t)p * kBatch + b];
   const uint32_t* cs = cell_start + (size_t)p * (kGridCells + 1);
   const uint32_t* ord = order + P.koff;
   const double* C = centres + P.koff * 4;
@@ -1298,7 +1472,7 @@ __global__ __launch_bounds__(256) void mbk_batch_estep_grid_kernel(const uint32_
   }
 }
 
-// ---- init sample order: (Morton code, index) sort keys ------------------------------------------------
+// ---- internal pruning order of the init samples: (Morton code of the colour, draw position) sort keys ----------
 __device__ __forceinline__ uint32_t spread3(uint32_t v) {
   v &= 0xFFu;
   v = (v | (v << 16)) & 0xFF0000FFu;
@@ -1309,20 +1483,20 @@ __device__ __forceinline__ uint32_t spread3(uint32_t v) {
 }
 __global__ __launch_bounds__(256) void sample_sortkey_kernel(const uint32_t* __restrict__ keys, const MbkP* __restrict__ probs, int n_prob,
                                                              const int32_t* __restrict__ init_idx, unsigned long long* __restrict__ out,
-                                                             long long total) {
-  const long long t = (long long)blockIdx.x * 256 + threadIdx.x;
+                                                             long long base, long long total) {
+  const long long t = (long long)blockIdx.x * 256 + threadIdx.x;      // sample base + t of the chunk's first problem
   if (t >= total) return;
   int p = 0;
-  while (p + 1 < n_prob && probs[p + 1].init_off <= t) ++p;
-  const uint32_t idx = (uint32_t)init_idx[t];
+  while (p + 1 < n_prob && probs[p + 1].init_off <= base + t) ++p;
+  const uint32_t idx = (uint32_t)init_idx[base + t];
   const uint32_t kk = keys[probs[p].off + idx];
   const uint32_t m = (spread3(kk >> 16) << 2) | (spread3(kk >> 8) << 1) | spread3(kk);
-  out[t] = ((unsigned long long)p << 56) | ((unsigned long long)m << 32) | idx;
+  out[t] = ((unsigned long long)p << 56) | ((unsigned long long)m << 32) | (uint32_t)(base + t - probs[p].init_off);
 }
-__global__ __launch_bounds__(256) void sample_unpack_kernel(const unsigned long long* __restrict__ sorted, int32_t* __restrict__ init_idx,
-                                                            long long total) {
+__global__ __launch_bounds__(256) void sample_unpack_kernel(const unsigned long long* __restrict__ sorted, int32_t* __restrict__ perm,
+                                                            long long base, long long total) {
   const long long t = (long long)blockIdx.x * 256 + threadIdx.x;
-  if (t < total) init_idx[t] = (int32_t)(uint32_t)sorted[t];
+  if (t < total) perm[base + t] = (int32_t)(uint32_t)sorted[t];
 }
 
 // ---- uniform(size=count) of numpy's legacy RandomState from the resident raw MT19937 words (mt.py) ---------
@@ -1367,7 +1541,7 @@ using namespace rhccq;
 extern "C" {
 
 // work layout for steps/assign: [probs MbkP[n_prob]] [part_off i64[n_prob]] [blk_off i64[n_prob+1]]
-//                               [pdist f64[sum tiles*1024]] [pidx i32[sum tiles*1024]]
+//                               [pdist f64[sum tiles*1024]] [pidx i32[sum tiles*1024]] [grid tables] [bkeys u32[n_prob*1024]]
 int64_t rhccq_mbk_work_bytes(const rhccq_mbk_problem* probs, int32_t n_prob) {
   if (!probs || n_prob <= 0) return 0;
   size_t part = 0;
@@ -1377,6 +1551,7 @@ int64_t rhccq_mbk_work_bytes(const rhccq_mbk_problem* probs, int32_t n_prob) {
   size_t ksum = 0;
   for (int i = 0; i < n_prob; ++i) ksum += (size_t)probs[i].k;
   bytes += align256((size_t)n_prob * (kGridCells + 1) * 4) + align256((size_t)n_prob * kGridCells * 4) + align256(ksum * 4);
+  bytes += align256((size_t)n_prob * kBatch * 4);
   return (int64_t)bytes;
 }
 
@@ -1389,6 +1564,7 @@ struct WorkView {
   uint32_t* cell_start;   // [n_prob][cells + 1]
   uint32_t* cursor;       // [n_prob][cells] (spare)
   uint32_t* order;        // [sum k] centre indices grouped by cell (problem-relative)
+  uint32_t* bkeys;        // [n_prob][1024] colours of the current batch rows (written by the draws)
   long long max_k;
 };
 
@@ -1424,6 +1600,12 @@ static int layout_work(rhccq_ctx* ctx, const rhccq_mbk_problem* probs, int n_pro
   v->cell_start = (uint32_t*)base; base += align256((size_t)n_prob * (kGridCells + 1) * 4);
   v->cursor = (uint32_t*)base; base += align256((size_t)n_prob * kGridCells * 4);
   v->order = (uint32_t*)base;
+  {
+    size_t ksum = 0;
+    for (int i = 0; i < n_prob; ++i) ksum += (size_t)probs[i].k;
+    base += align256(ksum * 4);
+  }
+  v->bkeys = (uint32_t*)base;
   v->max_k = 0;
   for (int i = 0; i < n_prob; ++i) v->max_k = probs[i].k > v->max_k ? probs[i].k : v->max_k;
   if (int e = put(ctx, v->probs, hp, sizeof(MbkP) * n_prob)) return e;
@@ -1449,45 +1631,55 @@ int rhccq_debug_stamps(unsigned long long* out16_host) {
 }
 #endif
 
-// ---- canonical order of the init samples -------------------------------------------------------------
-// sort key = problem << 56 | Morton code of the sampled colour << 32 | sample index: one device radix sort
-// (rocPRIM through hipCUB) orders the samples of every problem at once by (Morton code, index)
+// ---- Morton order of the init samples (internal pruning index of rhccq_mbk_init) ------------------------------
+// sort key = problem << 56 | Morton code of the sampled colour << 32 | draw position: one device radix sort
+// (rocPRIM through hipCUB) per chunk of <= 256 problems orders their samples at once
 int64_t rhccq_mbk_order_bytes(int64_t total) { return total <= 0 ? 0 : 16 * total + (8ll << 20); }
 
-int rhccq_mbk_order(rhccq_ctx* ctx, const uint32_t* keys, const rhccq_mbk_problem* probs, int32_t n_prob, int32_t* init_idx, void* tmp,
-                    int64_t tmp_bytes) {
-  if (!ctx || !keys || !probs || !init_idx || !tmp || n_prob <= 0) return rhccq_fail(ctx, RHCCQ_E_ARG, "mbk_order: bad argument");
-  if (n_prob > 256) return rhccq_fail(ctx, RHCCQ_E_LIMIT, "mbk_order: more than 256 problems in one call");
-  std::string stage;
-  stage.resize(sizeof(MbkP) * (size_t)n_prob);
-  MbkP* hp = (MbkP*)stage.data();
-  long long total = 0;
+int rhccq_mbk_order(rhccq_ctx* ctx, const uint32_t* keys, const rhccq_mbk_problem* probs, int32_t n_prob, const int32_t* init_idx,
+                    int32_t* perm, void* tmp, int64_t tmp_bytes) {
+  if (!ctx || !keys || !probs || !init_idx || !perm || !tmp || n_prob <= 0) return rhccq_fail(ctx, RHCCQ_E_ARG, "mbk_order: bad argument");
+  long long grand = 0;
   for (int i = 0; i < n_prob; ++i) {
     const rhccq_mbk_problem& q = probs[i];
-    if (q.init_n <= 0 || q.init_off != total || q.n <= 0 || q.n > 0x7fffffffll) return rhccq_fail(ctx, RHCCQ_E_ARG, "mbk_order: bad problem");
-    hp[i] = MbkP{q.off, q.n, q.k, q.koff, q.init_off, q.init_n, q.rand_off, q.first, q.T};
-    total += q.init_n;
+    if (q.init_n <= 0 || q.init_off != grand || q.n <= 0 || q.n > 0x7fffffffll) return rhccq_fail(ctx, RHCCQ_E_ARG, "mbk_order: bad problem");
+    grand += q.init_n;
   }
-  if (total > 0x7fffffffll) return rhccq_fail(ctx, RHCCQ_E_LIMIT, "mbk_order: too many samples");
-  if (tmp_bytes < rhccq_mbk_order_bytes(total)) return rhccq_fail(ctx, RHCCQ_E_ARG, "mbk_order: tmp too small");
-  if (int e = ensure_scratch(ctx, align256(sizeof(MbkP) * n_prob))) return e;
+  if (grand > 0x7fffffffll) return rhccq_fail(ctx, RHCCQ_E_LIMIT, "mbk_order: too many samples");
+  if (tmp_bytes < rhccq_mbk_order_bytes(grand)) return rhccq_fail(ctx, RHCCQ_E_ARG, "mbk_order: tmp too small");
+  constexpr int kChunk = 256;                              // 8 bits of the sort key name the problem
+  if (int e = ensure_scratch(ctx, align256(sizeof(MbkP) * kChunk))) return e;
   MbkP* dp = (MbkP*)ctx->scratch;
-  if (int e = put(ctx, dp, hp, sizeof(MbkP) * n_prob)) return e;
-  RHCCQ_HIP(ctx, hipStreamSynchronize(ctx->stream));      // `stage` is pageable host memory
-  unsigned long long* a = (unsigned long long*)tmp;
-  unsigned long long* b = a + total;
-  void* cub_tmp = (void*)(b + total);
-  size_t cub_avail = (size_t)tmp_bytes - 16 * (size_t)total, cub_need = 0;
-  hipcub::DoubleBuffer<unsigned long long> buf(a, b);
-  int top = 56;
-  while ((1 << (top - 56)) < n_prob) ++top;
-  RHCCQ_HIP(ctx, hipcub::DeviceRadixSort::SortKeys(nullptr, cub_need, buf, (int)total, 0, top, ctx->stream));
-  if (cub_need > cub_avail) return rhccq_fail(ctx, RHCCQ_E_LIMIT, "mbk_order: sort scratch exceeds tmp");
-  const unsigned grid = (unsigned)((total + 255) / 256);
-  hipLaunchKernelGGL(sample_sortkey_kernel, dim3(grid), dim3(256), 0, ctx->stream, keys, dp, n_prob, init_idx, a, total);
-  RHCCQ_HIP(ctx, hipcub::DeviceRadixSort::SortKeys(cub_tmp, cub_need, buf, (int)total, 0, top, ctx->stream));
-  hipLaunchKernelGGL(sample_unpack_kernel, dim3(grid), dim3(256), 0, ctx->stream, buf.Current(), init_idx, total);
-  RHCCQ_LAUNCH_CHECK(ctx);
+  std::string stage;
+  stage.resize(sizeof(MbkP) * (size_t)kChunk);
+  MbkP* hp = (MbkP*)stage.data();
+  for (int c0 = 0; c0 < n_prob; c0 += kChunk) {
+    const int nc = n_prob - c0 < kChunk ? n_prob - c0 : kChunk;
+    long long total = 0;
+    for (int i = 0; i < nc; ++i) {
+      const rhccq_mbk_problem& q = probs[c0 + i];
+      hp[i] = MbkP{q.off, q.n, q.k, q.koff, q.init_off, q.init_n, q.rand_off, q.first, q.T};
+      total += q.init_n;
+    }
+    const long long base = probs[c0].init_off;
+    // the previous chunk's kernels may still read the table: the copy is stream ordered behind them
+    if (int e = put(ctx, dp, hp, sizeof(MbkP) * nc)) return e;
+    RHCCQ_HIP(ctx, hipStreamSynchronize(ctx->stream));      // `stage` is pageable host memory
+    unsigned long long* a = (unsigned long long*)tmp;
+    unsigned long long* b = a + total;
+    void* cub_tmp = (void*)(b + total);
+    size_t cub_avail = (size_t)tmp_bytes - 16 * (size_t)total, cub_need = 0;
+    hipcub::DoubleBuffer<unsigned long long> buf(a, b);
+    int top = 56;
+    while ((1 << (top - 56)) < nc) ++top;
+    RHCCQ_HIP(ctx, hipcub::DeviceRadixSort::SortKeys(nullptr, cub_need, buf, (int)total, 0, top, ctx->stream));
+    if (cub_need > cub_avail) return rhccq_fail(ctx, RHCCQ_E_LIMIT, "mbk_order: sort scratch exceeds tmp");
+    const unsigned grid = (unsigned)((total + 255) / 256);
+    hipLaunchKernelGGL(sample_sortkey_kernel, dim3(grid), dim3(256), 0, ctx->stream, keys, dp, nc, init_idx, a, base, total);
+    RHCCQ_HIP(ctx, hipcub::DeviceRadixSort::SortKeys(cub_tmp, cub_need, buf, (int)total, 0, top, ctx->stream));
+    hipLaunchKernelGGL(sample_unpack_kernel, dim3(grid), dim3(256), 0, ctx->stream, buf.Current(), perm, base, total);
+    RHCCQ_LAUNCH_CHECK(ctx);
+  }
   return 0;
 }
 
@@ -1504,8 +1696,8 @@ int rhccq_mt_uniforms(rhccq_ctx* ctx, const uint32_t* words, int64_t pos, int64_
 }
 
 int rhccq_mbk_init(rhccq_ctx* ctx, const uint32_t* keys, const rhccq_mbk_problem* probs, int32_t n_prob, const int32_t* init_idx,
-                   const double* rand, double* centres, int32_t* chosen) {
-  if (!ctx || !keys || !probs || !init_idx || !rand || !centres || !chosen || n_prob <= 0)
+                   const int32_t* perm, const double* rand, double* centres, int32_t* chosen) {
+  if (!ctx || !keys || !probs || !init_idx || !perm || !rand || !centres || !chosen || n_prob <= 0)
     return rhccq_fail(ctx, RHCCQ_E_ARG, "mbk_init: bad argument");
   // scratch: [MbkP table][scratch_off table][per problem sample arrays]
   std::string stage;
@@ -1521,7 +1713,7 @@ int rhccq_mbk_init(rhccq_ctx* ctx, const uint32_t* keys, const rhccq_mbk_problem
     hp[i] = MbkP{q.off, q.n, q.k, q.koff, q.init_off, q.init_n, q.rand_off, q.first, q.T};
     ho[i] = (long long)words;
     const size_t nb = (size_t)((q.init_n + 63) / 64);
-    words += 2 * nb * 64 + 5 * nb + 5 * ((nb + 15) / 16) + 8;
+    words += 5 * nb * 64 + 5 * nb + 5 * ((nb + 15) / 16) + 8;       // samp, dsamp (uint2 each), mperm, tables
     words = (words + 63) & ~(size_t)63;
   }
   const size_t head = align256(sizeof(MbkP) * n_prob) + align256(8 * (size_t)n_prob);
@@ -1535,16 +1727,16 @@ int rhccq_mbk_init(rhccq_ctx* ctx, const uint32_t* keys, const rhccq_mbk_problem
   RHCCQ_HIP(ctx, hipStreamSynchronize(ctx->stream));
   const int lds_blocks = ctx->opt_init_lds_blocks < 0 ? kInitLdsBlocks : ctx->opt_init_lds_blocks;
   const int max_items = ctx->opt_init_max_items < 0 ? kMaxItems : ctx->opt_init_max_items;
-  hipLaunchKernelGGL(mbk_init_kernel, dim3(n_prob), dim3(kInitThreads), 0, ctx->stream, keys, dp, init_idx, rand, centres, chosen, dscr, dof,
+  hipLaunchKernelGGL(mbk_init_kernel, dim3(n_prob), dim3(kInitThreads), 0, ctx->stream, keys, dp, init_idx, perm, rand, centres, chosen, dscr, dof,
                      lds_blocks, max_items);
   RHCCQ_LAUNCH_CHECK(ctx);
   return 0;
 }
 
-int rhccq_mbk_steps(rhccq_ctx* ctx, const uint32_t* keys, const rhccq_mbk_problem* probs, int32_t n_prob, int64_t step0,
-                    int32_t n_steps, uint64_t seed, double* centres, double* weights, double* state, void* work, int64_t work_bytes,
-                    int32_t estep_mode, int32_t estep_split) {
-  if (!ctx || !keys || !probs || !centres || !weights || !state || !work || n_prob <= 0 || n_steps < 0 || step0 < 0)
+int rhccq_mbk_steps(rhccq_ctx* ctx, const uint32_t* keys, const rhccq_mbk_problem* probs, int32_t n_prob, int32_t n_steps,
+                    const uint32_t* words, int64_t n_words, double* centres, double* weights, double* state, void* work,
+                    int64_t work_bytes, int32_t estep_mode, int32_t estep_split) {
+  if (!ctx || !keys || !probs || !words || !centres || !weights || !state || !work || n_prob <= 0 || n_steps < 0 || n_words <= 0)
     return rhccq_fail(ctx, RHCCQ_E_ARG, "mbk_steps: bad argument");
   WorkView v;
   long long blocks;
@@ -1559,17 +1751,19 @@ int rhccq_mbk_steps(rhccq_ctx* ctx, const uint32_t* keys, const rhccq_mbk_proble
   if (estep_split != 0 && estep_split != 1 && estep_split != 2 && estep_split != 4 && estep_split != 8)
     return rhccq_fail(ctx, RHCCQ_E_ARG, "mbk_steps: estep_split must be 0, 1, 2, 4 or 8");
   const bool use_grid = estep_mode == RHCCQ_ESTEP_GRID || (estep_mode == RHCCQ_ESTEP_AUTO && ksum >= 200000);
+  // problems whose first batch has not been drawn yet (state[10] == 0) draw it now; the others return at once
+  hipLaunchKernelGGL(mbk_draw0_kernel, dim3(n_prob), dim3(kUpdThreads), 0, ctx->stream, keys, v.probs, state, words, (long long)n_words,
+                     v.bkeys);
   for (int s = 0; s < n_steps; ++s) {
-    const long long step = step0 + s;
     if (use_grid) {
       hipLaunchKernelGGL(grid_build_kernel, dim3(n_prob), dim3(1024), 0, ctx->stream, v.probs, centres, v.cell_start, v.order,
                          (const double*)state);
-      hipLaunchKernelGGL(mbk_batch_estep_grid_kernel, dim3(250, n_prob), dim3(256), 0, ctx->stream, keys, v.probs, centres, state, step,
-                         (unsigned long long)seed, v.cell_start, v.order, v.pdist, v.pidx, v.part_off);
+      hipLaunchKernelGGL(mbk_batch_estep_grid_kernel, dim3(250, n_prob), dim3(256), 0, ctx->stream, keys, v.probs, centres, state,
+                         (const uint32_t*)v.bkeys, v.cell_start, v.order, v.pdist, v.pidx, v.part_off);
     } else {
 #define RHCCQ_ESTEP_LAUNCH(SS)                                                                                                             \
   hipLaunchKernelGGL(mbk_batch_estep_kernel<SS>, dim3(max_tiles * kPtChunks * SS, n_prob), dim3(256), 0, ctx->stream, keys, v.probs, centres, \
-                     state, step, (unsigned long long)seed, v.pdist, v.pidx, v.part_off)
+                     state, (const uint32_t*)v.bkeys, v.pdist, v.pidx, v.part_off)
       switch (estep_split) {
         case 8: RHCCQ_ESTEP_LAUNCH(8); break;
         case 4: RHCCQ_ESTEP_LAUNCH(4); break;
@@ -1580,8 +1774,8 @@ int rhccq_mbk_steps(rhccq_ctx* ctx, const uint32_t* keys, const rhccq_mbk_proble
       hipLaunchKernelGGL(mbk_fold_tiles_kernel, dim3((1000 + 15) / 16, n_prob), dim3(64), 0, ctx->stream, v.probs, (const double*)state, v.pdist, v.pidx,
                          v.part_off);
     }
-    hipLaunchKernelGGL(mbk_update_kernel, dim3(n_prob), dim3(kUpdThreads), 0, ctx->stream, keys, v.probs, centres, weights, state, step,
-                       (unsigned long long)seed, v.pdist, v.pidx, v.part_off);
+    hipLaunchKernelGGL(mbk_update_kernel, dim3(n_prob), dim3(kUpdThreads), 0, ctx->stream, keys, v.probs, centres, weights, state, words,
+                       (long long)n_words, v.bkeys, v.pdist, v.pidx, v.part_off);
   }
   RHCCQ_LAUNCH_CHECK(ctx);
   return 0;

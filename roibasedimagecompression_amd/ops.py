@@ -152,9 +152,10 @@ class Rhccq:
         self._check(self.lib.rhccq_ctx_set_int(self.ctx, int(option), int(value)), "ctx_set_int")
 
     def _mt_words_dev(self, n):
-        """the first n raw MT19937 words on the device (uploaded once, regrown geometrically)"""
+        """at least the first n raw MT19937 words on the device (uploaded once, regrown geometrically)"""
         if self._mtw_dev is None or self._mtw_dev.numel() < n:
-            w = self.mtw.ensure(max(n, 1 << 22))
+            have = 0 if self._mtw_dev is None else self._mtw_dev.numel()
+            w = self.mtw.ensure(max(n, 2 * have, 1 << 22))
             self._mtw_dev = torch.from_numpy(w.view(np.int32)).to(self.device)
         return self._mtw_dev
 
@@ -355,8 +356,10 @@ class Rhccq:
 
     # -- K8 -----------------------------------------------------------------------------------------
     def minibatch_kmeans(self, key_list, k_list, return_info=False, poll_steps=64, return_device=False, timing=None, estep="auto", estep_split=0):
-        """Batched MiniBatchKMeans(k, batch_size=1000, random_state=42).fit_predict labels in the
-        canonical arithmetic of oracle.minibatch_kmeans_labels.  key_list items are numpy arrays or
+        """Batched MiniBatchKMeans(k, batch_size=1000, random_state=42).fit_predict labels: sklearn's fit operation
+        for operation (RandomState(42) replayed from its raw MT19937 words, k-means++ in draw order, batch-ordered
+        centre updates; the one canonical choice is the stable tie order of the reassignment argsort -- see
+        oracle.minibatch_kmeans_labels).  key_list items are numpy arrays or
         device int32 tensors (kept resident); labels come back as numpy arrays, or as device tensors
         with return_device=True.  `timing` (a dict) receives the HIP-event duration of the k-means++ launch
         (events on the launch stream).  `estep`: "auto" | "tiles" | "grid" -- how the batch E-step searches the
@@ -372,7 +375,6 @@ class Rhccq:
         keys = parts[0] if n_prob == 1 else torch.cat(parts)
         init_list = []
         ioff = roff = 0
-        max_steps = 0
         # numpy's RandomState(42) stream of every problem, replayed from the cached raw MT19937 words (mt.py): the
         # sample indices on the host (vectorised rejection sampling), the k-means++ uniforms on the device
         mtw = self.mtw
@@ -399,10 +401,12 @@ class Rhccq:
         todo = list(zip(sizes, k_list))
         # the numpy passes of a replay release the GIL: the problems' draws run side by side (the GPU waits for them)
         drawn = list(_draw_pool().map(draw, todo)) if n_prob > 1 else [draw(todo[0])]
+        cursor0 = []
         for i, ((n, k), (init_idx, first, pos)) in enumerate(zip(todo, drawn)):
             init_size = len(init_idx)
             T = 2 + int(math.log(k))
             nu = max((k - 1) * T, 1)
+            cursor0.append(pos + 2 * (k - 1) * T)             # stream position behind the k-means++ uniforms
             p = probs[i]
             p.off, p.n, p.k, p.koff = int(offs[i]), n, k, int(koff[i])
             p.init_off, p.init_n, p.rand_off, p.first, p.T = ioff, init_size, roff, first, T
@@ -410,24 +414,25 @@ class Rhccq:
             upos.append((pos, nu, roff))
             ioff += init_size
             roff += nu
-            max_steps = max(max_steps, (100 * n) // min(1000, n))
         words = self._mt_words_dev(max(pos + 2 * nu for pos, nu, _ in upos))
         d_rand = self.empty((roff,), torch.float64)
         for pos, nu, ro in upos:
             self._check(self.lib.rhccq_mt_uniforms(self.ctx, self._p(words), pos, nu, C.c_void_p(d_rand.data_ptr() + 8 * ro)), "mt_uniforms")
-        d_init = self.dev(np.concatenate(init_list))
-        # canonical sample order (Morton code of the colour, index), on the device: 64 consecutive samples
-        # form a compact box, which is what the exact block pruning of mbk_init_kernel relies on
+        d_init = self.dev(np.concatenate(init_list))           # sklearn's draw order
+        # internal pruning index: the sample positions in Morton order of their colours, on the device: 64 consecutive
+        # entries form a compact box, which is what the exact block pruning of mbk_init_kernel relies on
         obytes = int(self.lib.rhccq_mbk_order_bytes(ioff))
         otmp = self.empty((obytes,), torch.uint8)
-        self._check(self.lib.rhccq_mbk_order(self.ctx, self._p(keys), probs, n_prob, self._p(d_init), self._p(otmp), obytes), "mbk_order")
+        d_perm = self.empty((ioff,), torch.int32)
+        self._check(self.lib.rhccq_mbk_order(self.ctx, self._p(keys), probs, n_prob, self._p(d_init), self._p(d_perm), self._p(otmp), obytes),
+                    "mbk_order")
         K = int(koff[-1])
         centres = self.zeros((K, 4), torch.float64)
         chosen = self.zeros((K,), torch.int32)
         if timing is not None:
             ev = (torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True))
             ev[0].record()
-        self._check(self.lib.rhccq_mbk_init(self.ctx, self._p(keys), probs, n_prob, self._p(d_init), self._p(d_rand),
+        self._check(self.lib.rhccq_mbk_init(self.ctx, self._p(keys), probs, n_prob, self._p(d_init), self._p(d_perm), self._p(d_rand),
                                             self._p(centres), self._p(chosen)), "mbk_init")
         if timing is not None:
             ev[1].record()
@@ -436,28 +441,36 @@ class Rhccq:
         weights = self.zeros((K,), torch.float64)
         st0 = np.zeros((n_prob, 16))
         st0[:, 8] = k_list                                   # every centre starts with zero weight
+        st0[:, 9] = cursor0                                  # MT19937 words consumed so far
         state = self.dev(st0)
+        cur_max = max(cursor0)
+        WORDS_PER_STEP = 16384                               # kWordsMargin of mbk_update_kernel
         wbytes = int(self.lib.rhccq_mbk_work_bytes(probs, n_prob))
         work = self.empty((max(wbytes, 8),), torch.uint8)
-        step = 0
         k_arr = np.asarray(k_list, np.int64)
         limit = np.array([(100 * n) // min(1000, n) for n in sizes], np.int64)
         running = np.ones(n_prob, bool)
-        while step < max_steps:
-            ns = min(poll_steps, max_steps - step)
+        steps_done = np.zeros(n_prob, np.int64)
+        while running.any():                                 # every problem counts its own steps (state[:, 5])
+            ns = int(min(poll_steps, max(1, (limit - steps_done)[running].max())))
             # the grid E-step pays when many centres are in flight; once only stragglers are left the tiled
             # brute force has fewer and shorter launches per step
             mode = {"tiles": 1, "grid": 2}.get(estep) or (2 if int(k_arr[running].sum()) >= 200000 else 1)
             # few workgroups left (a straggler problem): several threads share a batch point in the tiled E-step
             wgs = int(((k_arr[running] + 511) // 512).sum()) * 4
             split = estep_split or next((sp for sp in (1, 2, 4, 8) if wgs * sp >= 1536), 8)
-            self._check(self.lib.rhccq_mbk_steps(self.ctx, self._p(keys), probs, n_prob, step, ns, SEED, self._p(centres),
-                                                 self._p(weights), self._p(state), self._p(work), wbytes, mode, split), "mbk_steps")
-            step += ns
+            words = self._mt_words_dev(cur_max + (ns + 2) * WORDS_PER_STEP)
+            self._check(self.lib.rhccq_mbk_steps(self.ctx, self._p(keys), probs, n_prob, ns, self._p(words), words.numel(),
+                                                 self._p(centres), self._p(weights), self._p(state), self._p(work), wbytes, mode, split),
+                        "mbk_steps")
             st = state.cpu().numpy()
+            cur_max = int(st[:, 9].max())
+            steps_done = st[:, 5].astype(np.int64)
+            starved = st[:, 4] == 3                          # ran into the end of the word table: extended above, resumes
+            if starved.any():
+                state[:, 4] = torch.where(state[:, 4] == 3, torch.zeros_like(state[:, 4]), state[:, 4])
+                st[starved, 4] = 0
             running = (st[:, 4] == 0) & (st[:, 5] < limit)
-            if not running.any():
-                break
         labels = self.empty((int(offs[-1]),), torch.int32)
         self._check(self.lib.rhccq_mbk_assign(self.ctx, self._p(keys), probs, n_prob, self._p(centres), self._p(work), wbytes,
                                               self._p(labels)), "mbk_assign")

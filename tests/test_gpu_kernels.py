@@ -123,7 +123,9 @@ def test_minibatch_vs_oracle_bit_exact(rh, O, estep):
     pal = pal[~np.all(pal == 0, axis=1)]
     rng = np.random.default_rng(2)
     P2 = np.unique(rng.integers(0, 256, (30000, 3)).astype(np.uint8), axis=0)
-    cases = [(pal, int(np.ceil(len(pal) * 0.2 / 10))), (pal, int(np.ceil(len(pal) * 0.1 / 10))), (P2, 450)]
+    P3 = np.unique(rng.integers(0, 48, (14000, 3)).astype(np.uint8), axis=0)
+    # k = 40: ~25 batch rows per centre -> the update walks the batch instead of the per-centre member lists
+    cases = [(pal, int(np.ceil(len(pal) * 0.2 / 10))), (pal, int(np.ceil(len(pal) * 0.1 / 10))), (P2, 450), (P3, 40)]
     labs, info = rh.minibatch_kmeans([O.pack_rgb(P) for P, _ in cases], [k for _, k in cases], return_info=True, estep=estep.split("/")[0],
                                       estep_split=int(estep.split("/")[1]) if "/" in estep else 1)
     for i, ((P, k), l) in enumerate(zip(cases, labs)):
@@ -185,7 +187,7 @@ def test_dct_quant_extension(rh, O, block):
 @pytest.mark.parametrize("path", ["default", "global_tables", "tiny_work_list"])
 def test_minibatch_init_chain_many_cases(rh, O, path):
     """The k-means++ chain of mbk_init_kernel (work list, lazy super-block maxima, hierarchical search) against
-    the oracle's exact-integer k-means++ on the same Morton-ordered sample, for several shapes -- every pick
+    the oracle's exact-integer k-means++ on the same init sample in sklearn's draw order, for several shapes -- every pick
     must be identical (this is the kernel where a reduction race once hid behind lucky timing).
     `global_tables` / `tiny_work_list` lower the thresholds (rhccq_ctx_set_int) so that the paths of very large
     problems -- block tables in global memory beyond 262 144 samples, per-candidate evaluation when the shared
@@ -217,8 +219,7 @@ def _init_chain_cases(rh, O):
         init_size = 3000 if 3000 >= k else 3 * k          # sklearn: 3 * batch_size, or 3 * k when that is < k
         init_size = min(init_size, n)
         rs.randint(0, n, init_size)
-        ii = rs.randint(0, n, init_size) if init_size < n else np.arange(n)
-        ii = ii[np.lexsort((ii, O.morton3(O.pack_rgb(P[ii]))))]
+        ii = rs.randint(0, n, init_size) if init_size < n else np.arange(n)     # sklearn's draw order
         want = O.kmeanspp_int(P[ii].astype(np.int64), k, rs)
         got = info["chosen"][info["koff"][i]:info["koff"][i + 1]]
         assert np.array_equal(got, want), (i, n, k, int(np.argmax(got != want)))
