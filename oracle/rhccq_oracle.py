@@ -57,10 +57,10 @@ import numpy as np
 __all__ = [
     "pack_rgb", "unpack_rgb", "unique_colors", "clustering_params", "eps_threshold",
     "eps_components", "kmeanspp_int", "kmeans_labels", "split_large_cluster",
-    "minibatch_kmeans_labels", "cluster_palette", "merge_components", "segment_crop",
+    "minibatch_kmeans_labels", "minibatch_kmeans_native", "kmeanspp_picks_native", "cluster_palette", "merge_components", "segment_crop",
     "level1_region", "region_quantization", "quantize_image", "optimal_index_dtype",
     "encode_frame", "pack_container", "container_bytes", "load_container", "decode_container",
-    "dct_quant_blocks", "counter_hash", "morton3",
+    "dct_quant_blocks",
 ]
 
 MINIBATCH_THRESHOLD = 10000  # clustering.py:205
@@ -69,8 +69,8 @@ _KM64 = None
 
 
 def _km64_lib():
-    """oracle/km64_estep.c built in place with gcc (the E-step needs a correctly rounded fma, which numpy
-    does not expose)."""
+    """oracle/km64_estep.c + oracle/mbk_oracle.c built in place with gcc (the E-step needs a correctly rounded fma,
+    which numpy does not expose; the native MiniBatchKMeans restatement serves the cases numpy is too slow for)."""
     global _KM64
     if _KM64 is not None:
         return _KM64
@@ -78,16 +78,62 @@ def _km64_lib():
     import os
     import subprocess
     here = os.path.dirname(os.path.abspath(__file__))
-    src = os.path.join(here, "km64_estep.c")
+    srcs = [os.path.join(here, "km64_estep.c"), os.path.join(here, "mbk_oracle.c")]
     out = os.path.join(here, "_build", "libkm64.so")
-    if not os.path.exists(out) or os.path.getmtime(out) < os.path.getmtime(src):
+    if not os.path.exists(out) or os.path.getmtime(out) < max(os.path.getmtime(f) for f in srcs):
         os.makedirs(os.path.dirname(out), exist_ok=True)
-        subprocess.check_call(["gcc", "-O2", "-ffp-contract=off", "-shared", "-fPIC", "-o", out, src, "-lm"])
+        subprocess.check_call(["gcc", "-O3", "-mavx2", "-mfma", "-ffp-contract=off", "-fopenmp", "-shared", "-fPIC", "-o", out] + srcs + ["-lm"])
     lib = ctypes.CDLL(out)
     lib.km64_estep.argtypes = [ctypes.c_void_p, ctypes.c_int64, ctypes.c_void_p, ctypes.c_int64, ctypes.c_void_p, ctypes.c_void_p]
     lib.km64_estep.restype = None
+    lib.mbk_fit.argtypes = [ctypes.c_void_p, ctypes.c_int64, ctypes.c_int32, ctypes.c_uint32, ctypes.c_int64, ctypes.c_int32,
+                            ctypes.c_void_p, ctypes.c_void_p, ctypes.c_void_p, ctypes.c_void_p, ctypes.c_void_p]
+    lib.mbk_fit.restype = ctypes.c_int
+    lib.mbk_init_picks.argtypes = [ctypes.c_void_p, ctypes.c_int64, ctypes.c_int32, ctypes.c_uint32, ctypes.c_int32, ctypes.c_void_p,
+                                   ctypes.c_void_p]
+    lib.mbk_init_picks.restype = ctypes.c_int
     _KM64 = lib
     return lib
+
+
+def _mbk_init_size(n, k, batch_size=1000):
+    bs = min(batch_size, n)
+    init_size = 3 * bs
+    if init_size < k:
+        init_size = 3 * k
+    return min(init_size, n)
+
+
+def minibatch_kmeans_native(points, k, seed=42, max_steps=None, threads=0, want_labels=True):
+    """oracle/mbk_oracle.c: the same restatement as minibatch_kmeans_labels() in C (OpenMP over `threads` host cores,
+    0 = all).  Returns (labels int32[n] or None, info) with info keys n_steps, centers, picks, init_indices, mt_words."""
+    P = np.ascontiguousarray(np.asarray(points).reshape(-1, 3).astype(np.uint8))
+    n = len(P)
+    isz = _mbk_init_size(n, k)
+    C = np.empty((k, 3), np.float64)
+    lab = np.empty(n, np.int32) if want_labels else None
+    picks = np.empty(k, np.int32)
+    init_idx = np.empty(isz, np.int64)
+    info = np.zeros(8, np.int64)
+    rc = _km64_lib().mbk_fit(P.ctypes.data, n, int(k), int(seed), -1 if max_steps is None else int(max_steps), int(threads),
+                             C.ctypes.data, lab.ctypes.data if want_labels else None, picks.ctypes.data, init_idx.ctypes.data,
+                             info.ctypes.data)
+    if rc:
+        raise ValueError("mbk_fit: bad arguments")
+    return lab, {"n_steps": int(info[0]), "centers": C, "picks": picks.astype(np.int64), "init_indices": init_idx,
+                 "mt_words": int(info[2]), "n_reassigned": int(info[3])}
+
+
+def kmeanspp_picks_native(points, k, seed=42, threads=0):
+    """k-means++ picks of the MiniBatchKMeans init alone (positions in the init sample, draw order) + the sample rows."""
+    P = np.ascontiguousarray(np.asarray(points).reshape(-1, 3).astype(np.uint8))
+    n = len(P)
+    picks = np.empty(k, np.int32)
+    init_idx = np.empty(_mbk_init_size(n, k), np.int64)
+    rc = _km64_lib().mbk_init_picks(P.ctypes.data, n, int(k), int(seed), int(threads), picks.ctypes.data, init_idx.ctypes.data)
+    if rc:
+        raise ValueError("mbk_init_picks: bad arguments")
+    return picks.astype(np.int64), init_idx
 
 
 def km64_estep(X, C, want_dist=False):
@@ -349,52 +395,8 @@ def split_large_cluster(colors, mc, kmeans=kmeans_labels):
 
 # --------------------------------------------------------------------------------------
 # K8: MiniBatchKMeans(k, batch_size=1000, random_state=42, n_init='auto')
-# (clustering.py:207-230)  --  Tier B
+# (clustering.py:207-230)
 # --------------------------------------------------------------------------------------
-_M64 = (1 << 64) - 1
-
-
-def counter_hash(seed, stream, counter):
-    """splitmix64-style counter hash shared with csrc/ (vectorised over `counter`)."""
-    counter = np.asarray(counter, dtype=np.uint64)
-    with np.errstate(over="ignore"):
-        z = (np.uint64((seed * 0x9E3779B97F4A7C15) & _M64) + np.uint64((stream * 0xD1B54A32D192ED03) & _M64)
-             + counter * np.uint64(0x2545F4914F6CDD1D))
-        z = (z ^ (z >> np.uint64(30))) * np.uint64(0xBF58476D1CE4E5B9)
-        z = (z ^ (z >> np.uint64(27))) * np.uint64(0x94D049BB133111EB)
-        z = z ^ (z >> np.uint64(31))
-    return z
-
-
-def morton3(keys):
-    """24-bit Z-order code of packed colours: bit i of R, G, B -> bits 3i+2, 3i+1, 3i."""
-    def spread(v):
-        v = v.astype(np.uint32) & np.uint32(0xFF)
-        v = (v | (v << np.uint32(16))) & np.uint32(0xFF0000FF)
-        v = (v | (v << np.uint32(8))) & np.uint32(0x0F00F00F)
-        v = (v | (v << np.uint32(4))) & np.uint32(0xC30C30C3)
-        v = (v | (v << np.uint32(2))) & np.uint32(0x49249249)
-        return v
-    keys = np.asarray(keys, dtype=np.uint32)
-    return (spread(keys >> np.uint32(16)) << np.uint32(2)) | (spread(keys >> np.uint32(8)) << np.uint32(1)) | spread(keys)
-
-
-def _bounded(z, n):
-    """(high 32 bits of z * n) >> 32  -> [0, n)."""
-    return ((z >> np.uint64(32)) * np.uint64(n)) >> np.uint64(32)
-
-
-def tree_sum_1024(v):
-    """sum of <= 1024 float64 values by the fixed tree v[i] += v[i+s], s = 512,256,...,1."""
-    buf = np.zeros(1024, np.float64)
-    buf[:len(v)] = v
-    s = 512
-    while s >= 1:
-        buf[:s] = buf[:s] + buf[s:2 * s]
-        s //= 2
-    return buf[0]
-
-
 def _mb_dist(Xb, C):
     """MiniBatch E-step distance on RAW coordinates (sklearn does not centre here)."""
     return _km64_dist(Xb, C)

@@ -137,6 +137,23 @@ def test_minibatch_vs_oracle_bit_exact(rh, O, estep):
         assert np.array_equal(l, ol), (l == ol).mean()
 
 
+def test_minibatch_equals_sklearn_golden(rh, O):
+    """HIP MiniBatchKMeans against scikit-learn ITSELF (tests/golden/g11_mbk_sklearn.*: sklearn 1.7.2 fits with the one
+    np.argsort of _mini_batch_step forced stable, generated by make_golden_mbk.py): k-means++ picks, step count, centres
+    bit for bit and labels (hash) on 8 inputs up to 790 421 colours / k = 15 809 -- whole Lenna and whole Kodak frames as
+    one segment, the bench generator's 1 Mpx photo.  No oracle in between.  For the 4 cases with k < 500 this is the
+    reference's untouched result."""
+    from test_oracle_golden import check_against_g11, g11_cases, g11_palette
+    cases = g11_cases()
+    g = load("g11_mbk_sklearn.npz")
+    names = list(cases)
+    pals = [g11_palette(n, cases[n]) for n in names]
+    labs, info = rh.minibatch_kmeans([O.pack_rgb(P) for P in pals], [cases[n]["k"] for n in names], return_info=True)
+    for i, n in enumerate(names):
+        a, b = info["koff"][i], info["koff"][i + 1]
+        check_against_g11(n, cases[n], g, info["chosen"][a:b], info["state"][i][5], info["centres"][a:b, :3], labs[i])
+
+
 def test_merge_kernels_and_remap_decode(rh, O):
     import torch
     g = load("g5_merge.npz")

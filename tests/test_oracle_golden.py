@@ -2,6 +2,7 @@
 (tests/golden/make_golden.py).  CPU only."""
 import json
 import os
+import sys
 
 import numpy as np
 import pytest
@@ -116,19 +117,79 @@ def test_g4_cluster_palette():
     assert tiers["A"] + tiers["A'"] >= 18
 
 
-def test_g10_minibatch_tier_b():
+def test_g10_minibatch_reference_function_bit_exact():
+    """cluster_palette_colors_parallel itself (the reference's function, MiniBatchKMeans branch, clustering.py:207-230) on a
+    192x192 Lenna crop at q = 10 / 20 (k = 330 / 659): with the sklearn-faithful restatement the palette and every index are
+    identical (Tier A) -- round 1 could only claim palette size +-2 % / PSNR +-0.5 dB here."""
     g = load("g10_minibatch.npz")
     img = g["img"]
     pal, idx = O.unique_colors(img)
     for q in (10, 20):
         eps, _, mc = O.clustering_params(len(pal), q)
         npal, nidx = O.cluster_palette(q, pal, idx, eps, mc)
-        gp, gi = g[f"pal_q{q}"], g[f"idx_q{q}"]
-        assert abs(len(npal) - len(gp)) <= max(2, 0.02 * len(gp)), (len(npal), len(gp))
-        ref = psnr(gp[gi], img.reshape(-1, 3))
-        mine = psnr(npal[nidx], img.reshape(-1, 3))
-        print(q, len(npal), len(gp), ref, mine)
-        assert abs(ref - mine) < 0.5
+        assert np.array_equal(npal, g[f"pal_q{q}"])
+        assert np.array_equal(nidx, g[f"idx_q{q}"])
+
+
+def g11_cases():
+    import json
+    return json.load(open(os.path.join(G, "g11_mbk_sklearn.json")))["cases"]
+
+
+def g11_palette(name, case):
+    """the colours the reference hands to MiniBatchKMeans for this case: sorted unique colours of the image, black set aside"""
+    import hashlib
+    from PIL import Image
+    if name.startswith("synth_photo"):
+        sys.path.insert(0, os.path.join(os.path.dirname(__file__), ".."))
+        from roibasedimagecompression_amd import synth               # pure numpy generator
+        img = {"synth_photo_1024_q20": lambda: synth.photo(1024, 1024, 1234),
+               "synth_photo_640_q40": lambda: synth.photo(640, 640, 1235, sigma=3.0)}[name]()
+    else:
+        f = {"lenna": "Lenna.png", "kodak1_": "kodak_1.png", "kodak13": "kodak_13.png", "kodak23": "kodak_23.png"}
+        fn = next(v for k, v in f.items() if name.startswith(k))
+        img = np.asarray(Image.open(os.path.join(G, fn)).convert("RGB"), dtype=np.uint8)
+        if name.startswith("lenna192"):
+            img = img[128:320, 128:320]
+    assert hashlib.sha256(np.ascontiguousarray(img).tobytes()).hexdigest() == case["img_sha256"], name
+    u = np.unique(img.reshape(-1, 3), axis=0)
+    u = u[~np.all(u == 0, axis=1)]
+    assert len(u) == case["n"]
+    return u
+
+
+def check_against_g11(name, case, g, picks, n_steps, centres, labels):
+    """Tier A against scikit-learn itself (stable-argsort fit, tests/golden/make_golden_mbk.py): k-means++ picks, step
+    count, centres bit for bit, labels by hash"""
+    import hashlib
+    assert np.array_equal(np.asarray(picks, np.int64), g[f"{name}_picks"].astype(np.int64)), (name, "k-means++ picks")
+    assert int(n_steps) == case["stable"]["n_steps"], (name, n_steps, case["stable"]["n_steps"])
+    assert np.array_equal(np.asarray(centres, np.float64), g[f"{name}_centres"]), (name, "centres")
+    lab = np.ascontiguousarray(np.asarray(labels, np.int32))
+    assert np.array_equal(np.bincount(lab, minlength=case["k"]), g[f"{name}_sizes"]), (name, "cluster sizes")
+    assert hashlib.sha256(lab.tobytes()).hexdigest() == case["stable"]["labels_sha256"], (name, "labels")
+
+
+@pytest.mark.parametrize("name", ["lenna192_q20", "lenna192_q10", "lenna_full_q20", "kodak1_q20", "kodak13_q10", "kodak23_q20",
+                                  "synth_photo_1024_q20", "synth_photo_640_q40"])
+def test_g11_minibatch_equals_sklearn(name):
+    """The MiniBatchKMeans restatement against scikit-learn's own fit on 8 inputs up to 790 421 colours / k = 15 809 (whole
+    Lenna and whole Kodak frames as ONE segment, the bench generator's 1 Mpx photo).  Native C restatement on all of them;
+    the numpy restatement on the small ones (it needs minutes beyond k ~ 3 000) -- both must equal sklearn bit for bit.
+    Where no cap is hit (k < 500: 4 cases) sklearn's untouched fit equals the stable-argsort one, i.e. the reference's
+    result itself is reproduced; beyond, the untouched fit differs only through np.argsort's tie order
+    (`default.equals_stable` in g11_mbk_sklearn.json)."""
+    cases = g11_cases()
+    case = cases[name]
+    g = load("g11_mbk_sklearn.npz")
+    P = g11_palette(name, case)
+    lab, info = O.minibatch_kmeans_native(P, case["k"])
+    check_against_g11(name, case, g, info["picks"], info["n_steps"], info["centers"], lab)
+    if case["k"] <= 700:
+        lab2, info2 = O.minibatch_kmeans_labels(P, case["k"], return_info=True)
+        check_against_g11(name, case, g, info2["picks"], info2["n_steps"], info2["centers"], lab2)
+    if case["k"] < 500:
+        assert case["default"]["equals_stable"], "below the cap the reference's own fit is the stable one"
 
 
 def comps_from(g, name):
