@@ -1,19 +1,35 @@
 """decoder/uncompression/comparison.py of the reference: `calculate_quality_metrics` runs on the MI355X
-(roibasedimagecompression_amd/api/comparison.py); the OpenCV / matplotlib helpers of that module are placeholders
--- a deployment keeps the reference's own functions for them."""
+(roibasedimagecompression_amd/api/comparison.py).  The OpenCV / matplotlib helpers of that module come from the reference's own
+file when its checkout sits behind this repository on sys.path (they are looked up there lazily); otherwise they are
+placeholders that raise."""
+import importlib.util
+import os
+import sys
+
+from roibasedimagecompression_amd._shim import upstream
 from roibasedimagecompression_amd.api.comparison import calculate_quality_metrics  # noqa: F401
 
-
-def _upstream(name):
-    def fn(*args, **kwargs):
-        raise NotImplementedError(f"{name}: stage outside the MI355X hot path -- keep the reference's module for it "
-                                  "(see INTEGRATION.md)")
-    fn.__name__ = name
-    return fn
+_HELPERS = ("create_difference_visualization", "print_quality_report", "plot_comparison", "calculate_adaptive_quality_metrics",
+            "print_adaptive_metrics")
 
 
-create_difference_visualization = _upstream("create_difference_visualization")
-print_quality_report = _upstream("print_quality_report")
-plot_comparison = _upstream("plot_comparison")
-calculate_adaptive_quality_metrics = _upstream("calculate_adaptive_quality_metrics")
-print_adaptive_metrics = _upstream("print_adaptive_metrics")
+def _downstream_module():
+    pkg = sys.modules[__name__.rpartition(".")[0]]
+    here = os.path.dirname(os.path.abspath(__file__))
+    for d in pkg.__path__:
+        cand = os.path.join(d, "comparison.py")
+        if os.path.abspath(d) != here and os.path.isfile(cand):
+            spec = importlib.util.spec_from_file_location(__name__ + "._reference", cand)
+            mod = importlib.util.module_from_spec(spec)
+            spec.loader.exec_module(mod)
+            return mod
+    return None
+
+
+def __getattr__(name):
+    if name in _HELPERS:
+        mod = _downstream_module()
+        fn = getattr(mod, name) if mod is not None else upstream(name)
+        globals()[name] = fn
+        return fn
+    raise AttributeError(name)

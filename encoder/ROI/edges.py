@@ -1,18 +1,11 @@
-"""Placeholder for a stage that is UPSTREAM/DOWNSTREAM of the MI355X hot path (SURVEY.md 8f "next" rows).
-The names exist so that the reference's import lines resolve; a deployment keeps the reference's own
-module here (it needs OpenCV / scikit-image, which this build does not re-implement yet)."""
+"""Placeholder for a stage UPSTREAM/DOWNSTREAM of the MI355X hot path (SURVEY.md 8f "next" rows).  When the reference
+checkout sits behind this repository on sys.path its own module of this name is executed instead (roibasedimagecompression_amd/_shim.py);
+otherwise the names exist so that the reference's import lines resolve and raise when called."""
+from roibasedimagecompression_amd._shim import defer_to_downstream, upstream
 
-
-def _upstream(name):
-    def fn(*args, **kwargs):
-        raise NotImplementedError(f"{name}: stage outside the MI355X hot path -- keep the reference's module for it "
-                                  "(see INTEGRATION.md)")
-    fn.__name__ = name
-    return fn
-
-
-compute_local_density = _upstream("compute_local_density")
-suggest_automatic_threshold = _upstream("suggest_automatic_threshold")
-get_edge_map = _upstream("get_edge_map")
-get_edge_map_fast = _upstream("get_edge_map_fast")
-find_best_edges_by_quality = _upstream("find_best_edges_by_quality")
+if defer_to_downstream(__name__, __file__) is None:
+    compute_local_density = upstream("compute_local_density")
+    suggest_automatic_threshold = upstream("suggest_automatic_threshold")
+    get_edge_map = upstream("get_edge_map")
+    get_edge_map_fast = upstream("get_edge_map_fast")
+    find_best_edges_by_quality = upstream("find_best_edges_by_quality")

@@ -1,16 +1,9 @@
-"""Placeholder for a stage that is UPSTREAM/DOWNSTREAM of the MI355X hot path (SURVEY.md 8f "next" rows).
-The names exist so that the reference's import lines resolve; a deployment keeps the reference's own
-module here (it needs OpenCV / scikit-image, which this build does not re-implement yet)."""
+"""Placeholder for a stage UPSTREAM/DOWNSTREAM of the MI355X hot path (SURVEY.md 8f "next" rows).  When the reference
+checkout sits behind this repository on sys.path its own module of this name is executed instead (roibasedimagecompression_amd/_shim.py);
+otherwise the names exist so that the reference's import lines resolve and raise when called."""
+from roibasedimagecompression_amd._shim import defer_to_downstream, upstream
 
-
-def _upstream(name):
-    def fn(*args, **kwargs):
-        raise NotImplementedError(f"{name}: stage outside the MI355X hot path -- keep the reference's module for it "
-                                  "(see INTEGRATION.md)")
-    fn.__name__ = name
-    return fn
-
-
-remove_small_regions = _upstream("remove_small_regions")
-connect_nearby_pixels = _upstream("connect_nearby_pixels")
-connect_by_closing_fast = _upstream("connect_by_closing_fast")
+if defer_to_downstream(__name__, __file__) is None:
+    remove_small_regions = upstream("remove_small_regions")
+    connect_nearby_pixels = upstream("connect_nearby_pixels")
+    connect_by_closing_fast = upstream("connect_by_closing_fast")

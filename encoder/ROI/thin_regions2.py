@@ -1,14 +1,7 @@
-"""Placeholder for a stage that is UPSTREAM/DOWNSTREAM of the MI355X hot path (SURVEY.md 8f "next" rows).
-The names exist so that the reference's import lines resolve; a deployment keeps the reference's own
-module here (it needs OpenCV / scikit-image, which this build does not re-implement yet)."""
+"""Placeholder for a stage UPSTREAM/DOWNSTREAM of the MI355X hot path (SURVEY.md 8f "next" rows).  When the reference
+checkout sits behind this repository on sys.path its own module of this name is executed instead (roibasedimagecompression_amd/_shim.py);
+otherwise the names exist so that the reference's import lines resolve and raise when called."""
+from roibasedimagecompression_amd._shim import defer_to_downstream, upstream
 
-
-def _upstream(name):
-    def fn(*args, **kwargs):
-        raise NotImplementedError(f"{name}: stage outside the MI355X hot path -- keep the reference's module for it "
-                                  "(see INTEGRATION.md)")
-    fn.__name__ = name
-    return fn
-
-
-remove_thin_structures_optimized = _upstream("remove_thin_structures_optimized")
+if defer_to_downstream(__name__, __file__) is None:
+    remove_thin_structures_optimized = upstream("remove_thin_structures_optimized")

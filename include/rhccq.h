@@ -51,6 +51,11 @@ const char* rhccq_last_error(const rhccq_ctx* ctx);
 int rhccq_ctx_set_int(rhccq_ctx* ctx, int32_t option, int64_t value);
 int rhccq_sync(rhccq_ctx* ctx);                 /* hipStreamSynchronize on the context stream */
 void* rhccq_stream(rhccq_ctx* ctx);             /* the hipStream_t in use */
+/* Launch the following entry points on another HIP stream (not owned).  The Python side calls this whenever torch's
+ * current stream differs from the bound one, so that the caller's allocations / memsets (torch, current stream) and the
+ * kernels stay ordered on ONE stream -- e.g. inside `with torch.cuda.stream(s):`.  Work already queued on the previous
+ * stream is not waited for: ordering across streams is the caller's business, as with torch itself. */
+int rhccq_ctx_set_stream(rhccq_ctx* ctx, void* hip_stream);
 int rhccq_abi_version(void);
 
 /* ---- parameters: compute_clustering_params (encoder/compression/clustering.py:108-135) ----- */

@@ -30,6 +30,7 @@ PROTOTYPES = {
     "rhccq_ctx_set_int": (c_int32, [c_void_p, c_int32, c_int64]),
     "rhccq_sync": (c_int32, [c_void_p]),
     "rhccq_stream": (c_void_p, [c_void_p]),
+    "rhccq_ctx_set_stream": (c_int32, [c_void_p, c_void_p]),
     "rhccq_params": (c_int32, [c_int64, c_double, C.POINTER(c_double), C.POINTER(c_int64)]),
     "rhccq_eps_threshold": (c_int32, [c_double, C.POINTER(c_int32), C.POINTER(c_int32), C.POINTER(c_double)]),
     "rhccq_job_scan": (c_int32, [c_void_p, c_void_p, c_int32, c_int32, c_int32, C.POINTER(c_void_p), C.POINTER(c_int32),

@@ -63,6 +63,12 @@ int rhccq_sync(rhccq_ctx* ctx) {
 
 void* rhccq_stream(rhccq_ctx* ctx) { return ctx ? (void*)ctx->stream : nullptr; }
 
+int rhccq_ctx_set_stream(rhccq_ctx* ctx, void* hip_stream) {
+  if (!ctx) return RHCCQ_E_ARG;
+  ctx->stream = (hipStream_t)hip_stream;                // not owned; later entry points launch on it
+  return 0;
+}
+
 // compute_clustering_params (encoder/compression/clustering.py:127-133), same float64 expressions
 int rhccq_params(int64_t n_colors, double quality, double* eps_host, int64_t* max_colors_host) {
   if (!eps_host || !max_colors_host) return RHCCQ_E_ARG;

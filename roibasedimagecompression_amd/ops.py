@@ -15,6 +15,7 @@ Reference functions served (paths relative to the reference root):
 import ctypes as C
 import math
 import os
+import threading
 
 import numpy as np
 import torch
@@ -110,19 +111,49 @@ class _MtStream:
 
 
 _first_cache = {}
+_first_lock = threading.Lock()
 
 
 def first_centre_index(n, u0):
-    """RandomState.choice(n, p=ones/n): searchsorted(cumsum(p)/cumsum(p)[-1], u0, 'right')."""
+    """RandomState.choice(n, p=ones/n): searchsorted(cumsum(p)/cumsum(p)[-1], u0, 'right').  Called from the lanes of
+    a StreamEncoder and from the draw pool: the value is computed locally, the cache only ever hands out finished ones."""
     key = (n, u0)
-    if key not in _first_cache:
+    v = _first_cache.get(key)
+    if v is None:
         p = np.full(n, 1.0) / np.float64(n)
         cdf = np.cumsum(p)
         cdf /= cdf[-1]
-        if len(_first_cache) > 4096:                         # a stream of frames brings ever new (n, u0): keep it bounded
-            _first_cache.clear()
-        _first_cache[key] = min(int(np.searchsorted(cdf, u0, side="right")), n - 1)
-    return _first_cache[key]
+        v = min(int(np.searchsorted(cdf, u0, side="right")), n - 1)
+        with _first_lock:
+            if len(_first_cache) > 4096:                     # a stream of frames brings ever new (n, u0): keep it bounded
+                _first_cache.clear()
+            _first_cache[key] = v
+    return v
+
+
+class _StreamBoundLib:
+    """The C ABI as seen by one Rhccq: before every entry point that takes the context, the context is re-bound to
+    torch's CURRENT stream when that changed (rhccq_ctx_set_stream) -- every buffer of this module is allocated, zeroed
+    and freed by torch on the current stream, so the kernels must run there too (a `with torch.cuda.stream(s):` around
+    the mirrored API would otherwise race the memsets against kernels on the stream captured at construction)."""
+
+    def __init__(self, lib, owner):
+        self._lib, self._owner = lib, owner
+
+    def __getattr__(self, name):
+        fn = getattr(self._lib, name)
+        args = _lib.PROTOTYPES.get(name, (None, []))[1]
+        if not args or args[0] is not _lib.c_void_p or name in ("rhccq_ctx_destroy", "rhccq_last_error", "rhccq_ctx_set_stream", "rhccq_stream"):
+            setattr(self, name, fn)
+            return fn
+        owner = self._owner
+
+        def bound(*a):
+            owner._bind_stream()
+            return fn(*a)
+        bound.__name__ = name
+        setattr(self, name, bound)
+        return bound
 
 
 class Rhccq:
@@ -132,12 +163,13 @@ class Rhccq:
     def __init__(self, device=0):
         if not torch.cuda.is_available():
             raise RhccqError("no HIP device visible: the RHCCQ product path needs an MI355X (there is no CPU fallback)")
-        self.lib = _lib.load()
+        self._raw = _lib.load()
+        self.lib = _StreamBoundLib(self._raw, self)
         self.device = torch.device("cuda", device)
         torch.cuda.set_device(self.device)
-        self.stream = torch.cuda.current_stream(self.device)
+        self._bound = torch.cuda.current_stream(self.device).cuda_stream
         h = C.c_void_p()
-        rc = self.lib.rhccq_ctx_create(device, C.c_void_p(self.stream.cuda_stream), C.byref(h))
+        rc = self._raw.rhccq_ctx_create(device, C.c_void_p(self._bound), C.byref(h))
         if rc:
             raise RhccqError(f"rhccq_ctx_create failed ({rc})")
         self.ctx = h
@@ -146,6 +178,15 @@ class Rhccq:
         self._mtw_dev = None
 
     OPT_INIT_LDS_BLOCKS, OPT_INIT_MAX_ITEMS = 1, 2
+
+    def _bind_stream(self):
+        """kernels follow torch's current stream (see _StreamBoundLib)"""
+        s = torch.cuda.current_stream(self.device).cuda_stream
+        if s != self._bound:
+            rc = self._raw.rhccq_ctx_set_stream(self.ctx, C.c_void_p(s))
+            if rc:
+                raise RhccqError(f"rhccq_ctx_set_stream failed ({rc})")
+            self._bound = s
 
     def set_option(self, option, value):
         """rhccq_ctx_set_int: thresholds between equivalent kernel paths (include/rhccq.h)"""
@@ -161,7 +202,7 @@ class Rhccq:
 
     def close(self):
         if getattr(self, "ctx", None):
-            self.lib.rhccq_ctx_destroy(self.ctx)
+            self._raw.rhccq_ctx_destroy(self.ctx)
             self.ctx = None
 
     def __del__(self):
@@ -173,7 +214,7 @@ class Rhccq:
     # -- helpers --------------------------------------------------------------------------------
     def _check(self, rc, what):
         if rc:
-            msg = self.lib.rhccq_last_error(self.ctx)
+            msg = self._raw.rhccq_last_error(self.ctx)
             raise RhccqError(f"{what} failed ({rc}): {msg.decode() if msg else ''}")
 
     @staticmethod

@@ -4,6 +4,7 @@ reference's names; the container code (host side) is byte-exact against the refe
 import json
 import os
 import re
+import sys
 
 import numpy as np
 import pytest
@@ -89,6 +90,40 @@ def test_reference_import_surface():
     assert merge_region_components_simple([], (0, 0, 4, 4)) == []
     with pytest.raises(NotImplementedError):
         extract_regions(None, None, None)
+
+
+def test_reference_tree_behind_the_repository_is_not_shadowed(tmp_path):
+    """INTEGRATION.md section 1 "shadow on PYTHONPATH": with this repository FIRST on sys.path and a reference checkout behind
+    it, the hot-path modules resolve here while every other module of `encoder` / `decoder` (stages this build does not
+    replace, files it does not know) resolves to the reference's own file -- placeholders step aside."""
+    import subprocess
+    import textwrap
+    ref = tmp_path / "reference"
+    for d in ("encoder/ROI", "encoder/subregions", "encoder/enhancer", "decoder/uncompression", "other"):
+        (ref / d).mkdir(parents=True)
+    (ref / "encoder/ROI/small_gaps.py").write_text("def bridge_small_gaps(*a):\n    return 'reference small_gaps'\n")
+    (ref / "encoder/ROI/brand_new.py").write_text("VALUE = 41\n")
+    (ref / "encoder/enhancer/clahe.py").write_text("def get_enhanced_image(*a):\n    return 'reference clahe'\n")
+    (ref / "decoder/uncompression/comparison.py").write_text("def plot_comparison(*a):\n    return 'reference plot'\n")
+    (ref / "encoder/compression").mkdir()
+    (ref / "encoder/compression/clustering.py").write_text("raise RuntimeError('the hot-path module must come from the repository')\n")
+    (ref / "other/jpeg.py").write_text("Q = 3\n")
+    code = textwrap.dedent(f"""
+        import sys
+        sys.path.insert(0, {ROOT!r}); sys.path.append({str(ref)!r})
+        from encoder.ROI.small_gaps import bridge_small_gaps
+        from encoder.ROI.brand_new import VALUE
+        from encoder.enhancer.clahe import get_enhanced_image
+        from decoder.uncompression.comparison import plot_comparison, calculate_quality_metrics
+        import encoder.compression.clustering as c
+        import other.jpeg
+        assert bridge_small_gaps() == 'reference small_gaps' and VALUE == 41 and get_enhanced_image() == 'reference clahe'
+        assert plot_comparison() == 'reference plot' and calculate_quality_metrics.__module__.startswith('roibasedimagecompression_amd')
+        assert c.__file__.startswith({ROOT!r}) and other.jpeg.Q == 3
+        print('ok')
+    """)
+    r = subprocess.run([sys.executable, "-c", code], capture_output=True, text=True, env={**os.environ, "PYTHONDONTWRITEBYTECODE": "1"})
+    assert r.returncode == 0 and r.stdout.strip() == "ok", r.stderr
 
 
 def test_index_list_behaves_like_a_list():

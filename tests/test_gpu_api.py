@@ -129,3 +129,33 @@ def test_quality_metrics_vs_oracle():
     assert np.isinf(same["psnr"]) and same["mse"] == 0 and abs(same["ssim"] - 1.0) < 1e-12
     tiny = calculate_quality_metrics(a[:5, :5].copy(), b[:5, :5].copy())          # no 7x7 window fits: reference falls back to 0
     assert tiny["ssim"] == 0.0
+
+
+def test_mirrored_api_under_a_non_default_stream():
+    """default_context() caches one Rhccq per device; a caller inside `with torch.cuda.stream(s)` gets torch's
+    zero-fills and allocations on s, so the kernels must follow (rhccq_ctx_set_stream per call).  The notebook chain on a
+    side stream, after heavy work was queued on the default stream, must still equal the oracle."""
+    import torch
+    from oracle import rhccq_oracle as O
+    from encoder.compression.clustering import get_all_unique_colors, compute_clustering_params, cluster_palette_colors_parallel
+    from roibasedimagecompression_amd.ops import default_context
+    rh = default_context()
+    g = np.load(os.path.join(G, "g4_cluster.npz"))
+    side = torch.cuda.Stream()
+    for i in range(0, int(g["n"]), 5):
+        img, q = g[f"img{i}"], int(g[f"q{i}"])
+        busy = torch.randn(4096, 4096, device="cuda")
+        for _ in range(4):
+            busy = busy @ busy * 1e-3                                         # keeps the default stream occupied
+        with torch.cuda.stream(side):
+            d = get_all_unique_colors(img, (0, 0))
+            eps, ms, mc = compute_clustering_params(d["actual_colors"], q, color_space="lab")
+            o = cluster_palette_colors_parallel(q, d, eps=eps, min_samples=1, max_colors_per_cluster=mc)
+            assert rh._bound == side.cuda_stream
+            p1, i1 = arrs(o)
+        pal, idx = O.unique_colors(img)
+        npal, nidx = O.cluster_palette(q, pal, idx, eps, mc)
+        assert np.array_equal(p1, npal) and np.array_equal(i1, nidx), (i, q)
+    d = get_all_unique_colors(g["img0"], (0, 0))                             # and back on the default stream
+    assert rh._bound == torch.cuda.current_stream().cuda_stream
+    torch.cuda.synchronize()

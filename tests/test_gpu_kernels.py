@@ -154,6 +154,20 @@ def test_minibatch_equals_sklearn_golden(rh, O):
         check_against_g11(n, cases[n], g, info["chosen"][a:b], info["state"][i][5], info["centres"][a:b, :3], labs[i])
 
 
+def test_minibatch_more_than_256_problems(rh, O):
+    """the Morton sort names the problem in 8 bits of its key -- rhccq_mbk_order chunks by 256 problems.
+    300 small problems in one call (a batch of 65+ 4K frames has that many segments), spot-checked against the oracle."""
+    rng = np.random.default_rng(77)
+    pals = [np.unique(rng.integers(0, 40 + (i % 7) * 30, (1500, 3)).astype(np.uint8), axis=0) for i in range(300)]
+    ks = [3 + (i % 5) for i in range(300)]
+    labs, info = rh.minibatch_kmeans([O.pack_rgb(P) for P in pals], ks, return_info=True)
+    for i in (0, 1, 255, 256, 257, 299):
+        ol, oi = O.minibatch_kmeans_labels(pals[i], ks[i], return_info=True)
+        assert int(info["state"][i][5]) == oi["n_steps"], i
+        assert np.array_equal(info["centres"][info["koff"][i]:info["koff"][i + 1], :3], oi["centers"]), i
+        assert np.array_equal(labs[i], ol), i
+
+
 def test_merge_kernels_and_remap_decode(rh, O):
     import torch
     g = load("g5_merge.npz")
