@@ -45,9 +45,13 @@ const char* rhccq_last_error(const rhccq_ctx* ctx);
  *   RHCCQ_OPT_INIT_LDS_BLOCKS  k-means++ (rhccq_mbk_init): block tables live in LDS while the init sample has at
  *                              most this many 64-sample blocks (0..4096, default 4096), in global memory beyond;
  *   RHCCQ_OPT_INIT_MAX_ITEMS   capacity of the shared (candidate, block) work list (1..12288, default 12288);
- *                              picks that exceed it evaluate each candidate by its own enumeration instead. */
+ *                              picks that exceed it evaluate each candidate by its own enumeration instead;
+ *   RHCCQ_OPT_INIT_KERNEL      0 (default): the second-generation k-means++ chain whenever the block tables fit LDS;
+ *                              1: the first-generation chain always (same picks; kept for problems beyond LDS and as
+ *                              a cross-check). */
 #define RHCCQ_OPT_INIT_LDS_BLOCKS 1
 #define RHCCQ_OPT_INIT_MAX_ITEMS 2
+#define RHCCQ_OPT_INIT_KERNEL 3
 int rhccq_ctx_set_int(rhccq_ctx* ctx, int32_t option, int64_t value);
 int rhccq_sync(rhccq_ctx* ctx);                 /* hipStreamSynchronize on the context stream */
 void* rhccq_stream(rhccq_ctx* ctx);             /* the hipStream_t in use */

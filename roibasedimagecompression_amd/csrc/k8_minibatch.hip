@@ -660,6 +660,505 @@ __global__ __launch_bounds__(kInitThreads) void mbk_init_kernel(const uint32_t* 
   }
 }
 
+// =====================================================================================================
+// k-means++ chain, second generation.  Same arithmetic and the same picks as init_body() above (both are exact
+// integers); what changes is how one pick is scheduled on the CU, because the chain is bound by instruction issue:
+//   * 8 waves instead of 16, and phases that used one wave per candidate are vectorised ACROSS candidates (the
+//     candidate search runs in 4 waves, 4 candidates each, 16 lanes per candidate at levels 2 and 3);
+//   * enumeration in ONE phase: a (candidate, 64 super-blocks) unit tests its boxes and expands its hits to blocks
+//     on the spot, appending (candidate, block) items to the shared list -- two barriers and one list less;
+//   * evaluation by quarter waves: 16 lanes x 4 samples per item, 4 items per wave instruction stream (half the
+//     instructions per item); the stored per-sample value is c' = closest - |x|^2, so that the improvement
+//     closest - d = c' - |c|^2 + 2<c, x> costs one dot product;
+//   * the samples a wave evaluated STAY in its registers until the winner is known: the commit needs no second
+//     trip to the L2, and the draw position of every sample travels in the spare bits of its (key, c') pair.
+// =====================================================================================================
+constexpr int kJThreads = 512;
+constexpr int kJWaves = kJThreads / 64;
+constexpr int kJMaxItems = 4096;          // (candidate, block) items per pick in LDS; beyond: per-candidate enumeration
+constexpr int kJKeep = 12;                // evaluation instructions (4 items each) a wave keeps in registers
+constexpr int kJTouch = 1024;
+
+struct JShared {
+  unsigned long long delta[kTMaxI];
+  unsigned long long R[kTMaxI];           // integer search targets: ceil(u * pot)
+  unsigned long long pot;
+  unsigned long long red64[kJWaves];
+  int cand[kTMaxI];
+  uint32_t ckey[kTMaxI];
+  uint32_t cna[kTMaxI];
+  uint32_t ckp[kTMaxI][4];
+  int n_items, overflow, n_touch2[2];
+};
+
+// sample pair, Morton order: x = key | (dpos & 255) << 24 ; y = (c' & 0x7ffff) | (dpos >> 8) << 19, c' = closest - |key|^2
+__device__ __forceinline__ uint2 jpack(uint32_t key, int cprime, uint32_t dpos) {
+  return make_uint2(key | (dpos << 24), ((uint32_t)cprime & 0x7ffffu) | ((dpos >> 8) << 19));
+}
+__device__ __forceinline__ int j_cprime(uint32_t y) { return (int)(y << 13) >> 13; }
+__device__ __forceinline__ uint32_t j_dpos(uint32_t x, uint32_t y) { return (x >> 24) | ((y >> 19) << 8); }
+
+__device__ __forceinline__ unsigned row_incscan_u32(unsigned v) {                 // inclusive scan inside each row of 16 lanes
+  v += (unsigned)__builtin_amdgcn_update_dpp(0, (int)v, 0x111, 0xF, 0xF, true);
+  v += (unsigned)__builtin_amdgcn_update_dpp(0, (int)v, 0x112, 0xF, 0xF, true);
+  v += (unsigned)__builtin_amdgcn_update_dpp(0, (int)v, 0x114, 0xF, 0xF, true);
+  v += (unsigned)__builtin_amdgcn_update_dpp(0, (int)v, 0x118, 0xF, 0xF, true);
+  return v;
+}
+__device__ __forceinline__ unsigned long long readlane64(unsigned long long v, int l) {
+  return ((unsigned long long)(unsigned)__builtin_amdgcn_readlane((int)(v >> 32), l) << 32) | (unsigned)__builtin_amdgcn_readlane((int)(unsigned)v, l);
+}
+template <typename T>
+__device__ __forceinline__ T sel4(int q, const T (&a)[4]) { return q == 0 ? a[0] : q == 1 ? a[1] : q == 2 ? a[2] : a[3]; }
+
+// improvement of the 4 samples a lane holds against candidate (ck, na = |ck|^2): sum of max(0, c' - na + 2 <ck, x>)
+__device__ __forceinline__ unsigned j_eval4(uint32_t ck, int na, const uint4& a, const uint4& b) {
+  const int i0 = j_cprime(a.y) - na + 2 * (int)__builtin_amdgcn_udot4(ck, a.x, 0u, false);
+  const int i1 = j_cprime(a.w) - na + 2 * (int)__builtin_amdgcn_udot4(ck, a.z, 0u, false);
+  const int i2 = j_cprime(b.y) - na + 2 * (int)__builtin_amdgcn_udot4(ck, b.x, 0u, false);
+  const int i3 = j_cprime(b.w) - na + 2 * (int)__builtin_amdgcn_udot4(ck, b.z, 0u, false);
+  return (unsigned)(max(i0, 0) + max(i1, 0)) + (unsigned)(max(i2, 0) + max(i3, 0));
+}
+
+// commit of one sample against the new centre; returns its true closest distance afterwards
+__device__ __forceinline__ unsigned j_commit1(uint32_t ck, int na, uint32_t x, uint32_t y, int m, uint2* samp, uint2* dsamp, uint32_t* dsum,
+                                             uint32_t* dssum) {
+  const int dot2 = 2 * (int)__builtin_amdgcn_udot4(ck, x, 0u, false);
+  int cp = j_cprime(y);
+  const int imp = cp - na + dot2;
+  const unsigned nx = norm2_key(x & 0xffffffu);
+  if (imp > 0) {
+    cp = na - dot2;                                       // new c' = d - |x|^2
+    const uint32_t dpos = j_dpos(x, y);
+    samp[m].y = ((uint32_t)cp & 0x7ffffu) | (y & 0xfff80000u);
+    dsamp[dpos].y = (uint32_t)(cp + (int)nx);
+    atomicSub(&dsum[dpos >> 6], (unsigned)imp);
+    atomicSub(&dssum[dpos >> 10], (unsigned)imp);
+  }
+  return (unsigned)(cp + (int)nx);
+}
+
+// one row of 16 lanes = one block of 64 samples (lane j holds samples 4j .. 4j+3 in a, b): lower closest[] against
+// the new centre, refresh the block's max, note its super-block as touched
+__device__ __forceinline__ void j_commit_row(bool on, int b, uint32_t ck, int na, const uint4& a, const uint4& bb, uint2* samp, uint2* dsamp,
+                                             uint4* blk, uint32_t* dsum, uint32_t* dssum, int* touch, int* n_touch) {
+  const int j = threadIdx.x & 15;
+  unsigned mx = 0;
+  if (on) {
+    const int m0 = (b << 6) + 4 * j;
+    const unsigned t0 = j_commit1(ck, na, a.x, a.y, m0, samp, dsamp, dsum, dssum);
+    const unsigned t1 = j_commit1(ck, na, a.z, a.w, m0 + 1, samp, dsamp, dsum, dssum);
+    const unsigned t2 = j_commit1(ck, na, bb.x, bb.y, m0 + 2, samp, dsamp, dsum, dssum);
+    const unsigned t3 = j_commit1(ck, na, bb.z, bb.w, m0 + 3, samp, dsamp, dsum, dssum);
+    mx = max(max(t0, t1), max(t2, t3));
+  }
+  mx = dpp_row_max(mx);
+  if (on && j == 0) {
+    blk[b].w = mx;
+    const int slot = atomicAdd(n_touch, 1);
+    if (slot < kJTouch) touch[slot] = b >> 4;
+  }
+}
+
+// calls f(my_block, on) for the blocks named by the set bits of `mb` (bit l <-> the block lane l holds in `b`), four
+// blocks per call: row q of the wave gets the q-th of them
+template <typename F>
+__device__ __forceinline__ void j_for_rows(unsigned long long mb, int b, F&& f) {
+  const int q = (threadIdx.x & 63) >> 4;
+  while (mb) {
+    int b4[4];
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+      if (mb) { b4[i] = __builtin_amdgcn_readlane(b, __ffsll((long long)mb) - 1); mb &= mb - 1; }
+      else b4[i] = -1;
+    }
+    const int my_b = sel4(q, b4);
+    f(my_b, my_b >= 0);
+  }
+}
+
+// box tests of one candidate against 64 super-blocks (one per lane), hits expanded to blocks: calls g(mask, b) with the
+// ballot of the blocks that may improve and the block index each lane tested
+template <typename G>
+__device__ __forceinline__ void j_enumerate(const CandP& cp, int sb_first, int nsb, int nb, const uint4* sup, const uint4* blk, G&& g) {
+  const int lane = threadIdx.x & 63;
+  const int sbi = sb_first + lane;
+  bool hs = false;
+  if (sbi < nsb) {
+    const uint4 se = sup[sbi];
+    hs = box_dist2(cp, se.x, se.y, se.z) < se.w;
+  }
+  unsigned long long ms = __ballot(hs);
+  while (ms) {
+    int s4[4];
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+      if (ms) { s4[i] = sb_first + __ffsll((long long)ms) - 1; ms &= ms - 1; }
+      else s4[i] = -1;
+    }
+    const int my_s = sel4(lane >> 4, s4);
+    const int b = my_s * 16 + (lane & 15);
+    bool hb = my_s >= 0 && b < nb;
+    if (hb) {
+      const uint4 be = blk[b];
+      hb = box_dist2(cp, be.x, be.y, be.z) < be.w;
+    }
+    g(__ballot(hb), b, hb);
+  }
+}
+
+__global__ __launch_bounds__(kJThreads) void mbk_init2_kernel(const uint32_t* __restrict__ keys, const MbkP* __restrict__ probs,
+                                                               const int32_t* __restrict__ init_idx, const int32_t* __restrict__ perm,
+                                                               const double* __restrict__ rand, double* __restrict__ centres,
+                                                               int32_t* __restrict__ chosen, uint32_t* scratch,
+                                                               const long long* __restrict__ scratch_off, int max_items) {
+  __shared__ JShared sh;
+  __shared__ uint4 blk[kInitLdsBlocks];                  // per Morton block: box (3 pairs), max closest
+  __shared__ uint4 sup[kInitLdsSuper];                   // per Morton super-block: box, max of the blocks' max (may lag high)
+  __shared__ uint32_t dsum[kInitLdsBlocks];              // per draw block: sum of closest
+  __shared__ uint32_t dssum[kInitLdsSuper];
+  __shared__ uint32_t items[kJMaxItems];
+  __shared__ int s_touch[2 * kJTouch];
+  const MbkP P = probs[blockIdx.x];
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const int n = (int)P.init_n, k = (int)P.k, T = P.T;
+  const int nb = (n + 63) >> 6, np = nb << 6, nsb = (nb + 15) >> 4;
+  uint2* samp = reinterpret_cast<uint2*>(scratch + scratch_off[blockIdx.x]);
+  uint2* dsamp = samp + np;
+  int32_t* cho = chosen + P.koff;
+  // ---- gather the sample (both orders), first centre, tables ---------------------------------------------
+  const uint32_t kf = keys[P.off + init_idx[P.init_off + P.first]];
+  {
+    const int last_d = perm[P.init_off + n - 1];
+    for (int i = tid; i < np; i += kJThreads) {
+      const int d = i < n ? perm[P.init_off + i] : i;     // padding: the last Morton sample again, closest = 0, unused draw slots
+      const uint32_t kk = keys[P.off + init_idx[P.init_off + (i < n ? d : last_d)]];
+      const unsigned cl = i < n ? (unsigned)dist2_keys(kk, kf) : 0u;
+      samp[i] = jpack(kk, (int)cl - (int)norm2_key(kk), (uint32_t)d);
+      dsamp[d] = make_uint2(kk, cl);
+    }
+  }
+  __syncthreads();
+  for (int b = wave; b < nb; b += kJWaves) {
+    const uint2 sv = samp[(b << 6) + lane];
+    const uint32_t kk = sv.x & 0xffffffu;
+    unsigned r0 = key_r(kk), r1 = r0, g0 = key_g(kk), g1 = g0, b0 = key_b(kk), b1 = b0;
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) {
+      r0 = min(r0, (unsigned)__shfl_down(r0, o, 64)); r1 = max(r1, (unsigned)__shfl_down(r1, o, 64));
+      g0 = min(g0, (unsigned)__shfl_down(g0, o, 64)); g1 = max(g1, (unsigned)__shfl_down(g1, o, 64));
+      b0 = min(b0, (unsigned)__shfl_down(b0, o, 64)); b1 = max(b1, (unsigned)__shfl_down(b1, o, 64));
+    }
+    const unsigned dm = wave_max_u32((unsigned)(j_cprime(sv.y) + (int)norm2_key(kk)));
+    const unsigned ds = wave_sum_u32(dsamp[(b << 6) + lane].y);
+    if (lane == 0) {
+      blk[b] = make_uint4(box_pair(r0, r1), box_pair(g0, g1), box_pair(b0, b1), dm);
+      dsum[b] = ds;
+    }
+  }
+  __syncthreads();
+  unsigned long long psum = 0;
+  for (int sb = tid; sb < nsb; sb += kJThreads) {
+    int r0 = 255, g0 = 255, b0 = 255, r1 = 0, g1 = 0, b1 = 0;
+    unsigned m = 0, sum = 0;
+    for (int b = sb * 16; b < min(sb * 16 + 16, nb); ++b) {
+      const uint4 be = blk[b];
+      r0 = min(r0, pair_lo(be.x)); g0 = min(g0, pair_lo(be.y)); b0 = min(b0, pair_lo(be.z));
+      r1 = max(r1, pair_hi(be.x)); g1 = max(g1, pair_hi(be.y)); b1 = max(b1, pair_hi(be.z));
+      m = max(m, be.w);
+      sum += dsum[b];
+    }
+    sup[sb] = make_uint4(box_pair((unsigned)r0, (unsigned)r1), box_pair((unsigned)g0, (unsigned)g1), box_pair((unsigned)b0, (unsigned)b1), m);
+    dssum[sb] = sum;
+    psum += sum;
+  }
+  psum = block_sum<unsigned long long>(psum, sh.red64);
+  if (tid == 0) { cho[0] = P.first; sh.n_touch2[0] = 0; sh.n_touch2[1] = 0; sh.pot = psum; sh.n_items = 0; sh.overflow = 0; }
+  if (tid < kTMaxI) sh.delta[tid] = 0;
+  if (tid < T && k > 1) sh.R[tid] = (unsigned long long)ceil(rand[P.rand_off + tid] * (double)psum);
+  __syncthreads();
+  const int nch = (nsb + 63) >> 6;
+  const unsigned long long below = (1ull << lane) - 1ull;
+  const int rq = lane >> 4, rj = lane & 15;
+  for (int c = 1; c < k; ++c) {
+    // the next pick's uniforms are a cold line in HBM: fetch them now, use them at the end of the pick
+    double u_next = 0.0;
+    if (tid < T && c + 1 < k) u_next = rand[P.rand_off + (size_t)c * T + tid];
+    const unsigned long long pot = sh.pot;
+    if (tid < T) sh.delta[tid] = 0;                      // (read for the arg-max before the previous pick's closing barrier)
+    const int* touch_r = s_touch + (((c - 1) & 1) ? kJTouch : 0);
+    const int n_touched = min(sh.n_touch2[(c - 1) & 1], kJTouch);
+    // ================= phase 1: the T candidates (waves 0-3, four candidates each) ===========================
+    if (wave < 4) {
+      // np.searchsorted(cumsum(closest), r, 'left') in DRAW order; cum and the targets R = ceil(r) are exact integers
+      unsigned long long Rq[4], baseq[4];
+      int sbq[4], bq[4];
+      bool act[4], fnd[4];
+#pragma unroll
+      for (int q = 0; q < 4; ++q) {
+        const int t = wave + 4 * q;
+        act[q] = t < T;
+        const unsigned long long rv = act[q] ? sh.R[t] : 0ull;
+        Rq[q] = ((unsigned long long)(unsigned)__builtin_amdgcn_readfirstlane((int)(rv >> 32)) << 32) | (unsigned)__builtin_amdgcn_readfirstlane((int)(unsigned)rv);
+        fnd[q] = !act[q] || Rq[q] == 0;                  // R = 0: position 0
+        sbq[q] = 0; baseq[q] = 0; bq[q] = 0;
+      }
+      unsigned long long carry = 0;
+      for (int ch = 0; ch < nch; ++ch) {
+        const int sb = ch * 64 + lane;
+        const unsigned v = sb < nsb ? dssum[sb] : 0u;
+        const unsigned long long inc = carry + wave_incscan_limbs(v);
+        const unsigned long long exc = inc - v;
+#pragma unroll
+        for (int q = 0; q < 4; ++q) {
+          if (!fnd[q]) {
+            const unsigned long long m = __ballot(v > 0 && exc < Rq[q] && Rq[q] <= inc);
+            if (m) {
+              const int l = __ffsll((long long)m) - 1;
+              sbq[q] = ch * 64 + l;
+              baseq[q] = readlane64(exc, l);
+              fnd[q] = true;
+            }
+          }
+        }
+        carry = readlane64(inc, 63);
+      }
+      // level 2: the 16 draw blocks of each candidate's super-block, one row of lanes per candidate
+      unsigned long long base2q[4];
+      bool miss[4];
+      {
+        const int my_sb = sel4(rq, sbq);
+        const unsigned long long my_base = sel4(rq, baseq), my_R = sel4(rq, Rq);
+        const bool my_on = sel4(rq, act) && sel4(rq, fnd) && my_R != 0;
+        const int b2 = my_sb * 16 + rj;
+        const unsigned v2 = (my_on && b2 < nb) ? dsum[b2] : 0u;
+        const unsigned long long cum2 = my_base + row_incscan_u32(v2);
+        const unsigned long long m2 = __ballot(my_on && v2 > 0 && (cum2 - v2) < my_R && my_R <= cum2);
+#pragma unroll
+        for (int q = 0; q < 4; ++q) {
+          const unsigned bits = (unsigned)(m2 >> (16 * q)) & 0xffffu;
+          base2q[q] = 0;
+          miss[q] = false;
+          if (act[q] && Rq[q] != 0) {
+            if (fnd[q] && bits) {
+              const int jq = __ffs((int)bits) - 1;
+              bq[q] = sbq[q] * 16 + jq;
+              base2q[q] = readlane64(cum2 - v2, 16 * q + jq);
+            } else {
+              miss[q] = true;                              // target beyond the total (cannot happen): the last sample
+              bq[q] = nb - 1;
+            }
+          }
+        }
+      }
+      // level 3: the 64 samples of the draw block, 4 per lane
+      {
+        const int my_b = sel4(rq, bq);
+        const bool my_on = sel4(rq, act);
+        const unsigned long long my_R = sel4(rq, Rq), my_b2 = sel4(rq, base2q);
+        const unsigned rr = sel4(rq, miss) ? 0xffffffffu : (unsigned)(my_R - my_b2);
+        const int i0 = (my_b << 6) + 4 * rj;
+        uint4 a = make_uint4(0, 0, 0, 0), bb = a;
+        if (my_on) {
+          const uint4* p4 = reinterpret_cast<const uint4*>(dsamp + i0);
+          a = p4[0];
+          bb = p4[1];
+        }
+        const unsigned c0 = i0 < n ? a.y : 0u, c1 = i0 + 1 < n ? a.w : 0u, c2 = i0 + 2 < n ? bb.y : 0u, c3 = i0 + 3 < n ? bb.w : 0u;
+        const unsigned s0 = c0, s1 = s0 + c1, s2 = s1 + c2, s3 = s2 + c3;
+        const unsigned exr = row_incscan_u32(s3) - s3;
+        const int first = (i0 < n && exr + s0 >= rr) ? 0 : (i0 + 1 < n && exr + s1 >= rr) ? 1 : (i0 + 2 < n && exr + s2 >= rr) ? 2
+                          : (i0 + 3 < n && exr + s3 >= rr) ? 3 : 4;
+        const uint32_t fkey = first == 0 ? a.x : first == 1 ? a.z : first == 2 ? bb.x : bb.z;
+        const unsigned long long m3 = __ballot(my_on && first < 4);
+#pragma unroll
+        for (int q = 0; q < 4; ++q) {
+          if (!act[q]) continue;
+          const int t = wave + 4 * q;
+          const unsigned bits = (unsigned)(m3 >> (16 * q)) & 0xffffu;
+          int cand;
+          uint32_t ck;
+          if (bits) {
+            const int l = 16 * q + __ffs((int)bits) - 1;
+            cand = (bq[q] << 6) + 4 * (l & 15) + __builtin_amdgcn_readlane(first, l);
+            ck = (uint32_t)__builtin_amdgcn_readlane((int)fkey, l);
+          } else {
+            cand = min(n - 1, (bq[q] << 6) + 63);
+            ck = dsamp[cand].x;
+          }
+          if (lane == 0) {
+            sh.cand[t] = cand;
+            sh.ckey[t] = ck;
+            sh.cna[t] = norm2_key(ck);
+            const CandP cp = cand_pairs(ck);
+            sh.ckp[t][0] = cp.r; sh.ckp[t][1] = cp.g; sh.ckp[t][2] = cp.b;
+          }
+        }
+      }
+    } else {
+      // the other waves refresh the super-block maxima the previous winner touched (a stale, larger maximum is
+      // conservative, so the enumeration may read either value)
+      for (int i = tid - 4 * 64; i < n_touched * 16; i += kJThreads - 4 * 64) {
+        const int sb = touch_r[i >> 4], b = sb * 16 + (i & 15);
+        unsigned m = b < nb ? blk[b].w : 0u;
+        m = dpp_row_max(m);
+        if ((i & 15) == 0) sup[sb].w = m;
+      }
+    }
+    __syncthreads();
+    // ================= phase 2: which blocks can each candidate improve? =====================================
+    // (candidate, 64 super-blocks) units; hits are expanded to blocks at once and appended to the shared item list
+    for (int u = wave, t = 0, ch = wave; u < T * nch; u += kJWaves, ch += kJWaves) {
+      while (ch >= nch) { ch -= nch; ++t; }                // unit u = (candidate t, chunk ch)
+      const CandP cp{sh.ckp[t][0], sh.ckp[t][1], sh.ckp[t][2]};
+      j_enumerate(cp, ch * 64, nsb, nb, sup, blk, [&](unsigned long long mb, int b, bool hb) {
+        const int cnt = __popcll(mb);
+        if (cnt) {
+          int base = 0;
+          if (lane == 0) base = atomicAdd(&sh.n_items, cnt);
+          base = __builtin_amdgcn_readfirstlane(base);
+          if (base + cnt > max_items) { if (lane == 0) sh.overflow = 1; }
+          else if (hb) items[base + __popcll(mb & below)] = ((uint32_t)t << 24) | (uint32_t)b;
+        }
+      });
+    }
+    __syncthreads();
+    // ================= phase 3: potentials ===================================================================
+    const bool use_list = sh.overflow == 0;
+    const int n_items = use_list ? sh.n_items : 0;
+    const int n_ops = (n_items + 3) >> 2;                  // one evaluation instruction stream = 4 items, one per row
+    const bool kept = n_ops <= kJWaves * kJKeep;           // every item's samples stay in the registers of its wave
+    int* touch_w = s_touch + ((c & 1) ? kJTouch : 0);
+    int* n_touch_w = &sh.n_touch2[c & 1];
+    uint4 ka[kJKeep], kb[kJKeep];
+    uint32_t kw[kJKeep];
+    if (use_list) {
+#pragma unroll
+      for (int s = 0; s < kJKeep; ++s) {
+        const int ii = 4 * (wave + s * kJWaves) + rq;
+        kw[s] = ii < n_items ? items[ii] : 0xffffffffu;
+        ka[s] = make_uint4(0, 0, 0, 0);
+        kb[s] = ka[s];
+        if (kw[s] != 0xffffffffu) {
+          const uint4* p4 = reinterpret_cast<const uint4*>(samp + ((kw[s] & 0xffffffu) << 6) + 4 * rj);
+          ka[s] = p4[0];
+          kb[s] = p4[1];
+        }
+      }
+#pragma unroll
+      for (int s = 0; s < kJKeep; ++s) {
+        const bool on = kw[s] != 0xffffffffu;
+        const int t = on ? (int)(kw[s] >> 24) : 0;
+        unsigned imp = on ? j_eval4(sh.ckey[t], (int)sh.cna[t], ka[s], kb[s]) : 0u;
+        imp = dpp_row_sum(imp);
+        if (on && rj == 0 && imp) atomicAdd(&sh.delta[t], (unsigned long long)imp);
+      }
+      for (int o = wave + kJKeep * kJWaves; o < n_ops; o += kJWaves) {   // more items than the registers hold
+        const int ii = 4 * o + rq;
+        const uint32_t w = ii < n_items ? items[ii] : 0xffffffffu;
+        const bool on = w != 0xffffffffu;
+        unsigned imp = 0;
+        if (on) {
+          const uint4* p4 = reinterpret_cast<const uint4*>(samp + ((w & 0xffffffu) << 6) + 4 * rj);
+          const int t = (int)(w >> 24);
+          imp = j_eval4(sh.ckey[t], (int)sh.cna[t], p4[0], p4[1]);
+        }
+        imp = dpp_row_sum(imp);
+        if (on && rj == 0 && imp) atomicAdd(&sh.delta[w >> 24], (unsigned long long)imp);
+      }
+    } else {
+      // the item list overflowed (the first picks, when every block can still improve): each candidate is enumerated
+      // and evaluated by one wave, no list
+      for (int t = wave; t < T; t += kJWaves) {
+        const CandP cp{sh.ckp[t][0], sh.ckp[t][1], sh.ckp[t][2]};
+        const uint32_t ck = sh.ckey[t];
+        const int na = (int)sh.cna[t];
+        unsigned long long acc = 0;
+        for (int ch = 0; ch < nch; ++ch) {
+          j_enumerate(cp, ch * 64, nsb, nb, sup, blk, [&](unsigned long long mb, int b, bool hb) {
+            j_for_rows(mb, b, [&](int my_b, bool on) {
+              if (on) {
+                const uint4* p4 = reinterpret_cast<const uint4*>(samp + (my_b << 6) + 4 * rj);
+                acc += j_eval4(ck, na, p4[0], p4[1]);
+              }
+            });
+          });
+        }
+        acc = wave_sum(acc);
+        if (lane == 0) sh.delta[t] = acc;
+      }
+    }
+    __syncthreads();
+    // ================= phase 4: greedy choice + commit =======================================================
+    // largest reduction == smallest potential; the first candidate wins ties
+    const unsigned long long dv = lane < T ? sh.delta[lane] : 0ull;
+    const unsigned dhi = (unsigned)(dv >> 32), dlo = (unsigned)dv;
+    const unsigned mhi = wave_max_u32(dhi);
+    const unsigned mlo = wave_max_u32(dhi == mhi ? dlo : 0u);
+    const unsigned long long bd = ((unsigned long long)mhi << 32) | mlo;
+    const int best = __ffsll((long long)__ballot(lane < T && dv == bd)) - 1;
+    const uint32_t kbest = (uint32_t)__builtin_amdgcn_readlane((int)(lane < T ? sh.ckey[lane] : 0u), best);
+    const int nabest = (int)norm2_key(kbest);
+    if (use_list && kept) {
+#pragma unroll
+      for (int s = 0; s < kJKeep; ++s) {
+        const bool mine = kw[s] != 0xffffffffu && (int)(kw[s] >> 24) == best;
+        if (__ballot(mine))
+          j_commit_row(mine, (int)(kw[s] & 0xffffffu), kbest, nabest, ka[s], kb[s], samp, dsamp, blk, dsum, dssum, touch_w, n_touch_w);
+      }
+    } else if (use_list) {
+      for (int o = wave; o < n_ops; o += kJWaves) {
+        const int ii = 4 * o + rq;
+        const uint32_t w = ii < n_items ? items[ii] : 0xffffffffu;
+        const bool mine = w != 0xffffffffu && (int)(w >> 24) == best;
+        if (!__ballot(mine)) continue;
+        uint4 a = make_uint4(0, 0, 0, 0), bb = a;
+        if (mine) {
+          const uint4* p4 = reinterpret_cast<const uint4*>(samp + ((w & 0xffffffu) << 6) + 4 * rj);
+          a = p4[0];
+          bb = p4[1];
+        }
+        j_commit_row(mine, (int)(w & 0xffffffu), kbest, nabest, a, bb, samp, dsamp, blk, dsum, dssum, touch_w, n_touch_w);
+      }
+    } else {
+      const CandP cp = cand_pairs(kbest);
+      for (int ch = wave; ch < nch; ch += kJWaves) {
+        j_enumerate(cp, ch * 64, nsb, nb, sup, blk, [&](unsigned long long mb, int b, bool hb) {
+          j_for_rows(mb, b, [&](int my_b, bool on) {
+            uint4 a = make_uint4(0, 0, 0, 0), bb = a;
+            if (on) {
+              const uint4* p4 = reinterpret_cast<const uint4*>(samp + (my_b << 6) + 4 * rj);
+              a = p4[0];
+              bb = p4[1];
+            }
+            j_commit_row(on, my_b, kbest, nabest, a, bb, samp, dsamp, blk, dsum, dssum, touch_w, n_touch_w);
+          });
+        });
+      }
+    }
+    if (tid == 0) { cho[c] = sh.cand[best]; sh.pot = pot - bd; sh.n_items = 0; sh.overflow = 0; sh.n_touch2[(c + 1) & 1] = 0; }
+    if (tid < T) sh.R[tid] = (unsigned long long)ceil(u_next * (double)(pot - bd));
+    __syncthreads();
+    // more touched super-blocks than the list holds (only in the first picks): refresh all of them
+    if (sh.n_touch2[c & 1] > kJTouch) {
+      for (int sb = tid; sb < nsb; sb += kJThreads) {
+        unsigned m = 0;
+        for (int b = sb * 16; b < min(sb * 16 + 16, nb); ++b) m = max(m, blk[b].w);
+        sup[sb].w = m;
+      }
+      __syncthreads();
+      if (tid == 0) sh.n_touch2[c & 1] = 0;
+      __syncthreads();
+    }
+  }
+  for (int j = tid; j < k; j += kJThreads) {
+    const uint32_t kk = dsamp[cho[j]].x;
+    const double c0 = (double)key_r(kk), c1 = (double)key_g(kk), c2 = (double)key_b(kk);
+    double* C = centres + (P.koff + j) * 4;
+    C[0] = c0; C[1] = c1; C[2] = c2; C[3] = km64_csq(c0, c1, c2);
+  }
+}
+
 // ------------------------------------------------------------------------------------------------
 // mini-batch steps
 // ------------------------------------------------------------------------------------------------
@@ -1727,8 +2226,16 @@ int rhccq_mbk_init(rhccq_ctx* ctx, const uint32_t* keys, const rhccq_mbk_problem
   RHCCQ_HIP(ctx, hipStreamSynchronize(ctx->stream));
   const int lds_blocks = ctx->opt_init_lds_blocks < 0 ? kInitLdsBlocks : ctx->opt_init_lds_blocks;
   const int max_items = ctx->opt_init_max_items < 0 ? kMaxItems : ctx->opt_init_max_items;
-  hipLaunchKernelGGL(mbk_init_kernel, dim3(n_prob), dim3(kInitThreads), 0, ctx->stream, keys, dp, init_idx, perm, rand, centres, chosen, dscr, dof,
-                     lds_blocks, max_items);
+  // second-generation chain (8 waves, tables in LDS) whenever every problem's block tables fit; the first generation keeps
+  // the tables of larger problems (more than 262 144 init samples) in global memory
+  bool lean = ctx->opt_init_kernel != 1;
+  for (int i = 0; i < n_prob && lean; ++i) lean = (probs[i].init_n + 63) / 64 <= lds_blocks;
+  if (lean)
+    hipLaunchKernelGGL(mbk_init2_kernel, dim3(n_prob), dim3(kJThreads), 0, ctx->stream, keys, dp, init_idx, perm, rand, centres, chosen, dscr,
+                       dof, max_items < kJMaxItems ? max_items : kJMaxItems);
+  else
+    hipLaunchKernelGGL(mbk_init_kernel, dim3(n_prob), dim3(kInitThreads), 0, ctx->stream, keys, dp, init_idx, perm, rand, centres, chosen, dscr, dof,
+                       lds_blocks, max_items);
   RHCCQ_LAUNCH_CHECK(ctx);
   return 0;
 }

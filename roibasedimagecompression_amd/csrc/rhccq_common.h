@@ -18,6 +18,7 @@ struct rhccq_ctx {
   // tuning knobs (rhccq_ctx_set_int); -1 = built-in value
   int opt_init_lds_blocks = -1;
   int opt_init_max_items = -1;
+  int opt_init_kernel = 0;   // 0 = second-generation k-means++ chain when the tables fit LDS, 1 = first generation always
 };
 
 #define RHCCQ_HIP(ctx, expr)                                                        \

@@ -177,7 +177,7 @@ class Rhccq:
         self.mtw = MtWords()
         self._mtw_dev = None
 
-    OPT_INIT_LDS_BLOCKS, OPT_INIT_MAX_ITEMS = 1, 2
+    OPT_INIT_LDS_BLOCKS, OPT_INIT_MAX_ITEMS, OPT_INIT_KERNEL = 1, 2, 3
 
     def _bind_stream(self):
         """kernels follow torch's current stream (see _StreamBoundLib)"""

@@ -215,43 +215,49 @@ def test_dct_quant_extension(rh, O, block):
     assert np.array_equal(q.cpu().numpy(), oq)
 
 
-@pytest.mark.parametrize("path", ["default", "global_tables", "tiny_work_list"])
+@pytest.mark.parametrize("path", ["default", "tiny_work_list", "first_generation", "first_generation_tiny_work_list", "global_tables"])
 def test_minibatch_init_chain_many_cases(rh, O, path):
-    """The k-means++ chain of mbk_init_kernel (work list, lazy super-block maxima, hierarchical search) against
-    the oracle's exact-integer k-means++ on the same init sample in sklearn's draw order, for several shapes -- every pick
-    must be identical (this is the kernel where a reduction race once hid behind lucky timing).
-    `global_tables` / `tiny_work_list` lower the thresholds (rhccq_ctx_set_int) so that the paths of very large
-    problems -- block tables in global memory beyond 262 144 samples, per-candidate evaluation when the shared
-    work list overflows -- run on inputs the oracle can check."""
-    import math
+    """The k-means++ chains (mbk_init2_kernel: candidate search vectorised across candidates, one-phase enumeration,
+    quarter-wave evaluation with the samples kept in registers for the commit; mbk_init_kernel: the first generation,
+    still used beyond 262 144 init samples) against the oracle's exact-integer k-means++ on the same init sample in
+    sklearn's draw order, for several shapes -- every pick must be identical (this is the kernel where a reduction race
+    once hid behind lucky timing).  `tiny_work_list` / `global_tables` lower the thresholds (rhccq_ctx_set_int) so that
+    the paths of very large problems -- per-candidate evaluation when the shared work list overflows, block tables in
+    global memory -- run on inputs the oracle can check."""
     if path == "global_tables":
         rh.set_option(rh.OPT_INIT_LDS_BLOCKS, 8)
-    elif path == "tiny_work_list":
+    if path.endswith("tiny_work_list"):
         rh.set_option(rh.OPT_INIT_MAX_ITEMS, 24)
+    if path.startswith("first_generation"):
+        rh.set_option(rh.OPT_INIT_KERNEL, 1)
     try:
         _init_chain_cases(rh, O)
     finally:
         rh.set_option(rh.OPT_INIT_LDS_BLOCKS, 4096)
         rh.set_option(rh.OPT_INIT_MAX_ITEMS, 12288)
+        rh.set_option(rh.OPT_INIT_KERNEL, 0)
 
 
 def _init_chain_cases(rh, O):
     import math
     rng = np.random.default_rng(123)
     cases = []
-    for n, hi, k in ((12000, 256, 130), (30000, 256, 900), (45000, 96, 2500), (20000, 40, 400), (70000, 256, 4200)):
+    for n, hi, k in ((12000, 256, 130), (30000, 256, 900), (45000, 96, 2500), (20000, 40, 400), (70000, 256, 4200), (400000, 256, 9000)):
         P = np.unique(rng.integers(0, hi, (n, 3)).astype(np.uint8), axis=0)
         if len(P) >= 10000:
             cases.append((P, k))
     labs, info = rh.minibatch_kmeans([O.pack_rgb(P) for P, _ in cases], [k for _, k in cases], return_info=True)
     for i, (P, k) in enumerate(cases):
         n = len(P)
-        rs = np.random.RandomState(42)
-        init_size = 3000 if 3000 >= k else 3 * k          # sklearn: 3 * batch_size, or 3 * k when that is < k
-        init_size = min(init_size, n)
-        rs.randint(0, n, init_size)
-        ii = rs.randint(0, n, init_size) if init_size < n else np.arange(n)     # sklearn's draw order
-        want = O.kmeanspp_int(P[ii].astype(np.int64), k, rs)
+        if i == 0:                                         # the numpy statement once, the native one (same picks, G11) for the rest
+            rs = np.random.RandomState(42)
+            init_size = 3000 if 3000 >= k else 3 * k      # sklearn: 3 * batch_size, or 3 * k when that is < k
+            init_size = min(init_size, n)
+            rs.randint(0, n, init_size)
+            ii = rs.randint(0, n, init_size) if init_size < n else np.arange(n)     # sklearn's draw order
+            want = O.kmeanspp_int(P[ii].astype(np.int64), k, rs)
+        else:
+            want, _ = O.kmeanspp_picks_native(P, k)
         got = info["chosen"][info["koff"][i]:info["koff"][i + 1]]
         assert np.array_equal(got, want), (i, n, k, int(np.argmax(got != want)))
 
