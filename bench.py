@@ -1,23 +1,33 @@
 #!/usr/bin/env python3
 """bench.py -- Mpixels/s of the RHCCQ encoder hot path on MI355X (BASELINE.json metric).
 
-A "step" = one pass of the hot path over one synthetic 3840x2160 RGB frame resident in HBM
-(BASELINE.json configs[1]): per-segment unique colours -> three-level palette clustering (level 1 /
-level 2 / level 3 of rhccq.ipynb:978-1039) -> final palette + index map, followed by the
-DCT/quantisation EXTENSION tile (8x8 blocks, two-tier ROI/background steps) that BASELINE.json's
-metric names but the reference does not contain; the extension is inside the timed
-region so that no named work is skipped, and its share is reported in `stages_ms`.
+A "step" = one pass of the hot path over one batch of synthetic input resident in HBM.  Three workloads (--mode):
 
-Multi-GPU: frames are independent (SURVEY.md 8e "frame-parallel"): every rank encodes its own frame,
-no data-path collective; value = pixels of all ranks / max-over-ranks time ("weak" scaling).
+  frame   (default; BASELINE.json configs[1]) one 3840x2160 RGB frame per GPU: per-segment unique colours ->
+          three-level palette clustering (rhccq.ipynb:978-1039) -> final palette + index map, followed by the
+          DCT/quantisation EXTENSION tile (8x8, two-tier ROI/background steps) that BASELINE.json's metric names
+          but the reference does not contain; the extension is inside the timed region so that no
+          named work is skipped, its share is reported in `stages_ms`.  Frames are independent: every rank encodes its
+          own frame, no data-path collective; value = pixels of all ranks / max-over-ranks time ("weak").
+  tiled   (configs[3]) ONE 7680x4320 frame cut into one tile per GPU (2x4 at 8 GPUs), pixels stay tile-local, palettes
+          are exchanged: 1 all-gather (segment bitmaps + stats) + up to 3 small MIN all-reduces over RCCL
+          (parallel.TiledFrameEncoder); value = frame pixels / max-over-ranks time ("strong").
+  stream  (configs[4]) a stream of 4K frames per GPU through stream.StreamEncoder (batches in flight on host threads
+          with their own HIP streams), 16x16 DCT extension, two quality tiers; value = pixels of all ranks / time ("weak").
 
-    python bench.py --gpus 1 --steps 3 --warmup 1
-    python -m torch.distributed.run --nnodes=1 --nproc-per-node N --master-addr 127.0.0.1 \
-        --master-port P bench.py --gpus N --steps K --warmup W
+    python bench.py [--gpus N] [--steps K] [--warmup W] [--mode frame|tiled|stream]
+
+With --gpus N > 1 and no torch.distributed environment the script starts the N ranks itself (torch.distributed.run on
+127.0.0.1) BEFORE anything touches a GPU, and exits with their code; the driver's own launch line
+    python -m torch.distributed.run --nnodes=1 --nproc-per-node N --master-addr 127.0.0.1 --master-port P bench.py --gpus N ...
+is taken as is.  A --gpus that does not match WORLD_SIZE, or more ranks than devices, is an error (exit 2), never a silent
+single-GPU run.
 """
 import argparse
 import json
 import os
+import socket
+import subprocess
 import sys
 import time
 
@@ -27,19 +37,70 @@ ROOT = os.path.dirname(os.path.abspath(__file__))
 sys.path.insert(0, ROOT)
 
 HBM_PEAK_GBS = 8000.0            # MI355X HBM3E spec peak (MI355X_MICROARCH.md)
+VALU_PEAK_TOPS = 157.3           # fp32 / int32 vector peak of the chip (MI355X_MICROARCH.md), for the brute-force equivalent
+N_CUS = 256
 
 
-def build_inputs(rh, H, W, seed, tiles, q_roi, q_non, sigma):
+def parse():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=3)
+    ap.add_argument("--warmup", type=int, default=2)
+    ap.add_argument("--mode", choices=["frame", "tiled", "stream"], default="frame")
+    ap.add_argument("--height", type=int, default=None)
+    ap.add_argument("--width", type=int, default=None)
+    ap.add_argument("--quality", type=int, default=20, help="ROI quality tier (configs[1]: the only tier)")
+    ap.add_argument("--quality-bg", type=int, default=None, help="background tier (stream / tiled modes default to 10: rhccq_20_10)")
+    ap.add_argument("--sigma", type=float, default=2.0, help="sensor-noise sigma of the synthetic photo")
+    ap.add_argument("--block", type=int, default=None, help="DCT extension block (8; 16 in stream mode)")
+    ap.add_argument("--cpu-sample", type=int, default=1280, help="edge of the CPU-baseline crop (0 = skip)")
+    ap.add_argument("--no-probes", action="store_true")
+    ap.add_argument("--frames-per-step", type=int, default=None,
+                    help="frames encoded together per step and GPU (frame mode: 1 = configs[1]; stream mode: 16)")
+    ap.add_argument("--lanes", type=int, default=None, help="stream mode: batches in flight on this many host threads (3)")
+    return ap.parse_args()
+
+
+def self_launch(args):
+    """--gpus N without a torch.distributed environment: start the N ranks (before any GPU call) and relay their exit code"""
+    import torch
+    have = torch.cuda.device_count()                      # does not initialise the GPU on this image
+    if have < args.gpus:
+        sys.stderr.write(f"bench.py: --gpus {args.gpus} but only {have} device(s) are visible\n")
+        sys.exit(2)
+    s = socket.socket()
+    s.bind(("127.0.0.1", 0))
+    port = s.getsockname()[1]
+    s.close()
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", f"--nproc-per-node={args.gpus}", "--master-addr", "127.0.0.1",
+           "--master-port", str(port), os.path.abspath(__file__)] + sys.argv[1:]
+    env = dict(os.environ, HSA_ENABLE_IPC_MODE_LEGACY=os.environ.get("HSA_ENABLE_IPC_MODE_LEGACY", "0"))
+    sys.exit(subprocess.call(cmd, env=env))
+
+
+def build_inputs(rh, H, W, seed, tiles, q_roi, q_non, sigma, tile=None):
+    """synthetic frame + class label maps on the device; `tile` = (r0, c0, h, w) keeps only that window (tiled mode)"""
     import torch
     from roibasedimagecompression_amd import synth
     from roibasedimagecompression_amd.frame import ClassSpec
     img = synth.photo(H, W, seed, sigma=sigma)
     (lr, nr, br), (ln, nn, bn) = synth.frame_classes(H, W, tiles)
-    rgb = torch.from_numpy(img).to(rh.device)
-    specs = [ClassSpec(torch.from_numpy(lr).to(rh.device), np.zeros(nr, np.int64), [br], q_roi),
-             ClassSpec(torch.from_numpy(ln).to(rh.device), np.zeros(nn, np.int64), [bn], q_non)]
-    roi_mask = torch.from_numpy((lr > 0).astype(np.uint8)).to(rh.device)
+    if tile is not None:
+        r0, c0, h, w = tile
+        sl = (slice(r0, r0 + h), slice(c0, c0 + w))
+        img_d, lr_d, ln_d = (np.ascontiguousarray(a[sl]) for a in (img, lr, ln))
+    else:
+        img_d, lr_d, ln_d = img, lr, ln
+    rgb = torch.from_numpy(img_d).to(rh.device)
+    specs = [ClassSpec(torch.from_numpy(lr_d).to(rh.device), np.zeros(nr, np.int64), [br], q_roi),
+             ClassSpec(torch.from_numpy(ln_d).to(rh.device), np.zeros(nn, np.int64), [bn], q_non)]
+    roi_mask = torch.from_numpy((lr_d > 0).astype(np.uint8)).to(rh.device)
     return img, rgb, specs, roi_mask, (lr, ln, br, bn)
+
+
+def dct_ext(rh, rgb, roi_mask, block):
+    luma, qstep = rh.luma_qstep(rgb, roi_mask, block, 4.0, 16.0)
+    return rh.dct_quant(luma, block, qstep, want_coef=False)
 
 
 def one_step(rh, enc, rgb, specs, roi_mask, block, stage_acc=None, extra=()):
@@ -47,31 +108,26 @@ def one_step(rh, enc, rgb, specs, roi_mask, block, stage_acc=None, extra=()):
     batch, --frames-per-step) and the DCT/quantisation extension of every frame"""
     import torch
     if extra:
-        outs = enc.encode_batch([(rgb, specs)] + [(r, sp) for r, sp, _ in extra])
-        out = outs[0]
+        out = enc.encode_batch([(rgb, specs)] + [(r, sp) for r, sp, _ in extra])[0]
     else:
         out = enc.encode(rgb, specs)
     t0 = time.perf_counter()
-    luma, qstep = rh.luma_qstep(rgb, roi_mask, block, 4.0, 16.0)
-    coef, q = rh.dct_quant(luma, block, qstep, want_coef=False)
+    dct_ext(rh, rgb, roi_mask, block)
     for r, sp, m in extra:
-        l2, q2 = rh.luma_qstep(r, m, block, 4.0, 16.0)
-        rh.dct_quant(l2, block, q2, want_coef=False)
+        dct_ext(rh, r, m, block)
     if stage_acc is not None:
         torch.cuda.synchronize()
         for k, v in enc.timings.items():
             stage_acc[k] = stage_acc.get(k, 0.0) + v
         stage_acc["dct_ext"] = stage_acc.get("dct_ext", 0.0) + (time.perf_counter() - t0)
-    return out, q
+    return out
 
 
-def roofline_probe(rh, rgb, specs, iters=5):
+# ---- probes -------------------------------------------------------------------------------------------------------
+def hbm_probe(rh, rgb, specs, iters=5):
     """HIP-event timing (events recorded on the stream the kernel is launched on) of the heaviest HBM-streaming
     kernel of the path, job_scan_kernel<true> (K0 + K1a: one read of RGB + every class label map, one byte flag
-    per pixel): `iters` launches on cleared flags, as in a real frame.  `rh.scan_events` also brackets every
-    in-frame launch of the process; those brackets are reported separately because an event recorded right
-    behind the 64 MiB flag memset adds its own packet latency (~100 us) to the kernel time.  `rocprofv3
-    --kernel-trace --stats` of the default command (profiles/) averages all launches: 143.7 us over 12."""
+    per pixel): `iters` launches on cleared flags, as in a real frame."""
     import torch
     H, W = int(rgb.shape[0]), int(rgb.shape[1])
     labels = [c.labels for c in specs]
@@ -83,30 +139,30 @@ def roofline_probe(rh, rgb, specs, iters=5):
         rh.job_scan(rgb, labels, job_base, bitmaps, stats, black_is_colour=False)
     torch.cuda.synchronize()
     times = [e0.elapsed_time(e1) * 1e-3 for e0, e1 in rh.scan_events]
-    t_all = float(np.mean(times))                   # brackets of in-frame launches also hold the event packets' own latency
     t = float(np.mean(times[n_before:]))            # back-to-back launches: bracket == kernel time (rocprofv3 agrees to ~1 %)
-    px = H * W
-    algo_bytes = px * (3 + 4 * len(specs))          # RGB + one int32 label per class, read once
+    algo_bytes = H * W * (3 + 4 * len(specs))       # RGB + one int32 label per class, read once
     # HBM traffic per launch from the PMC passes kept under profiles/ (separate FETCH_SIZE / WRITE_SIZE runs of
     # this command; FETCH_SIZE doubled as MI355X_MICROARCH.md prescribes for wide coalesced reads on gfx950)
     traffic = None
-    pmc = os.path.join(ROOT, "profiles", "r01_pmc_fetch_write_kb.json")
-    if os.path.exists(pmc):
-        rec = json.load(open(pmc)).get("void rhccq::job_scan_kernel<true>")
-        if rec and H * W == 3840 * 2160:
-            traffic = (2 * rec["FETCH_SIZE"]["mean"] + rec["WRITE_SIZE"]["mean"]) * 1024
+    for name in ("r02_pmc_fetch_write_kb.json", "r01_pmc_fetch_write_kb.json"):
+        pmc = os.path.join(ROOT, "profiles", name)
+        if os.path.exists(pmc) and H * W == 3840 * 2160:
+            rec = json.load(open(pmc)).get("void rhccq::job_scan_kernel<true>")
+            if rec:
+                traffic = (2 * rec["FETCH_SIZE"]["mean"] + rec["WRITE_SIZE"]["mean"]) * 1024
+                break
     return {"bound": "hbm", "kernel": "job_scan_kernel<true>", "achieved": algo_bytes / t / 1e9, "peak": HBM_PEAK_GBS,
             "unit": "GB/s", "frac": algo_bytes / t / 1e9 / HBM_PEAK_GBS, "traffic": traffic,
             "algorithmic_bytes_per_launch": algo_bytes, "avg_launch_s": t, "launches": iters,
-            "avg_event_bracket_s_all_launches": t_all, "all_launches": len(times),
-            "note": "per-pixel passes are < 0.3 % of the step; the step is bound by the sequential k-means++ chain "
-                    "(dominant_kernel); HIP-event brackets include the dispatch latency onto an idle stream (~15-25 us "
-                    "above the kernel time rocprofv3 reports)"}
+            "share_of_step_gpu_time": "< 0.1 %: the per-pixel passes (scan, index, remap) are ~0.9 ms of the step"}
 
 
 def chain_probe(rh, enc, rgb, specs, ms_per_step):
-    """The kernel that dominates the step: mbk_init_kernel, the sequential k-means++ chain of the level-1
-    MiniBatchKMeans problems (one workgroup per segment palette).  HIP events around its launch."""
+    """The kernel that dominates the step: the sequential k-means++ chain of the level-1 MiniBatchKMeans problems (one
+    workgroup per segment palette), HIP events around its launch.  Neither HBM nor MFMA bounds it: each pick depends on the
+    previous one, and one pick is a chain of LDS / L2 round trips and ~10^3 instructions per wave on ONE CU.  Reported as the
+    brute-force-equivalent rate: sum over picks of T candidates x init_size samples pair evaluations (8 integer ops each,
+    SURVEY.md 8d) against the chip's vector peak -- the kernel prunes, so what it really issues is lower still."""
     import math
     S = enc.prepare(rgb, specs)
     jobs, _ = enc.level1_jobs(S)
@@ -122,10 +178,15 @@ def chain_probe(rh, enc, rgb, specs, ms_per_step):
         return None
     t = {}
     rh.minibatch_kmeans(parts, ks, return_device=True, timing=t)
-    return {"kernel": "mbk_init_kernel", "launch_ms": t["init_ms"], "problems": len(ks), "picks_longest_chain": max(ks),
+    pairs = sum((k - 1) * (2 + int(math.log(k))) * max(3 * k, 3000) for k in ks)
+    ops = 8.0 * pairs
+    sec = t["init_ms"] * 1e-3
+    return {"bound": "valu-latency", "kernel": "mbk_init2_kernel", "launch_ms": t["init_ms"], "problems": len(ks), "picks_longest_chain": max(ks),
             "us_per_pick": t["init_ms"] * 1e3 / max(ks), "share_of_step": t["init_ms"] / ms_per_step,
-            "bound": "one workgroup per problem; each pick depends on the previous one; the per-pick time is the "
-                     "instruction issue of one CU over ~1000 instructions per wave (DESIGN.md section 3)"}
+            "brute_force_pair_evaluations": pairs, "achieved": ops / sec / 1e12, "peak": VALU_PEAK_TOPS, "unit": "Tops/s (brute-force equivalent)",
+            "frac": ops / sec / 1e12 / VALU_PEAK_TOPS, "cus_occupied": len(ks), "cus": N_CUS,
+            "note": "one workgroup per problem; the chain cannot leave its CU: the per-pick time (search -> enumerate -> evaluate -> commit, "
+                    "4 barriers, 2 L2 round trips) sets the step, not throughput"}
 
 
 def pixel_probe(rh, rgb, iters=10):
@@ -168,19 +229,47 @@ def neighbour_probe(rh):
         rh.eps_components(keys, [eps] * len(keys))
         t = time.perf_counter() - t0
         n = sum(len(k) for k in keys)
-        out[str(eps)] = {"palettes": len(keys), "points": n, "wall_s_incl_h2d": t, "GB_s_7B_per_point": 7 * n / t / 1e9}
+        out[str(eps)] = {"palettes": len(keys), "points": n, "wall_s_incl_h2d": t, "GB_s_7B_per_point": 7 * n / t / 1e9,
+                         "pair_tests_per_s": sum(len(k) * (len(k) - 1) / 2 for k in keys) / t}
     return out
 
 
-def cpu_baseline(img, lab_roi, lab_non, size, q):
-    """The oracle (kind 'port', numpy, 1 thread of the host) on a bounded crop of the same frame and
-    label maps: same stage boundaries (unique -> 3 levels -> final palette + indices)."""
+def host_cores():
+    """cores this process may really use: the affinity mask, cut by the cgroup CPU quota (a GPU box hands a 1-GPU job a share
+    of a large host: OpenMP threads beyond the quota only spin against each other)"""
+    n = os.cpu_count() or 1
+    try:
+        n = len(os.sched_getaffinity(0))
+    except Exception:
+        pass
+    for path in ("/sys/fs/cgroup/cpu.max", "/sys/fs/cgroup/cpu/cpu.cfs_quota_us"):
+        try:
+            txt = open(path).read().split()
+            if path.endswith("cpu.max"):
+                if txt[0] != "max":
+                    n = min(n, max(1, int(int(txt[0]) / int(txt[1]))))
+            else:
+                q = int(txt[0])
+                if q > 0:
+                    n = min(n, max(1, q // int(open("/sys/fs/cgroup/cpu/cpu.cfs_period_us").read())))
+            break
+        except Exception:
+            continue
+    return max(1, min(n, 32))
+
+
+def cpu_baseline(img, lab_roi, lab_non, size, qs):
+    """The CPU restatement (kind 'port': oracle/, numpy + the native C pieces oracle/mbk_oracle.c, km64_estep.c) on a bounded
+    centre crop of the same frame and label maps, same stage boundaries (unique -> 3 levels -> final palette + indices), timed
+    with one thread and with all host cores (OpenMP over the MiniBatchKMeans / KMeans E-steps and the k-means++ candidates;
+    the numpy bookkeeping between them stays single-threaded)."""
+    os.environ.setdefault("OMP_WAIT_POLICY", "PASSIVE")   # before libgomp loads: idle threads sleep instead of spinning
     from oracle import rhccq_oracle as O
     H, W = img.shape[:2]
     r0, c0 = (H - size) // 2, (W - size) // 2
     crop = img[r0:r0 + size, c0:c0 + size]
-    classes = []
-    for lab in (lab_roi, lab_non):
+    classes, q_used = [], []
+    for lab, q in zip((lab_roi, lab_non), qs):
         l = lab[r0:r0 + size, c0:c0 + size]
         m = l > 0
         if not m.any():
@@ -192,86 +281,113 @@ def cpu_baseline(img, lab_roi, lab_non, size, q):
         bbox = (int(rows.min()), int(cols.min()), int(rows.max()) + 1, int(cols.max()) + 1)
         sl = (slice(bbox[0], bbox[2]), slice(bbox[1], bbox[3]))
         classes.append([{"bbox": bbox, "bbox_mask": m[sl], "seglabels": l2[sl].astype(np.int32)}])
-    t0 = time.perf_counter()
-    O.encode_frame(crop, classes, [q] * len(classes))
-    dt = time.perf_counter() - t0
-    return {"value": size * size / dt / 1e6, "unit": "Mpixels/s", "cores": 1, "kind": "port",
-            "sample": f"centre {size}x{size} crop of the same synthetic frame and label maps, numpy oracle, {dt:.1f} s"}
+        q_used.append(q)
+    nproc = host_cores()
+    model = next((ln.split(":", 1)[1].strip() for ln in open("/proc/cpuinfo") if ln.startswith("model name")), "?")
+    legs = {}
+    for threads in (nproc, 1):
+        t0 = time.perf_counter()
+        O.encode_frame(crop, classes, q_used, minibatch=lambda pts, k, th=threads: O.minibatch_kmeans_native(pts, k, threads=th)[0])
+        legs[threads] = time.perf_counter() - t0
+        if nproc == 1:
+            break
+    dt = legs[nproc]
+    return {"value": size * size / dt / 1e6, "unit": "Mpixels/s", "cores": nproc, "kind": "port", "cpu_model": model, "nproc": nproc,
+            "sample": f"centre {size}x{size} crop of the same synthetic frame and label maps, native C (OpenMP) + numpy restatement, {dt:.1f} s",
+            "one_thread": {"value": size * size / legs[1] / 1e6, "unit": "Mpixels/s", "cores": 1, "seconds": round(legs[1], 1)},
+            "reference_cpu_of_record": {"value": 0.046, "unit": "Mpixels/s", "cores": 8,
+                                        "what": "the reference itself (sklearn 1.7.2) in the build container, whole Lenna 512x512 as one segment, "
+                                                "N = 148 279 colours, k = 2 966 (BASELINE.md section 3); 0.0060 Mpixels/s for its 64-segment notebook path"}}
 
 
+# ---- main -----------------------------------------------------------------------------------------------------------
 def main():
-    ap = argparse.ArgumentParser()
-    ap.add_argument("--gpus", type=int, default=1)
-    ap.add_argument("--steps", type=int, default=3)
-    ap.add_argument("--warmup", type=int, default=2)
-    ap.add_argument("--height", type=int, default=2160)
-    ap.add_argument("--width", type=int, default=3840)
-    ap.add_argument("--quality", type=int, default=20, help="one ROI quality tier (configs[1])")
-    ap.add_argument("--sigma", type=float, default=2.0, help="sensor-noise sigma of the synthetic photo")
-    ap.add_argument("--block", type=int, default=8)
-    ap.add_argument("--cpu-sample", type=int, default=576, help="edge of the CPU-baseline crop (0 = skip)")
-    ap.add_argument("--no-probes", action="store_true")
-    ap.add_argument("--frames-per-step", type=int, default=1,
-                    help="frames encoded together per step (default 1 = BASELINE configs[1], a single frame; > 1 is the "
-                         "stream / batch regime of configs[2] and [4]: one batched clustering launch per level)")
-    ap.add_argument("--stream-probe", action="store_true",
-                    help="also time 48 frames in the stream regime (3 lanes x batches of 8) and report it as `stream_regime`; "
-                         "off by default so that every job_scan launch of the default command belongs to the single-frame workload "
-                         "(the population the roofline object and the committed rocprof summary average)")
-    ap.add_argument("--lanes", type=int, default=1,
-                    help="stream regime: batches of --frames-per-step frames in flight on this many host threads, each with "
-                         "its own HIP stream (stream.StreamEncoder); a step is then lanes x frames-per-step frames")
-    args = ap.parse_args()
-
-    import torch
-    import torch.distributed as dist
-    world = int(os.environ.get("WORLD_SIZE", "1"))
+    args = parse()
+    env_world = os.environ.get("WORLD_SIZE")
+    if env_world is None and args.gpus > 1:
+        self_launch(args)                                  # does not return
+    world = int(env_world or "1")
     rank = int(os.environ.get("RANK", "0"))
     local = int(os.environ.get("LOCAL_RANK", "0"))
     rehearsal = os.environ.get("RHCCQ_BENCH_REHEARSAL") == "1"     # several ranks on ONE GPU over gloo: exercises the
-    if rehearsal:                                                   # launch path on a one-GPU box, never a bench line
+    if world != args.gpus and not rehearsal:                       # launch path on a one-GPU box, never a bench line
+        sys.stderr.write(f"bench.py: --gpus {args.gpus} does not match WORLD_SIZE={world}\n")
+        sys.exit(2)
+    import roibasedimagecompression_amd  # noqa: F401  (sets GPU_MAX_HW_QUEUES before the HIP runtime starts)
+    import torch
+    import torch.distributed as dist
+    if rehearsal:
         local = 0
     if world > 1:
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        if not rehearsal and torch.cuda.device_count() < world:
+            sys.stderr.write(f"bench.py: {world} ranks but {torch.cuda.device_count()} device(s)\n")
+            sys.exit(2)
         torch.cuda.set_device(local)
         if rehearsal:
             dist.init_process_group("gloo")
         else:
             dist.init_process_group("nccl", device_id=torch.device("cuda", local))
-    from roibasedimagecompression_amd.ops import Rhccq
     from roibasedimagecompression_amd.frame import FrameEncoder
+    from roibasedimagecompression_amd.ops import Rhccq
     Rhccq.scan_events = []          # class-wide: the lanes of the stream regime own their own contexts
     rh = Rhccq(local)
-    enc = FrameEncoder(rh)
-    H, W = args.height, args.width
-    # at >= 4K the reference's SLIC scaling yields <= 2 segments per region (SURVEY.md 8a preface)
-    B = max(1, args.frames_per_step)
-    img, rgb, specs, roi_mask, (lr, ln, br, bn) = build_inputs(rh, H, W, 1234 + rank * B, (2, 1), args.quality, args.quality, args.sigma)
-    extra = []
-    for i in range(1, B):
-        _, r_i, sp_i, m_i, _ = build_inputs(rh, H, W, 1234 + rank * B + i, (2, 1), args.quality, args.quality, args.sigma)
-        extra.append((r_i, sp_i, m_i))
+    mode = args.mode
+    H = args.height or (4320 if mode == "tiled" else 2160)
+    W = args.width or (7680 if mode == "tiled" else 3840)
+    block = args.block or (16 if mode == "stream" else 8)
+    q_roi = args.quality
+    q_bg = args.quality_bg if args.quality_bg is not None else (args.quality if mode == "frame" else 10)
+    B = args.frames_per_step or (16 if mode == "stream" else 1)
+    L = args.lanes or (3 if mode == "stream" else 1)
 
     def barrier():
         if world > 1:
             dist.barrier()
         torch.cuda.synchronize()
 
-    L = max(1, args.lanes)
-    if L > 1:
-        # stream regime with several batches in flight: the timed region is ONE run over steps x lanes batches
+    stages, out, enc = {}, None, None
+    if mode == "tiled":
+        # configs[3]: one frame, one tile per rank; rows x cols as square as the rank count allows (2 x 4 at 8 ranks)
+        from roibasedimagecompression_amd.parallel import TiledFrameEncoder, tile_grid
+        rows = max(r for r in (1, 2, 3, 4) if world % r == 0 and r * r <= world)
+        tiles = tile_grid(H, W, rows, world // rows)
+        img, rgb, specs, roi_mask, (lr, ln, br, bn) = build_inputs(rh, H, W, 1234, (2, 1), q_roi, q_bg, args.sigma, tile=tiles[rank])
+        enc = TiledFrameEncoder(rh, (H, W), tiles[rank]).set_tiles(tiles) if world > 1 else FrameEncoder(rh)
+
+        def step():
+            o = enc.encode(rgb, specs)
+            dct_ext(rh, rgb, roi_mask, block)
+            return o
+        for _ in range(args.warmup):
+            step()
+        barrier()
+        t0 = time.perf_counter()
+        for _ in range(args.steps):
+            out = step()
+        barrier()
+        dt = time.perf_counter() - t0
+        px = H * W * args.steps
+        workload = (f"configs[3]: single {W}x{H} RGB synthetic 'photo' frame (seed 1234, sigma={args.sigma}) cut into {rows}x{world // rows} tiles, one per GPU; "
+                    f"quality tiers ({q_roi},{q_bg}), 2 segments per class; exchange = 1 all-gather (segment bitmaps + stats) + MIN all-reduces of "
+                    f"palette-sized first-position tables over {'RCCL' if not rehearsal else 'gloo'}; {block}x{block} DCT extension per tile")
+        scaling, par = "strong", f"tile-parallel {rows}x{world // rows}"
+    elif mode == "stream":
+        # configs[4]: a stream of 4K frames per GPU, batches of B frames, L batches in flight
         from roibasedimagecompression_amd.stream import StreamEncoder
-        from roibasedimagecompression_amd.frame import ClassSpec  # noqa: F401
-        batch_frames = [(rgb, specs)] + [(r, sp) for r, sp, _ in extra]
-        masks = [roi_mask] + [m for _, _, m in extra]
+        frames, masks = [], []
+        for i in range(B):
+            img, r_i, sp_i, m_i, (lr, ln, br, bn) = build_inputs(rh, H, W, 1234 + rank * B + i, (2, 1), q_roi, q_bg, args.sigma)
+            frames.append((r_i, sp_i))
+            masks.append(m_i)
+        rgb, specs = frames[0]
         se = StreamEncoder(local, batch=B, lanes=L)
 
         def run(n_steps):
-            outs = se.run(batch_frames * (L * n_steps))
-            for _ in range(L * n_steps):                        # the DCT extension of every frame, as in one_step
-                for (r, _), m in zip(batch_frames, masks):
-                    l2, q2 = rh.luma_qstep(r, m, args.block, 4.0, 16.0)
-                    rh.dct_quant(l2, args.block, q2, want_coef=False)
+            outs = se.run(frames * (L * n_steps))
+            for _ in range(L * n_steps):
+                for (r, _), m in zip(frames, masks):
+                    dct_ext(rh, r, m, block)
             return outs
         run(max(args.warmup, 1))
         barrier()
@@ -279,73 +395,66 @@ def main():
         out = run(args.steps)[0]
         barrier()
         dt = time.perf_counter() - t0
-        B = B * L
+        px = H * W * args.steps * world * B * L
+        workload = (f"configs[4]: stream of {B * L * args.steps} {W}x{H} RGB synthetic 'photo' frames per GPU ({B} distinct frames, seeds 1234+rank*{B}+i, "
+                    f"sigma={args.sigma}) through StreamEncoder: batches of {B}, {L} in flight; quality tiers ({q_roi},{q_bg}), three-level palette "
+                    f"hierarchy, {block}x{block} DCT extension")
+        scaling, par = "weak", f"frame-parallel x{world}, {L} lanes x batch {B}"
     else:
+        enc = FrameEncoder(rh)
+        img, rgb, specs, roi_mask, (lr, ln, br, bn) = build_inputs(rh, H, W, 1234 + rank * B, (2, 1), q_roi, q_bg, args.sigma)
+        extra = []
+        for i in range(1, B):
+            _, r_i, sp_i, m_i, _ = build_inputs(rh, H, W, 1234 + rank * B + i, (2, 1), q_roi, q_bg, args.sigma)
+            extra.append((r_i, sp_i, m_i))
         for _ in range(args.warmup):
-            one_step(rh, enc, rgb, specs, roi_mask, args.block, extra=extra)
+            one_step(rh, enc, rgb, specs, roi_mask, block, extra=extra)
         barrier()
         t0 = time.perf_counter()
-        out = None
         for _ in range(args.steps):
-            out, q = one_step(rh, enc, rgb, specs, roi_mask, args.block, extra=extra)
+            out = one_step(rh, enc, rgb, specs, roi_mask, block, extra=extra)
         barrier()
         dt = time.perf_counter() - t0
+        if rank == 0:
+            one_step(rh, enc, rgb, specs, roi_mask, block, stage_acc=stages, extra=extra)
+        px = H * W * args.steps * world * B
+        workload = ((f"configs[1]: single {W}x{H} RGB synthetic 'photo' frame per GPU (seed 1234+rank, sigma={args.sigma}), " if B == 1 else
+                     f"batch of {B} {W}x{H} RGB synthetic 'photo' frames per GPU per step (seeds 1234+rank*{B}+i, sigma={args.sigma}), ")
+                    + (f"one quality tier q={q_roi} (levels {q_roi}/{min(2 * q_roi, 100)}/{min(4 * q_roi, 100)}), " if q_roi == q_bg else f"quality tiers ({q_roi},{q_bg}), ")
+                    + f"2 segments per class, ROI ellipse 35 % + 3 px overlap; {block}x{block} DCT + two-tier quantisation extension in the timed region")
+        scaling, par = "weak", f"frame-parallel x{world}"
     if world > 1:
         t = torch.tensor([dt], dtype=torch.float64, device=rh.device)
+        if rehearsal:
+            t = t.cpu()
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
         dt = float(t.item())
-    stages = {}
-    if rank == 0:
-        one_step(rh, enc, rgb, specs, roi_mask, args.block, stage_acc=stages, extra=extra)
-    px = H * W * args.steps * world * B
     line = {
-        "metric": "Mpixels/s encoded (ROI cluster + DCT/quant) at 4K RGB",
+        "metric": "Mpixels/s encoded (ROI cluster + DCT/quant) at 4K RGB" if mode != "tiled" else "Mpixels/s encoded (ROI cluster + DCT/quant), one 8K RGB frame tiled over the GPUs",
         "value": px / dt / 1e6, "unit": "Mpixels/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
-        "ms_per_step": dt / args.steps * 1e3, "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
+        "ms_per_step": dt / args.steps * 1e3, "higher_is_better": True, "scaling": scaling, "vs_baseline": None,
         "dtype": "u8 keys / int32 exact k-means++ / f64 Lloyd+mini-batch", "data": "synthetic" + (" (REHEARSAL: ranks share one GPU)" if rehearsal else ""),
-        "config": {"workload": (f"configs[1]: single {W}x{H} RGB synthetic 'photo' frame per GPU (seed 1234+rank, sigma={args.sigma}), " if B == 1 else
-                                f"batch of {B} {W}x{H} RGB synthetic 'photo' frames per GPU per step (seeds 1234+rank*{B}+i, sigma={args.sigma}), ")
-                               + f"one quality tier q={args.quality} (levels {args.quality}/{min(2*args.quality,100)}/{min(4*args.quality,100)}), "
-                               "2 segments per class, ROI ellipse 35 % + 3 px overlap; "
-                               f"{args.block}x{args.block} DCT + two-tier quantisation extension in the timed region",
-                   "frames_per_step_per_gpu": B, "lanes": L, "parallelism": f"frame-parallel x{world}"},
+        "config": {"workload": workload, "mode": mode, "frames_per_step_per_gpu": B * L if mode == "stream" else B, "lanes": L, "parallelism": par},
     }
     if rank == 0:
-        line["stages_ms"] = {k: round(v * 1e3, 3) for k, v in stages.items()}
+        if stages:
+            line["stages_ms"] = {k: round(v * 1e3, 3) for k, v in stages.items()}
         line["final_colours"] = int(len(out["palette"]))
         line["unique_colours_per_segment"] = [int(v) for v in out["n_unique"]]
-        if not args.no_probes and world == 1:
-            line["dominant_kernel"] = chain_probe(rh, enc, rgb, specs, dt / args.steps * 1e3 / B)
+        probes = not args.no_probes and world == 1 and mode == "frame" and B == 1
+        roof = hbm_probe(rh, rgb, specs) if mode != "tiled" or world == 1 else None
+        if probes:
+            dom = chain_probe(rh, enc, rgb, specs, dt / args.steps * 1e3)
+            if roof is not None and dom is not None:
+                roof["dominant_kernel"] = dom
             line["neighbour_pass"] = neighbour_probe(rh)
             line["pixel_neighbour_pass_extension"] = pixel_probe(rh, rgb)
-        if args.stream_probe and world == 1 and B == 1 and L == 1:
-            # the same path in the stream regime (configs[4]: many 4K frames on one GPU): batches of 8 frames share one
-            # batched clustering launch per level (the sequential k-means++ chains run side by side) and 3 batches are
-            # in flight on 3 host threads / HIP streams, so one batch's host work hides behind another's GPU work
-            from roibasedimagecompression_amd.stream import StreamEncoder
-            nb, lanes, reps = 8, 3, 6
-            more = [(rgb, specs)]
-            for i in range(1, 2 * nb):
-                _, r_i, sp_i, _, _ = build_inputs(rh, H, W, 1234 + i, (2, 1), args.quality, args.quality, args.sigma)
-                more.append((r_i, sp_i))
-            se = StreamEncoder(local, batch=nb, lanes=lanes)
-            se.run(more + more[:nb])                                            # warm-up: one batch per lane
-            torch.cuda.synchronize()
-            t1 = time.perf_counter()
-            se.run(more * (reps // 2))
-            torch.cuda.synchronize()
-            d1 = time.perf_counter() - t1
-            line["stream_regime"] = {"frames": reps * nb, "frames_per_batch": nb, "lanes": lanes, "value": reps * nb * H * W / d1 / 1e6,
-                                     "unit": "Mpixels/s", "wall_s": d1,
-                                     "note": "palette hierarchy only (no DCT extension); python bench.py --frames-per-step 16 --lanes 4 "
-                                             "times this regime as the main value"}
-            del more
-        line["roofline"] = roofline_probe(rh, rgb, specs)
-        if args.cpu_sample and world == 1:
-            line["cpu_baseline"] = cpu_baseline(img, lr, ln, args.cpu_sample, args.quality)
+        line["roofline"] = roof
+        if args.cpu_sample and world == 1 and mode == "frame":
+            line["cpu_baseline"] = cpu_baseline(img, lr, ln, min(args.cpu_sample, H, W), (q_roi, q_bg))
         else:
             line["cpu_baseline"] = None
-        print(json.dumps(line))
+        print(json.dumps(line), flush=True)
     if world > 1:
         dist.barrier()
         dist.destroy_process_group()

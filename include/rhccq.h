@@ -173,16 +173,20 @@ int rhccq_mt_uniforms(rhccq_ctx* ctx, const uint32_t* words, int64_t pos, int64_
 int rhccq_mbk_init(rhccq_ctx* ctx, const uint32_t* keys, const rhccq_mbk_problem* probs_host,
                    int32_t n_prob, const int32_t* init_idx, const int32_t* perm, const double* rand,
                    double* centres, int32_t* chosen);
-/* run up to n_steps mini-batch steps for every problem that has not stopped; state: double[n_prob][16] =
- * {ewa, ewa_min, no_improvement, since_reassign, done (1 converged, 2 out of steps, 3 word table exhausted: extend
- * `words`, clear the flag, call again), steps_done, have_ewa, have_min, n_zero_weight_centres (initialise to k),
- * MT cursor = raw words consumed so far (initialise to the position behind the k-means++ uniforms), batch_drawn
- * (initialise to 0), reserved...}; weights double[sum k]; words / n_words: raw MT19937(42) words on the device -- a
- * step consumes at most 16 384 of them (a problem stops with done = 3 before a step that could run past the end) */
+/* run mini-batch steps step0 .. step0 + n_steps - 1 for every problem that has not stopped (call with step0 = 0 first, then
+ * with the number of steps launched so far; all problems of a call sequence share the step index).  state:
+ * double[n_prob][16] = {[0] ewa, [1] ewa_min, [2] no_improvement, [3] samples since the last reassignment, [4] why the
+ * problem stopped (0 running, 1 converged, 2 out of steps, 3 word table exhausted -- fatal: size `words` so that it
+ * cannot happen), [5] steps done, [6] have_ewa, [7] have_min, [8] zero-weight centres (initialise to k), [9] MT cursor
+ * = raw words consumed so far (initialise to the position behind the k-means++ uniforms), [10] first batch drawn, [11]
+ * stop_at (steps done when it stopped, 0 while running), [12..14] the odd-step twins of [3], [8], [9] (a step reads the
+ * slots of its parity and writes the other's; after s steps the current values sit in the slots of parity s & 1)};
+ * initialise everything but [8] and [9] to 0.  weights double[sum k]; words / n_words: raw MT19937(42) words on the
+ * device -- a step consumes at most 16 384 of them. */
 int rhccq_mbk_steps(rhccq_ctx* ctx, const uint32_t* keys, const rhccq_mbk_problem* probs_host,
-                    int32_t n_prob, int32_t n_steps, const uint32_t* words, int64_t n_words, double* centres,
-                    double* weights, double* state, void* work, int64_t work_bytes, int32_t estep_mode,
-                    int32_t estep_split);
+                    int32_t n_prob, int64_t step0, int32_t n_steps, const uint32_t* words, int64_t n_words,
+                    double* centres, double* weights, double* state, void* work, int64_t work_bytes,
+                    int32_t estep_mode, int32_t estep_split);
 /* estep_mode: how the batch E-step finds each point's nearest centre -- identical results either way:
  * RHCCQ_ESTEP_TILES brute force over LDS tiles of centres (few problems in flight), RHCCQ_ESTEP_GRID centres
  * re-binned into a 32^3 grid every step and searched ring by ring (many problems in flight: a batch of frames),

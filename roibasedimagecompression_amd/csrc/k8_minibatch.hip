@@ -663,8 +663,6 @@ __global__ __launch_bounds__(kInitThreads) void mbk_init_kernel(const uint32_t* 
 // =====================================================================================================
 // k-means++ chain, second generation.  Same arithmetic and the same picks as init_body() above (both are exact
 // integers); what changes is how one pick is scheduled on the CU, because the chain is bound by instruction issue:
-//   * 8 waves instead of 16, and phases that used one wave per candidate are vectorised ACROSS candidates (the
-//     candidate search runs in 4 waves, 4 candidates each, 16 lanes per candidate at levels 2 and 3);
 //   * enumeration in ONE phase: a (candidate, 64 super-blocks) unit tests its boxes and expands its hits to blocks
 //     on the spot, appending (candidate, block) items to the shared list -- two barriers and one list less;
 //   * evaluation by quarter waves: 16 lanes x 4 samples per item, 4 items per wave instruction stream (half the
@@ -673,10 +671,10 @@ __global__ __launch_bounds__(kInitThreads) void mbk_init_kernel(const uint32_t* 
 //   * the samples a wave evaluated STAY in its registers until the winner is known: the commit needs no second
 //     trip to the L2, and the draw position of every sample travels in the spare bits of its (key, c') pair.
 // =====================================================================================================
-constexpr int kJThreads = 512;
+constexpr int kJThreads = 1024;
 constexpr int kJWaves = kJThreads / 64;
 constexpr int kJMaxItems = 4096;          // (candidate, block) items per pick in LDS; beyond: per-candidate enumeration
-constexpr int kJKeep = 12;                // evaluation instructions (4 items each) a wave keeps in registers
+constexpr int kJKeep = 6;                 // evaluation instructions (4 items each) a wave keeps in registers
 constexpr int kJTouch = 1024;
 
 struct JShared {
@@ -820,7 +818,8 @@ __global__ __launch_bounds__(kJThreads) void mbk_init2_kernel(const uint32_t* __
   __shared__ uint32_t items[kJMaxItems];
   __shared__ int s_touch[2 * kJTouch];
   const MbkP P = probs[blockIdx.x];
-  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const int tid = threadIdx.x, lane = tid & 63;
+  const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);     // wave-uniform BY CONSTRUCTION: loops and branches on it stay scalar
   const int n = (int)P.init_n, k = (int)P.k, T = P.T;
   const int nb = (n + 63) >> 6, np = nb << 6, nsb = (nb + 15) >> 4;
   uint2* samp = reinterpret_cast<uint2*>(scratch + scratch_off[blockIdx.x]);
@@ -880,6 +879,10 @@ __global__ __launch_bounds__(kJThreads) void mbk_init2_kernel(const uint32_t* __
   const int nch = (nsb + 63) >> 6;
   const unsigned long long below = (1ull << lane) - 1ull;
   const int rq = lane >> 4, rj = lane & 15;
+#ifdef RHCCQ_STAMPS
+  unsigned long long _acc[16] = {0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0};
+  unsigned long long _last = clock64();
+#endif
   for (int c = 1; c < k; ++c) {
     // the next pick's uniforms are a cold line in HBM: fetch them now, use them at the end of the pick
     double u_next = 0.0;
@@ -888,124 +891,73 @@ __global__ __launch_bounds__(kJThreads) void mbk_init2_kernel(const uint32_t* __
     if (tid < T) sh.delta[tid] = 0;                      // (read for the arg-max before the previous pick's closing barrier)
     const int* touch_r = s_touch + (((c - 1) & 1) ? kJTouch : 0);
     const int n_touched = min(sh.n_touch2[(c - 1) & 1], kJTouch);
-    // ================= phase 1: the T candidates (waves 0-3, four candidates each) ===========================
-    if (wave < 4) {
-      // np.searchsorted(cumsum(closest), r, 'left') in DRAW order; cum and the targets R = ceil(r) are exact integers
-      unsigned long long Rq[4], baseq[4];
-      int sbq[4], bq[4];
-      bool act[4], fnd[4];
-#pragma unroll
-      for (int q = 0; q < 4; ++q) {
-        const int t = wave + 4 * q;
-        act[q] = t < T;
-        const unsigned long long rv = act[q] ? sh.R[t] : 0ull;
-        Rq[q] = ((unsigned long long)(unsigned)__builtin_amdgcn_readfirstlane((int)(rv >> 32)) << 32) | (unsigned)__builtin_amdgcn_readfirstlane((int)(unsigned)rv);
-        fnd[q] = !act[q] || Rq[q] == 0;                  // R = 0: position 0
-        sbq[q] = 0; baseq[q] = 0; bq[q] = 0;
-      }
-      unsigned long long carry = 0;
-      for (int ch = 0; ch < nch; ++ch) {
-        const int sb = ch * 64 + lane;
-        const unsigned v = sb < nsb ? dssum[sb] : 0u;
-        const unsigned long long inc = carry + wave_incscan_limbs(v);
-        const unsigned long long exc = inc - v;
-#pragma unroll
-        for (int q = 0; q < 4; ++q) {
-          if (!fnd[q]) {
-            const unsigned long long m = __ballot(v > 0 && exc < Rq[q] && Rq[q] <= inc);
-            if (m) {
-              const int l = __ffsll((long long)m) - 1;
-              sbq[q] = ch * 64 + l;
-              baseq[q] = readlane64(exc, l);
-              fnd[q] = true;
+    // ================= phase 1: waves t < T -- candidate t ====================================================
+    if (wave < T) {
+      // np.searchsorted(cumsum(closest), r, 'left') in DRAW order; cum and the target R = ceil(r) are exact integers
+      const int t = wave;
+      const unsigned long long rv = sh.R[t];
+      const unsigned long long R = ((unsigned long long)(unsigned)__builtin_amdgcn_readfirstlane((int)(rv >> 32)) << 32) |
+                                   (unsigned)__builtin_amdgcn_readfirstlane((int)(unsigned)rv);
+      int cand = R == 0 ? 0 : n - 1;                      // R = 0: position 0; a target beyond the total (cannot happen): the last
+      uint32_t ck = 0;
+      bool found = false;
+      if (R != 0) {
+        unsigned long long carry = 0;
+        for (int ch = 0; ch < nch && !found; ++ch) {
+          const int sb = ch * 64 + lane;
+          const unsigned v = sb < nsb ? dssum[sb] : 0u;
+          const unsigned long long inc = carry + wave_incscan_limbs(v);
+          const unsigned long long exc = inc - v;
+          const unsigned long long m1 = __ballot(v > 0 && exc < R && R <= inc);
+          if (m1) {
+            const int l1 = __ffsll((long long)m1) - 1;
+            const int sbh = ch * 64 + l1;
+            const unsigned long long base = readlane64(exc, l1);
+            // level 2: the 16 draw blocks of the super-block
+            const int b2 = sbh * 16 + (lane & 15);
+            const unsigned v2 = (lane < 16 && b2 < nb) ? dsum[b2] : 0u;
+            const unsigned long long cum2 = base + row_incscan_u32(v2);
+            const unsigned long long m2 = __ballot(lane < 16 && v2 > 0 && (cum2 - v2) < R && R <= cum2);
+            if (m2) {
+              const int l2 = __ffsll((long long)m2) - 1;
+              const int bh = sbh * 16 + l2;
+              const unsigned rr = (unsigned)(R - readlane64(cum2 - v2, l2));     // <= the block's sum
+              // level 3: the 64 samples of the draw block
+              const int i = (bh << 6) + lane;
+              const uint2 sv = dsamp[i];
+              const unsigned inc3 = wave_incscan_u32(i < n ? sv.y : 0u);          // 64 x 195075 fits 32 bits
+              const unsigned long long m3 = __ballot(i < n && inc3 >= rr);
+              const int l3 = m3 ? __ffsll((long long)m3) - 1 : min(63, n - 1 - (bh << 6));
+              cand = (bh << 6) + l3;
+              ck = (uint32_t)__builtin_amdgcn_readlane((int)sv.x, l3);
+              found = true;
             }
+            break;
           }
-        }
-        carry = readlane64(inc, 63);
-      }
-      // level 2: the 16 draw blocks of each candidate's super-block, one row of lanes per candidate
-      unsigned long long base2q[4];
-      bool miss[4];
-      {
-        const int my_sb = sel4(rq, sbq);
-        const unsigned long long my_base = sel4(rq, baseq), my_R = sel4(rq, Rq);
-        const bool my_on = sel4(rq, act) && sel4(rq, fnd) && my_R != 0;
-        const int b2 = my_sb * 16 + rj;
-        const unsigned v2 = (my_on && b2 < nb) ? dsum[b2] : 0u;
-        const unsigned long long cum2 = my_base + row_incscan_u32(v2);
-        const unsigned long long m2 = __ballot(my_on && v2 > 0 && (cum2 - v2) < my_R && my_R <= cum2);
-#pragma unroll
-        for (int q = 0; q < 4; ++q) {
-          const unsigned bits = (unsigned)(m2 >> (16 * q)) & 0xffffu;
-          base2q[q] = 0;
-          miss[q] = false;
-          if (act[q] && Rq[q] != 0) {
-            if (fnd[q] && bits) {
-              const int jq = __ffs((int)bits) - 1;
-              bq[q] = sbq[q] * 16 + jq;
-              base2q[q] = readlane64(cum2 - v2, 16 * q + jq);
-            } else {
-              miss[q] = true;                              // target beyond the total (cannot happen): the last sample
-              bq[q] = nb - 1;
-            }
-          }
+          carry = readlane64(inc, 63);
         }
       }
-      // level 3: the 64 samples of the draw block, 4 per lane
-      {
-        const int my_b = sel4(rq, bq);
-        const bool my_on = sel4(rq, act);
-        const unsigned long long my_R = sel4(rq, Rq), my_b2 = sel4(rq, base2q);
-        const unsigned rr = sel4(rq, miss) ? 0xffffffffu : (unsigned)(my_R - my_b2);
-        const int i0 = (my_b << 6) + 4 * rj;
-        uint4 a = make_uint4(0, 0, 0, 0), bb = a;
-        if (my_on) {
-          const uint4* p4 = reinterpret_cast<const uint4*>(dsamp + i0);
-          a = p4[0];
-          bb = p4[1];
-        }
-        const unsigned c0 = i0 < n ? a.y : 0u, c1 = i0 + 1 < n ? a.w : 0u, c2 = i0 + 2 < n ? bb.y : 0u, c3 = i0 + 3 < n ? bb.w : 0u;
-        const unsigned s0 = c0, s1 = s0 + c1, s2 = s1 + c2, s3 = s2 + c3;
-        const unsigned exr = row_incscan_u32(s3) - s3;
-        const int first = (i0 < n && exr + s0 >= rr) ? 0 : (i0 + 1 < n && exr + s1 >= rr) ? 1 : (i0 + 2 < n && exr + s2 >= rr) ? 2
-                          : (i0 + 3 < n && exr + s3 >= rr) ? 3 : 4;
-        const uint32_t fkey = first == 0 ? a.x : first == 1 ? a.z : first == 2 ? bb.x : bb.z;
-        const unsigned long long m3 = __ballot(my_on && first < 4);
-#pragma unroll
-        for (int q = 0; q < 4; ++q) {
-          if (!act[q]) continue;
-          const int t = wave + 4 * q;
-          const unsigned bits = (unsigned)(m3 >> (16 * q)) & 0xffffu;
-          int cand;
-          uint32_t ck;
-          if (bits) {
-            const int l = 16 * q + __ffs((int)bits) - 1;
-            cand = (bq[q] << 6) + 4 * (l & 15) + __builtin_amdgcn_readlane(first, l);
-            ck = (uint32_t)__builtin_amdgcn_readlane((int)fkey, l);
-          } else {
-            cand = min(n - 1, (bq[q] << 6) + 63);
-            ck = dsamp[cand].x;
-          }
-          if (lane == 0) {
-            sh.cand[t] = cand;
-            sh.ckey[t] = ck;
-            sh.cna[t] = norm2_key(ck);
-            const CandP cp = cand_pairs(ck);
-            sh.ckp[t][0] = cp.r; sh.ckp[t][1] = cp.g; sh.ckp[t][2] = cp.b;
-          }
-        }
+      if (!found) ck = dsamp[cand].x;
+      if (lane == 0) {
+        sh.cand[t] = cand;
+        sh.ckey[t] = ck;
+        sh.cna[t] = norm2_key(ck);
+        const CandP cp = cand_pairs(ck);
+        sh.ckp[t][0] = cp.r; sh.ckp[t][1] = cp.g; sh.ckp[t][2] = cp.b;
       }
     } else {
       // the other waves refresh the super-block maxima the previous winner touched (a stale, larger maximum is
       // conservative, so the enumeration may read either value)
-      for (int i = tid - 4 * 64; i < n_touched * 16; i += kJThreads - 4 * 64) {
+      for (int i = tid - T * 64; i < n_touched * 16; i += kJThreads - T * 64) {
         const int sb = touch_r[i >> 4], b = sb * 16 + (i & 15);
         unsigned m = b < nb ? blk[b].w : 0u;
         m = dpp_row_max(m);
         if ((i & 15) == 0) sup[sb].w = m;
       }
     }
+    STAMP(0);
     __syncthreads();
+    STAMP(1);
     // ================= phase 2: which blocks can each candidate improve? =====================================
     // (candidate, 64 super-blocks) units; hits are expanded to blocks at once and appended to the shared item list
     for (int u = wave, t = 0, ch = wave; u < T * nch; u += kJWaves, ch += kJWaves) {
@@ -1022,7 +974,9 @@ __global__ __launch_bounds__(kJThreads) void mbk_init2_kernel(const uint32_t* __
         }
       });
     }
+    STAMP(2);
     __syncthreads();
+    STAMP(3);
     // ================= phase 3: potentials ===================================================================
     const bool use_list = sh.overflow == 0;
     const int n_items = use_list ? sh.n_items : 0;
@@ -1088,7 +1042,14 @@ __global__ __launch_bounds__(kJThreads) void mbk_init2_kernel(const uint32_t* __
         if (lane == 0) sh.delta[t] = acc;
       }
     }
+    STAMP(4);
+#ifdef RHCCQ_STAMPS
+    _acc[10] += (unsigned long long)n_items;
+    _acc[11] += use_list ? (kept ? 0 : 1) : 0;
+    _acc[12] += use_list ? 0 : 1;
+#endif
     __syncthreads();
+    STAMP(5);
     // ================= phase 4: greedy choice + commit =======================================================
     // largest reduction == smallest potential; the first candidate wins ties
     const unsigned long long dv = lane < T ? sh.delta[lane] : 0ull;
@@ -1138,7 +1099,9 @@ __global__ __launch_bounds__(kJThreads) void mbk_init2_kernel(const uint32_t* __
     }
     if (tid == 0) { cho[c] = sh.cand[best]; sh.pot = pot - bd; sh.n_items = 0; sh.overflow = 0; sh.n_touch2[(c + 1) & 1] = 0; }
     if (tid < T) sh.R[tid] = (unsigned long long)ceil(u_next * (double)(pot - bd));
+    STAMP(6);
     __syncthreads();
+    STAMP(7);
     // more touched super-blocks than the list holds (only in the first picks): refresh all of them
     if (sh.n_touch2[c & 1] > kJTouch) {
       for (int sb = tid; sb < nsb; sb += kJThreads) {
@@ -1151,6 +1114,10 @@ __global__ __launch_bounds__(kJThreads) void mbk_init2_kernel(const uint32_t* __
       __syncthreads();
     }
   }
+#ifdef RHCCQ_STAMPS
+  if (tid == 0 && blockIdx.x == gridDim.x - 1)
+    for (int i = 0; i < 16; ++i) g_init_stamps[i] += _acc[i];
+#endif
   for (int j = tid; j < k; j += kJThreads) {
     const uint32_t kk = dsamp[cho[j]].x;
     const double c0 = (double)key_r(kk), c1 = (double)key_g(kk), c2 = (double)key_b(kk);
@@ -1167,7 +1134,24 @@ constexpr int kTileC = 512;         // centres per workgroup in the batch E-step
                                     // update folds but leaves too few workgroups: measured 9 % slower per step)
 constexpr int kPtChunks = kBatch / 256;   // a workgroup takes 256 of the batch points
 
-// state[p][16] = {ewa, ewa_min, no_improvement, since_reassign, done, steps_done, have_ewa, have_min, n_zero_weight, ...}
+// Per-problem state, double[16] (see rhccq_mbk_steps).  Every kernel of step `step` (the launch index, equal for all
+// problems of a call sequence) reads only slots that no kernel of the same launch writes:
+//   [0] ewa  [1] ewa_min  [2] no_improvement  [6] have_ewa  [7] have_min      -- role 1 of the update only
+//   [4] why it stopped (1 converged, 2 out of steps, 3 word table exhausted)    [5] steps done   [11] stop_at
+//   [3] / [12]  samples since the last reassignment, as seen by an even / odd step
+//   [8] / [13]  zero-weight centres,                  "
+//   [9] / [14]  MT19937 words consumed,               "          [10] first batch drawn
+// a step reads the slots of its parity and writes those of the next step's; stop_at = s + 1 is written during step s and
+// means "stopped before step s + 1", so the other roles of step s still see the problem running.
+constexpr int kStSince = 3, kStNzero = 8, kStCursor = 9;
+__device__ __forceinline__ int st_slot(int even_slot, long long step) {
+  return (step & 1) == 0 ? even_slot : (even_slot == kStSince ? 12 : even_slot == kStNzero ? 13 : 14);
+}
+__device__ __forceinline__ bool mbk_stopped(const double* st, long long step, long long n) {
+  const double stop_at = st[11];
+  const long long bs = n < 1000 ? n : 1000;
+  return (stop_at != 0.0 && (double)step >= stop_at) || st[4] == 3.0 || step >= (100 * n) / bs;
+}
 // kSplit threads share one batch point, each scanning a contiguous 1/kSplit of the tile's centres: with a single
 // straggler problem still running there are only ~160 workgroups for 256 CUs and a thread's serial walk over 512
 // centres (one wave per SIMD, ~8 cycles per dependent f64 instruction) is the whole step; splitting the walk keeps
@@ -1175,14 +1159,13 @@ constexpr int kPtChunks = kBatch / 256;   // a workgroup takes 256 of the batch 
 template <int kSplit>
 __global__ __launch_bounds__(256) void mbk_batch_estep_kernel(const uint32_t* __restrict__ keys, const MbkP* __restrict__ probs,
                                                               const double* __restrict__ centres, const double* __restrict__ state,
-                                                              const uint32_t* __restrict__ bkeys, double* __restrict__ pdist,
+                                                              long long step, const uint32_t* __restrict__ bkeys, double* __restrict__ pdist,
                                                               int32_t* __restrict__ pidx, const long long* __restrict__ part_off) {
   constexpr int kPts = 256 / kSplit, kSlice = kTileC / kSplit;
   const int p = blockIdx.y;
-  const double done = state[p * 16 + 4];                 // independent table reads, issued together
-  const MbkP P = probs[p];
+  const MbkP P = probs[p];                               // independent table reads, issued together
   const long long po = part_off[p];
-  if (done != 0.0) return;
+  if (mbk_stopped(state + p * 16, step, P.n)) return;
   const int n_tiles = (int)((P.k + kTileC - 1) / kTileC);
   const int tile = blockIdx.x / (kPtChunks * kSplit), chunk = blockIdx.x % (kPtChunks * kSplit);
   if (tile >= n_tiles) return;
@@ -1235,40 +1218,51 @@ __global__ __launch_bounds__(256) void mbk_batch_estep_kernel(const uint32_t* __
 // groups (smaller distance, then smaller tile).  Folding inside the single-workgroup update kernel meant ~700 KB
 // through one CU's few outstanding misses (10-14 us of every step); a last-arriving-workgroup fold inside the
 // E-step needs an agent-scope release (an L2 write-back) in every one of its ~900 workgroups and was slower still.
-__global__ __launch_bounds__(64) void mbk_fold_tiles_kernel(const MbkP* __restrict__ probs, const double* __restrict__ state,
+__global__ __launch_bounds__(64) void mbk_fold_tiles_kernel(const MbkP* __restrict__ probs, const double* __restrict__ state, long long step,
+                                                            const double* __restrict__ centres, const uint32_t* __restrict__ bkeys,
                                                             double* __restrict__ pdist, int32_t* __restrict__ pidx,
-                                                            const long long* __restrict__ part_off) {
+                                                            const long long* __restrict__ part_off, double* __restrict__ pper, int tiled) {
   const int p = blockIdx.y;
-  // the three table reads are independent: issue them together (a kernel this short is a chain of cold misses)
-  const double done = state[p * 16 + 4];
-  const long long pk = probs[p].k, pn = probs[p].n, po = part_off[p];
-  if (done != 0.0) return;
-  const int n_tiles = (int)((pk + kTileC - 1) / kTileC);
-  if (n_tiles == 1) return;
-  const int bs = (int)min((long long)1000, pn);
+  const MbkP P = probs[p];
+  const long long po = part_off[p];
+  if (mbk_stopped(state + p * 16, step, P.n)) return;
+  const int n_tiles = tiled ? (int)((P.k + kTileC - 1) / kTileC) : 1;     // the grid E-step leaves its result in the slot of tile 0
+  const int bs = (int)min((long long)1000, P.n);
   const int lane = threadIdx.x, g = lane >> 4;
   const int b = min(blockIdx.x * 16 + (lane & 15), bs - 1);      // clamped lanes redo the last point (same value written)
-  const double* fd = pdist + po + b;
   double bd = INFINITY;
-  int bt = 0x7fffffff;
-  for (int t0 = g; t0 < n_tiles; t0 += 64) {
-    double dv[16];
+  int bt = 0;
+  if (n_tiles > 1) {
+    const double* fd = pdist + po + b;
+    bt = 0x7fffffff;
+    for (int t0 = g; t0 < n_tiles; t0 += 64) {
+      double dv[16];
 #pragma unroll
-    for (int q = 0; q < 16; ++q) dv[q] = t0 + 4 * q < n_tiles ? fd[(size_t)(t0 + 4 * q) * kBatch] : INFINITY;
+      for (int q = 0; q < 16; ++q) dv[q] = t0 + 4 * q < n_tiles ? fd[(size_t)(t0 + 4 * q) * kBatch] : INFINITY;
 #pragma unroll
-    for (int q = 0; q < 16; ++q)
-      if (dv[q] < bd) { bd = dv[q]; bt = t0 + 4 * q; }
+      for (int q = 0; q < 16; ++q)
+        if (dv[q] < bd) { bd = dv[q]; bt = t0 + 4 * q; }
+    }
+#pragma unroll
+    for (int o = 16; o <= 32; o <<= 1) {
+      const double od = __shfl_xor(bd, o, 64);
+      const int ot = __shfl_xor(bt, o, 64);
+      if (od < bd || (od == bd && ot < bt)) { bd = od; bt = ot; }
+    }
   }
-#pragma unroll
-  for (int o = 16; o <= 32; o <<= 1) {
-    const double od = __shfl_xor(bd, o, 64);
-    const int ot = __shfl_xor(bt, o, 64);
-    if (od < bd || (od == bd && ot < bt)) { bd = od; bt = ot; }
-  }
-  if (g == 0 && bt != 0) {
+  if (g == 0) {
     const int32_t bj = pidx[po + b + (size_t)bt * kBatch];
-    pdist[po + b] = bd;
-    pidx[po + b] = bj;
+    if (bt != 0) {
+      pdist[po + b] = bd;
+      pidx[po + b] = bj;
+    }
+    // the row's term of the batch inertia (sklearn _inertia_dense -> _euclidean_dense_dense for 3 features: result = 0;
+    // result += d * d per feature; 0 + x is exact), against the centres BEFORE this step's update; the update's second
+    // workgroup adds the terms in batch order
+    const uint32_t kk = bkeys[(size_t)p * kBatch + b];
+    const double* c = centres + (P.koff + bj) * 4;
+    const double d0 = (double)key_r(kk) - c[0], d1 = (double)key_g(kk) - c[1], d2 = (double)key_b(kk) - c[2];
+    pper[(size_t)p * kBatch + b] = (d0 * d0 + d1 * d1) + d2 * d2;
   }
 }
 
@@ -1466,10 +1460,10 @@ __global__ __launch_bounds__(kUpdThreads) void mbk_draw0_kernel(const uint32_t* 
   double* st = state + p * kStateStride;
   if (st[10] != 0.0 || st[4] != 0.0) return;
   const MbkP P = probs[p];
-  const long long c = draw_batch(keys, P, words, n_words, (long long)st[9], bkeys + (size_t)p * kBatch, s_out, s_red, &s_cursor);
+  const long long c = draw_batch(keys, P, words, n_words, (long long)st[kStCursor], bkeys + (size_t)p * kBatch, s_out, s_red, &s_cursor);
   if (threadIdx.x == 0) {
-    if (c < 0) st[4] = 3.0;                              // word table exhausted: the host extends it and clears the flag
-    else { st[9] = (double)c; st[10] = 1.0; }
+    if (c < 0) st[4] = 3.0;                              // word table exhausted (the host sizes it so that this cannot happen)
+    else { st[kStCursor] = (double)c; st[10] = 1.0; }     // batch of step 0: even slots, bkeys buffer 0
   }
 }
 
@@ -1480,34 +1474,83 @@ __device__ unsigned long long g_upd_stamps[16];
 #define USTAMP(slot) do {} while (0)
 #endif
 
-// One mini-batch step after its E-step (sklearn _mini_batch_step + _mini_batch_convergence), one workgroup per problem.
-// state[p][16] = {ewa, ewa_min, no_improvement, since_reassign, done (1 converged, 2 out of steps, 3 word table exhausted),
-//                 steps_done, have_ewa, have_min, n_zero_weight_centres, MT cursor (raw words consumed so far), batch_drawn, ...}
+// One mini-batch step after its E-step (sklearn _mini_batch_step + _mini_batch_convergence): THREE workgroups per problem
+// (blockIdx.y = role), on three CUs, because the step is a chain of latencies and these three chains are independent:
+//   role 0  centre update (update_center_dense) and, in the rare steps that reassign low-count centres, the reassignment
+//           with its choice() replay followed by the next batch's draw;
+//   role 1  the batch inertia -- 1 000 terms added one after the other, as sklearn's single-threaded _inertia_dense does
+//           (the terms come from the fold kernel, evaluated against the centres before the update) -- and the EWA rule;
+//   role 2  the next step's batch (randint replay + colour gather) whenever this step does not reassign (then the stream
+//           position is known before the step starts).
 __global__ __launch_bounds__(kUpdThreads) void mbk_update_kernel(const uint32_t* __restrict__ keys, const MbkP* __restrict__ probs,
                                                                  double* __restrict__ centres, double* __restrict__ weights,
-                                                                 double* __restrict__ state, const uint32_t* __restrict__ words,
-                                                                 long long n_words, uint32_t* __restrict__ bkeys,
-                                                                 const double* __restrict__ pdist, const int32_t* __restrict__ pidx,
+                                                                 double* __restrict__ state, long long step,
+                                                                 const uint32_t* __restrict__ words, long long n_words,
+                                                                 const uint32_t* __restrict__ bkeys_cur, uint32_t* __restrict__ bkeys_next,
+                                                                 const double* __restrict__ pper, const int32_t* __restrict__ pidx,
                                                                  const long long* __restrict__ part_off) {
   __shared__ UpdShared sh;
-  const int p = blockIdx.x, tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const int p = blockIdx.x, role = blockIdx.y, tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
   double* st = state + p * kStateStride;
   // independent table reads issued together: the kernel is a chain of dependent accesses, every cold miss counts
-  const double st_done = st[4], st_since = st[3], st_nzero = st[8], st_steps = st[5], st_cursor = st[9];
+  const double st_since = st[st_slot(kStSince, step)], st_nzero = st[st_slot(kStNzero, step)], st_cursor = st[st_slot(kStCursor, step)];
   const MbkP P = probs[p];
   const long long po = part_off[p];
-  if (st_done != 0.0) return;
+  if (mbk_stopped(st, step, P.n)) return;
   const int k = (int)P.k;
   const long long n = P.n;
   const int bs = (int)min((long long)1000, n);
   const long long n_steps_max = (100 * n) / bs;
-  const long long step = (long long)st_steps;
   long long cursor = (long long)st_cursor;
-  if (step >= n_steps_max) {
-    if (tid == 0) st[4] = 2.0;                           // ran out of steps
+  // reassignment decision uses the weights BEFORE this step's update (sklearn _random_reassign):
+  // n_zero = number of zero-weight centres, maintained by the reassignment sweep (it can only be non-zero
+  // while every step reassigns)
+  double since = st_since + (double)bs;
+  const bool do_reassign = st_nzero > 0.0 || since >= 10.0 * (double)k;
+  if (do_reassign) since = 0.0;
+  if (role == 1) {
+    // ---- batch inertia + sklearn _mini_batch_convergence (EWA early stopping) ------------------------------
+    if (wave != 0) return;
+    for (int i = lane; i < kBatch; i += 64) sh.per[i] = i < bs ? pper[(size_t)p * kBatch + i] : 0.0;
+    __syncthreads();                                     // (only this wave is left in the workgroup)
+    if (lane != 0) return;
+    double inertia = 0.0;
+    for (int b = 0; b < kBatch; b += 8) {                // rows beyond the batch hold +0.0: x + 0 = x
+      const double4 u = *reinterpret_cast<const double4*>(&sh.per[b]), v = *reinterpret_cast<const double4*>(&sh.per[b + 4]);
+      inertia = inertia + u.x; inertia = inertia + u.y; inertia = inertia + u.z; inertia = inertia + u.w;
+      inertia = inertia + v.x; inertia = inertia + v.y; inertia = inertia + v.z; inertia = inertia + v.w;
+    }
+    st[5] = (double)(step + 1);
+    double stop = 0.0;
+    const double binert = inertia / (double)bs;
+    if (step + 1 != 1) {
+      double ewa;
+      if (st[6] == 0.0) { ewa = binert; st[6] = 1.0; }
+      else {
+        double a = (double)bs * 2.0 / ((double)n + 1.0);
+        a = a < 1.0 ? a : 1.0;
+        ewa = st[0] * (1.0 - a) + binert * a;
+      }
+      st[0] = ewa;
+      if (st[7] == 0.0 || ewa < st[1]) { st[2] = 0.0; st[1] = ewa; st[7] = 1.0; }
+      else st[2] += 1.0;
+      if (st[2] >= 10.0) stop = 1.0;
+    }
+    if (step + 1 >= n_steps_max && stop == 0.0) stop = 2.0;
+    if (stop != 0.0) { st[4] = stop; st[11] = (double)(step + 1); }
     return;
   }
-  if (cursor + kWordsMargin > n_words) {                 // before anything is modified: the host extends the table and resumes
+  if (role == 2) {
+    // ---- the next step's batch: minibatch_indices = random_state.randint(0, n_samples, batch_size) ------------
+    if (do_reassign) return;                             // the stream position depends on this step's choice(): role 0 draws
+    const long long c = draw_batch(keys, P, words, n_words, cursor, bkeys_next + (size_t)p * kBatch, sh.lab, sh.ired, &sh.cursor);
+    if (tid == 0) {
+      if (c < 0) st[4] = 3.0;                            // word table exhausted (the host sizes it so that this cannot happen)
+      else st[st_slot(kStCursor, step + 1)] = (double)c;
+    }
+    return;
+  }
+  if (do_reassign && cursor + kWordsMargin > n_words) {   // before anything is modified
     if (tid == 0) st[4] = 3.0;
     return;
   }
@@ -1517,41 +1560,22 @@ __global__ __launch_bounds__(kUpdThreads) void mbk_update_kernel(const uint32_t*
 #endif
   double* C = centres + P.koff * 4;
   double* W = weights + P.koff;
-  uint32_t* bkeys_p = bkeys + (size_t)p * kBatch;
-  // reassignment decision uses the weights BEFORE this step's update (sklearn _random_reassign):
-  // st[8] = number of zero-weight centres, maintained by the reassignment sweep (it can only be non-zero
-  // while every step reassigns)
-  double since = st_since + (double)bs;
-  const bool do_reassign = st_nzero > 0.0 || since >= 10.0 * (double)k;
-  if (do_reassign) since = 0.0;
+  const uint32_t* bkeys_p = bkeys_cur + (size_t)p * kBatch;
   if (do_reassign) {                                     // the words a shuffle would read: requested now, needed much later
     for (int i = tid; i < kStageWords; i += kUpdThreads) sh.stage[i] = words[cursor + i];
   }
   for (int i = tid; i < kHashSlots; i += kUpdThreads) { sh.hkey[i] = -1; sh.hcnt[i] = 0; }
   // ---- labels of the batch (the E-step kernels leave the folded arg-min in the slot of tile 0) ------------
-  double per = 0.0, cb0 = 0.0, cb1 = 0.0, cb2 = 0.0, wb = 0.0;
+  double cb0 = 0.0, cb1 = 0.0, cb2 = 0.0, wb = 0.0;
   if (tid < bs) {
     const int bj = pidx[po + tid];
     const uint32_t kk = bkeys_p[tid];
     sh.lab[tid] = bj;
     sh.bkey[tid] = kk;
     cb0 = C[bj * 4]; cb1 = C[bj * 4 + 1]; cb2 = C[bj * 4 + 2]; wb = W[bj];
-    // sklearn _euclidean_dense_dense for 3 features: result = 0; result += d*d per feature (0 + x is exact)
-    const double d0 = (double)key_r(kk) - cb0, d1 = (double)key_g(kk) - cb1, d2 = (double)key_b(kk) - cb2;
-    per = (d0 * d0 + d1 * d1) + d2 * d2;
   }
-  sh.per[tid] = per;
   USTAMP(0);
   __syncthreads();
-  // ---- batch inertia (_inertia_dense with one thread): the per-sample terms added in batch order, one after the
-  // other.  The last thread of the workgroup (a batch has 1 000 rows: it has no row of its own) walks them while the
-  // other waves build the member lists.
-  double inertia = 0.0;
-  if (tid == kUpdThreads - 1) {
-#pragma unroll 8
-    for (int b = 0; b < bs; ++b) inertia = inertia + sh.per[b];
-    sh.dred[0] = inertia;                                // read by thread 0 after the next barriers
-  }
   USTAMP(1);
   // ---- members of every touched centre (LDS hash keyed by centre) -------------------------------------
   if (tid < bs) {
@@ -1573,7 +1597,6 @@ __global__ __launch_bounds__(kUpdThreads) void mbk_update_kernel(const uint32_t*
     if (pos < kMemCap) sh.hmem[h][pos] = (unsigned short)tid;
   }
   __syncthreads();
-  const double inertia_all = sh.dred[0];
   USTAMP(2);
   // ---- update_center_dense: c*w, += x for the members IN BATCH ORDER, w += count, c *= 1/w (each rounded once) ----
   {
@@ -1736,33 +1759,20 @@ __global__ __launch_bounds__(kUpdThreads) void mbk_update_kernel(const uint32_t*
         r_run += __popcll(msel);
       }
       nzero = block_sum_i(nzero, sh);
-      if (tid == 0) st[8] = (double)nzero;
+      if (tid == 0) st[st_slot(kStNzero, step + 1)] = (double)nzero;
     }
   }
   USTAMP(4);
-  // ---- the next step's batch: minibatch_indices = random_state.randint(0, n_samples, batch_size) ------------
-  if (cursor >= 0) cursor = draw_batch(keys, P, words, n_words, cursor, bkeys_p, sh.lab, sh.ired, &sh.cursor);
-  // ---- sklearn _mini_batch_convergence (EWA early stopping) -------------------------------------------
+  // ---- a step that reassigned draws the next batch itself (role 2 stood back) -------------------------------------
+  if (do_reassign && cursor >= 0)
+    cursor = draw_batch(keys, P, words, n_words, cursor, bkeys_next + (size_t)p * kBatch, sh.lab, sh.ired, &sh.cursor);
   if (tid == 0) {
-    st[3] = since;
-    st[5] = (double)(step + 1);
-    if (cursor < 0) st[4] = 3.0;                         // cannot happen within kWordsMargin; the step itself is complete
-    else st[9] = (double)cursor;
-    const double binert = inertia_all / (double)bs;
-    if (step + 1 != 1) {
-      double ewa;
-      if (st[6] == 0.0) { ewa = binert; st[6] = 1.0; }
-      else {
-        double a = (double)bs * 2.0 / ((double)n + 1.0);
-        a = a < 1.0 ? a : 1.0;
-        ewa = st[0] * (1.0 - a) + binert * a;
-      }
-      st[0] = ewa;
-      if (st[7] == 0.0 || ewa < st[1]) { st[2] = 0.0; st[1] = ewa; st[7] = 1.0; }
-      else st[2] += 1.0;
-      if (st[2] >= 10.0) st[4] = 1.0;
+    st[st_slot(kStSince, step + 1)] = since;
+    if (!do_reassign) st[st_slot(kStNzero, step + 1)] = st_nzero;        // (0: it stays 0)
+    if (do_reassign) {
+      if (cursor < 0) st[4] = 3.0;                       // cannot happen within kWordsMargin
+      else st[st_slot(kStCursor, step + 1)] = (double)cursor;
     }
-    if (step + 1 >= n_steps_max && st[4] == 0.0) st[4] = 2.0;
   }
   USTAMP(5);
 }
@@ -1785,12 +1795,12 @@ __device__ __forceinline__ int grid_axis(double v) { return min(kGridG - 1, max(
 // so its result does not.
 __global__ __launch_bounds__(1024) void grid_build_kernel(const MbkP* __restrict__ probs, const double* __restrict__ centres,
                                                           uint32_t* __restrict__ cell_start /* [n_prob][cells+1] */,
-                                                          uint32_t* __restrict__ order, const double* __restrict__ state) {
+                                                          uint32_t* __restrict__ order, const double* __restrict__ state, long long step) {
   __shared__ uint32_t cnt[kGridCells];                   // counters, then fill cursors (128 KiB)
   __shared__ unsigned red[17];
   const int p = blockIdx.x;
-  if (state && state[p * 16 + 4] != 0.0) return;
   const MbkP P = probs[p];
+  if (state && mbk_stopped(state + p * 16, step, P.n)) return;
   const double* C = centres + P.koff * 4;
   uint32_t* cs = cell_start + (size_t)p * (kGridCells + 1);
   for (int c = threadIdx.x; c < kGridCells; c += 1024) cnt[c] = 0;
@@ -1941,12 +1951,13 @@ __device__ __forceinline__ void grid_scan_shell(int r_lo, int r_hi, int cx, int 
 // writes the same (distance, label) the tiled kernel + tile reduction produce, into tile 0 of the partials
 __global__ __launch_bounds__(256) void mbk_batch_estep_grid_kernel(const uint32_t* __restrict__ keys, const MbkP* __restrict__ probs,
                                                                    const double* __restrict__ centres, const double* __restrict__ state,
-                                                                   const uint32_t* __restrict__ bkeys, const uint32_t* __restrict__ cell_start,
+                                                                   long long step, const uint32_t* __restrict__ bkeys,
+                                                                   const uint32_t* __restrict__ cell_start,
                                                                    const uint32_t* __restrict__ order, double* __restrict__ pdist,
                                                                    int32_t* __restrict__ pidx, const long long* __restrict__ part_off) {
   const int p = blockIdx.y;
   const MbkP P = probs[p];
-  if (state[p * 16 + 4] != 0.0) return;
+  if (mbk_stopped(state + p * 16, step, P.n)) return;
   const int bs = (int)min((long long)1000, P.n);
   const int b = blockIdx.x * 4 + (threadIdx.x >> 6);     // one wave per batch point
   if (b >= bs) return;
@@ -2014,13 +2025,17 @@ __global__ __launch_bounds__(256) void mt_uniforms_odd_kernel(const uint32_t* __
   out[i] = ((double)(a >> 5) * 67108864.0 + (double)(b >> 6)) / 9007199254740992.0;
 }
 
+// hipFree waits for the whole device (every stream, also the other lanes of a pipelined call: a k-means++ chain in flight
+// there costs 200 ms), so the scratch starts generous and doubles: a steady stream of frames never reallocates
 static int ensure_scratch(rhccq_ctx* ctx, size_t bytes) {
   if (ctx->scratch_bytes >= bytes) return 0;
+  size_t want = ctx->scratch_bytes ? 2 * ctx->scratch_bytes : ((size_t)32 << 20);
+  while (want < bytes) want *= 2;
   if (ctx->scratch) RHCCQ_HIP(ctx, hipFree(ctx->scratch));
   ctx->scratch = nullptr;
   ctx->scratch_bytes = 0;
-  RHCCQ_HIP(ctx, hipMalloc(&ctx->scratch, bytes));
-  ctx->scratch_bytes = bytes;
+  RHCCQ_HIP(ctx, hipMalloc(&ctx->scratch, want));
+  ctx->scratch_bytes = want;
   return 0;
 }
 
@@ -2040,7 +2055,7 @@ using namespace rhccq;
 extern "C" {
 
 // work layout for steps/assign: [probs MbkP[n_prob]] [part_off i64[n_prob]] [blk_off i64[n_prob+1]]
-//                               [pdist f64[sum tiles*1024]] [pidx i32[sum tiles*1024]] [grid tables] [bkeys u32[n_prob*1024]]
+//                               [pdist f64[sum tiles*1024]] [pidx i32[sum tiles*1024]] [grid tables] [bkeys u32[2][n_prob*1024]] [pper f64[n_prob*1024]]
 int64_t rhccq_mbk_work_bytes(const rhccq_mbk_problem* probs, int32_t n_prob) {
   if (!probs || n_prob <= 0) return 0;
   size_t part = 0;
@@ -2050,7 +2065,7 @@ int64_t rhccq_mbk_work_bytes(const rhccq_mbk_problem* probs, int32_t n_prob) {
   size_t ksum = 0;
   for (int i = 0; i < n_prob; ++i) ksum += (size_t)probs[i].k;
   bytes += align256((size_t)n_prob * (kGridCells + 1) * 4) + align256((size_t)n_prob * kGridCells * 4) + align256(ksum * 4);
-  bytes += align256((size_t)n_prob * kBatch * 4);
+  bytes += 2 * align256((size_t)n_prob * kBatch * 4) + align256((size_t)n_prob * kBatch * 8);
   return (int64_t)bytes;
 }
 
@@ -2063,7 +2078,8 @@ struct WorkView {
   uint32_t* cell_start;   // [n_prob][cells + 1]
   uint32_t* cursor;       // [n_prob][cells] (spare)
   uint32_t* order;        // [sum k] centre indices grouped by cell (problem-relative)
-  uint32_t* bkeys;        // [n_prob][1024] colours of the current batch rows (written by the draws)
+  uint32_t* bkeys[2];     // [n_prob][1024] colours of the batch rows of even / odd steps (written by the draws)
+  double* pper;           // [n_prob][1024] the rows' inertia terms (fold kernel -> role 1 of the update)
   long long max_k;
 };
 
@@ -2104,7 +2120,9 @@ static int layout_work(rhccq_ctx* ctx, const rhccq_mbk_problem* probs, int n_pro
     for (int i = 0; i < n_prob; ++i) ksum += (size_t)probs[i].k;
     base += align256(ksum * 4);
   }
-  v->bkeys = (uint32_t*)base;
+  v->bkeys[0] = (uint32_t*)base; base += align256((size_t)n_prob * kBatch * 4);
+  v->bkeys[1] = (uint32_t*)base; base += align256((size_t)n_prob * kBatch * 4);
+  v->pper = (double*)base;
   v->max_k = 0;
   for (int i = 0; i < n_prob; ++i) v->max_k = probs[i].k > v->max_k ? probs[i].k : v->max_k;
   if (int e = put(ctx, v->probs, hp, sizeof(MbkP) * n_prob)) return e;
@@ -2240,10 +2258,10 @@ int rhccq_mbk_init(rhccq_ctx* ctx, const uint32_t* keys, const rhccq_mbk_problem
   return 0;
 }
 
-int rhccq_mbk_steps(rhccq_ctx* ctx, const uint32_t* keys, const rhccq_mbk_problem* probs, int32_t n_prob, int32_t n_steps,
+int rhccq_mbk_steps(rhccq_ctx* ctx, const uint32_t* keys, const rhccq_mbk_problem* probs, int32_t n_prob, int64_t step0, int32_t n_steps,
                     const uint32_t* words, int64_t n_words, double* centres, double* weights, double* state, void* work,
                     int64_t work_bytes, int32_t estep_mode, int32_t estep_split) {
-  if (!ctx || !keys || !probs || !words || !centres || !weights || !state || !work || n_prob <= 0 || n_steps < 0 || n_words <= 0)
+  if (!ctx || !keys || !probs || !words || !centres || !weights || !state || !work || n_prob <= 0 || n_steps < 0 || n_words <= 0 || step0 < 0)
     return rhccq_fail(ctx, RHCCQ_E_ARG, "mbk_steps: bad argument");
   WorkView v;
   long long blocks;
@@ -2259,18 +2277,21 @@ int rhccq_mbk_steps(rhccq_ctx* ctx, const uint32_t* keys, const rhccq_mbk_proble
     return rhccq_fail(ctx, RHCCQ_E_ARG, "mbk_steps: estep_split must be 0, 1, 2, 4 or 8");
   const bool use_grid = estep_mode == RHCCQ_ESTEP_GRID || (estep_mode == RHCCQ_ESTEP_AUTO && ksum >= 200000);
   // problems whose first batch has not been drawn yet (state[10] == 0) draw it now; the others return at once
-  hipLaunchKernelGGL(mbk_draw0_kernel, dim3(n_prob), dim3(kUpdThreads), 0, ctx->stream, keys, v.probs, state, words, (long long)n_words,
-                     v.bkeys);
+  if (step0 == 0)
+    hipLaunchKernelGGL(mbk_draw0_kernel, dim3(n_prob), dim3(kUpdThreads), 0, ctx->stream, keys, v.probs, state, words, (long long)n_words,
+                       v.bkeys[0]);
   for (int s = 0; s < n_steps; ++s) {
+    const long long step = step0 + s;
+    const uint32_t* bk = v.bkeys[step & 1];
     if (use_grid) {
       hipLaunchKernelGGL(grid_build_kernel, dim3(n_prob), dim3(1024), 0, ctx->stream, v.probs, centres, v.cell_start, v.order,
-                         (const double*)state);
-      hipLaunchKernelGGL(mbk_batch_estep_grid_kernel, dim3(250, n_prob), dim3(256), 0, ctx->stream, keys, v.probs, centres, state,
-                         (const uint32_t*)v.bkeys, v.cell_start, v.order, v.pdist, v.pidx, v.part_off);
+                         (const double*)state, step);
+      hipLaunchKernelGGL(mbk_batch_estep_grid_kernel, dim3(250, n_prob), dim3(256), 0, ctx->stream, keys, v.probs, centres, state, step, bk,
+                         v.cell_start, v.order, v.pdist, v.pidx, v.part_off);
     } else {
 #define RHCCQ_ESTEP_LAUNCH(SS)                                                                                                             \
   hipLaunchKernelGGL(mbk_batch_estep_kernel<SS>, dim3(max_tiles * kPtChunks * SS, n_prob), dim3(256), 0, ctx->stream, keys, v.probs, centres, \
-                     state, (const uint32_t*)v.bkeys, v.pdist, v.pidx, v.part_off)
+                     state, step, bk, v.pdist, v.pidx, v.part_off)
       switch (estep_split) {
         case 8: RHCCQ_ESTEP_LAUNCH(8); break;
         case 4: RHCCQ_ESTEP_LAUNCH(4); break;
@@ -2278,11 +2299,12 @@ int rhccq_mbk_steps(rhccq_ctx* ctx, const uint32_t* keys, const rhccq_mbk_proble
         default: RHCCQ_ESTEP_LAUNCH(1); break;
       }
 #undef RHCCQ_ESTEP_LAUNCH
-      hipLaunchKernelGGL(mbk_fold_tiles_kernel, dim3((1000 + 15) / 16, n_prob), dim3(64), 0, ctx->stream, v.probs, (const double*)state, v.pdist, v.pidx,
-                         v.part_off);
     }
-    hipLaunchKernelGGL(mbk_update_kernel, dim3(n_prob), dim3(kUpdThreads), 0, ctx->stream, keys, v.probs, centres, weights, state, words,
-                       (long long)n_words, v.bkeys, v.pdist, v.pidx, v.part_off);
+    // arg-min over the centre tiles (tiled E-step) and every row's inertia term against the centres before the update
+    hipLaunchKernelGGL(mbk_fold_tiles_kernel, dim3((1000 + 15) / 16, n_prob), dim3(64), 0, ctx->stream, v.probs, (const double*)state, step,
+                       (const double*)centres, bk, v.pdist, v.pidx, v.part_off, v.pper, use_grid ? 0 : 1);
+    hipLaunchKernelGGL(mbk_update_kernel, dim3(n_prob, 3), dim3(kUpdThreads), 0, ctx->stream, keys, v.probs, centres, weights, state, step,
+                       words, (long long)n_words, bk, v.bkeys[(step + 1) & 1], (const double*)v.pper, (const int32_t*)v.pidx, v.part_off);
   }
   RHCCQ_LAUNCH_CHECK(ctx);
   return 0;
@@ -2297,7 +2319,7 @@ int rhccq_mbk_assign(rhccq_ctx* ctx, const uint32_t* keys, const rhccq_mbk_probl
   if (int e = layout_work(ctx, probs, n_prob, work, work_bytes, &v, &blocks, &max_tiles)) return e;
   if (blocks > 0x7fffffffll) return rhccq_fail(ctx, RHCCQ_E_LIMIT, "mbk_assign: too many points");
   hipLaunchKernelGGL(grid_build_kernel, dim3(n_prob), dim3(1024), 0, ctx->stream, v.probs, centres, v.cell_start, v.order,
-                     (const double*)nullptr);
+                     (const double*)nullptr, 0ll);
   hipLaunchKernelGGL(mbk_assign_grid_kernel, dim3((unsigned)blocks), dim3(256), 0, ctx->stream, keys, v.probs, centres, v.cell_start, v.order,
                      labels_out, v.blk_off);
   RHCCQ_LAUNCH_CHECK(ctx);

@@ -112,6 +112,7 @@ class _MtStream:
 
 _first_cache = {}
 _first_lock = threading.Lock()
+_words_lock = threading.Lock()
 
 
 def first_centre_index(n, u0):
@@ -193,12 +194,20 @@ class Rhccq:
         self._check(self.lib.rhccq_ctx_set_int(self.ctx, int(option), int(value)), "ctx_set_int")
 
     def _mt_words_dev(self, n):
-        """at least the first n raw MT19937 words on the device (uploaded once, regrown geometrically)"""
-        if self._mtw_dev is None or self._mtw_dev.numel() < n:
-            have = 0 if self._mtw_dev is None else self._mtw_dev.numel()
-            w = self.mtw.ensure(max(n, 2 * have, 1 << 22))
-            self._mtw_dev = torch.from_numpy(w.view(np.int32)).to(self.device)
-        return self._mtw_dev
+        """at least the first n raw MT19937 words on the device (uploaded once, regrown geometrically; the lanes of a
+        pipelined call share their parent's table)"""
+        owner = getattr(self, "_parent", None) or self
+        t = owner._mtw_dev
+        if t is None or t.numel() < n:
+            with _words_lock:
+                t = owner._mtw_dev
+                if t is None or t.numel() < n:
+                    have = 0 if t is None else t.numel()
+                    w = owner.mtw.ensure(max(n, 2 * have, 1 << 22))
+                    t = torch.from_numpy(w.view(np.int32)).to(self.device)      # blocking copy: complete on return
+                    torch.cuda.current_stream(self.device).synchronize()
+                    owner._mtw_dev = t
+        return t
 
     def close(self):
         if getattr(self, "ctx", None):
@@ -396,7 +405,82 @@ class Rhccq:
         return out[:k], sums[:k]
 
     # -- K8 -----------------------------------------------------------------------------------------
-    def minibatch_kmeans(self, key_list, k_list, return_info=False, poll_steps=64, return_device=False, timing=None, estep="auto", estep_split=0):
+    MBK_LANES = 4        # problems of a small batch run as independent pipelines on this many HIP streams
+
+    def _lane(self, i):
+        """a sibling context on its own HIP stream (host thread `i` of a pipelined call); shares the MT19937 word table"""
+        lanes = self.__dict__.setdefault("_lanes", {})
+        if i not in lanes:
+            stream = torch.cuda.Stream(self.device)
+            with torch.cuda.stream(stream):
+                rh = Rhccq(self.device.index)
+            rh.mtw, rh._parent = self.mtw, self
+            lanes[i] = (stream, rh)
+        return lanes[i]
+
+    def _minibatch_lanes(self, key_list, k_list, return_info, poll_steps, return_device, estep, estep_split, n_lanes):
+        """Independent problems as independent pipelines: init -> steps -> assign of each lane's problems on its own HIP
+        stream, driven by its own host thread (the C calls and the state polls release the GIL).  The k-means++ chain of
+        one problem and the mini-batch steps of another then overlap instead of queueing behind each other on one
+        stream: a single 4K frame's level 1 costs max(init_p + steps_p) rather than max(init) + max(steps)."""
+        n_prob = len(key_list)
+        # longest chains first, each to the lane with the least work so far
+        order = sorted(range(n_prob), key=lambda i: -k_list[i])
+        groups, load = [[] for _ in range(n_lanes)], [0] * n_lanes
+        for i in order:
+            g = load.index(min(load))
+            groups[g].append(i)
+            load[g] += k_list[i]
+        parts = [k if torch.is_tensor(k) else self.dev(np.ascontiguousarray(np.asarray(k)).astype(np.uint32).view(np.int32)) for k in key_list]
+        here = torch.cuda.current_stream(self.device)
+        ready = torch.cuda.Event()
+        ready.record(here)
+        results, errors = [None] * n_lanes, []
+
+        def run(g):
+            try:
+                torch.cuda.set_device(self.device)
+                stream, rh = self._lane(g)
+                with torch.cuda.stream(stream):
+                    stream.wait_event(ready)
+                    idx = groups[g]
+                    out = rh.minibatch_kmeans([parts[i] for i in idx], [k_list[i] for i in idx], return_info=True, poll_steps=poll_steps,
+                                              return_device=True, estep=estep, estep_split=estep_split, lanes=1)
+                    done = torch.cuda.Event()
+                    done.record(stream)
+                    results[g] = (out, done)
+            except BaseException as e:                        # surfaced to the caller below
+                errors.append(e)
+
+        threads = [threading.Thread(target=run, args=(g,), name=f"rhccq-mbk{g}") for g in range(n_lanes) if groups[g]]
+        for t in threads:
+            t.start()
+        for t in threads:
+            t.join()
+        if errors:
+            raise errors[0]
+        labs = [None] * n_prob
+        infos = [None] * n_prob
+        for g in range(n_lanes):
+            if not groups[g]:
+                continue
+            (lg, ig), done = results[g]
+            here.wait_event(done)
+            for j, i in enumerate(groups[g]):
+                lg[j].record_stream(here)
+                labs[i] = lg[j]
+                a, b = int(ig["koff"][j]), int(ig["koff"][j + 1])
+                infos[i] = (ig["state"][j], ig["centres"][a:b], ig["chosen"][a:b], ig["weights"][a:b])
+        if not return_device:
+            labs = [l.cpu().numpy() for l in labs]
+        if return_info:
+            koff = np.concatenate([[0], np.cumsum(k_list)]).astype(np.int64)
+            return labs, {"state": np.stack([x[0] for x in infos]), "centres": np.concatenate([x[1] for x in infos]),
+                          "chosen": np.concatenate([x[2] for x in infos]), "koff": koff, "weights": np.concatenate([x[3] for x in infos])}
+        return labs
+
+    def minibatch_kmeans(self, key_list, k_list, return_info=False, poll_steps=64, return_device=False, timing=None, estep="auto", estep_split=0,
+                         lanes=None):
         """Batched MiniBatchKMeans(k, batch_size=1000, random_state=42).fit_predict labels: sklearn's fit operation
         for operation (RandomState(42) replayed from its raw MT19937 words, k-means++ in draw order, batch-ordered
         centre updates; the one canonical choice is the stable tie order of the reassignment argsort -- see
@@ -408,6 +492,12 @@ class Rhccq:
         n_prob = len(key_list)
         if n_prob == 0:
             return ([], []) if return_info else []
+        # few problems (a single frame): every problem its own pipeline; many (a batch of frames): one batched launch per
+        # phase keeps all CUs busy anyway and costs the host far less
+        if lanes is None:
+            lanes = min(n_prob, self.MBK_LANES) if (timing is None and 1 < n_prob <= 2 * self.MBK_LANES) else 1
+        if lanes > 1 and n_prob > 1:
+            return self._minibatch_lanes(key_list, k_list, return_info, poll_steps, return_device, estep, estep_split, min(lanes, n_prob))
         probs = (MbkProblem * n_prob)()
         sizes = [int(k.numel()) if torch.is_tensor(k) else len(k) for k in key_list]
         offs = np.concatenate([[0], np.cumsum(sizes)]).astype(np.int64)
@@ -491,27 +581,25 @@ class Rhccq:
         k_arr = np.asarray(k_list, np.int64)
         limit = np.array([(100 * n) // min(1000, n) for n in sizes], np.int64)
         running = np.ones(n_prob, bool)
-        steps_done = np.zeros(n_prob, np.int64)
-        while running.any():                                 # every problem counts its own steps (state[:, 5])
-            ns = int(min(poll_steps, max(1, (limit - steps_done)[running].max())))
+        step = 0                                             # launch index = step index of every problem still running
+        while running.any():
+            ns = int(min(poll_steps, max(1, limit[running].max() - step)))
             # the grid E-step pays when many centres are in flight; once only stragglers are left the tiled
             # brute force has fewer and shorter launches per step
             mode = {"tiles": 1, "grid": 2}.get(estep) or (2 if int(k_arr[running].sum()) >= 200000 else 1)
             # few workgroups left (a straggler problem): several threads share a batch point in the tiled E-step
             wgs = int(((k_arr[running] + 511) // 512).sum()) * 4
             split = estep_split or next((sp for sp in (1, 2, 4, 8) if wgs * sp >= 1536), 8)
-            words = self._mt_words_dev(cur_max + (ns + 2) * WORDS_PER_STEP)
-            self._check(self.lib.rhccq_mbk_steps(self.ctx, self._p(keys), probs, n_prob, ns, self._p(words), words.numel(),
+            words = self._mt_words_dev(cur_max + (ns + 2) * WORDS_PER_STEP)     # a step consumes at most WORDS_PER_STEP
+            self._check(self.lib.rhccq_mbk_steps(self.ctx, self._p(keys), probs, n_prob, step, ns, self._p(words), words.numel(),
                                                  self._p(centres), self._p(weights), self._p(state), self._p(work), wbytes, mode, split),
                         "mbk_steps")
+            step += ns
             st = state.cpu().numpy()
-            cur_max = int(st[:, 9].max())
-            steps_done = st[:, 5].astype(np.int64)
-            starved = st[:, 4] == 3                          # ran into the end of the word table: extended above, resumes
-            if starved.any():
-                state[:, 4] = torch.where(state[:, 4] == 3, torch.zeros_like(state[:, 4]), state[:, 4])
-                st[starved, 4] = 0
-            running = (st[:, 4] == 0) & (st[:, 5] < limit)
+            cur_max = int(max(st[:, 9].max(), st[:, 14].max()))
+            if (st[:, 4] == 3).any():
+                raise RhccqError("mini-batch steps ran past the end of the MT19937 word table (internal sizing error)")
+            running = (st[:, 11] == 0) & (st[:, 5] < limit)
         labels = self.empty((int(offs[-1]),), torch.int32)
         self._check(self.lib.rhccq_mbk_assign(self.ctx, self._p(keys), probs, n_prob, self._p(centres), self._p(work), wbytes,
                                               self._p(labels)), "mbk_assign")

@@ -1,0 +1,30 @@
+import os, sys
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+"""diagnostic only: per-phase cycle shares of mbk_init2_kernel (build with -DRHCCQ_STAMPS into dbg_build/)."""
+import ctypes, time, math
+import numpy as np
+import torch
+from roibasedimagecompression_amd import _lib
+_lib.LIB_PATH = "dbg_build/librhccq_dbg.so"
+from roibasedimagecompression_amd.ops import Rhccq
+from roibasedimagecompression_amd import synth
+rh = Rhccq(0)
+img = synth.photo(2160, 3840, 1234)
+keys = (img[..., 0].astype(np.uint32) << 16) | (img[..., 1].astype(np.uint32) << 8) | img[..., 2]
+pal = np.unique(keys[:, 1920:])
+pal = pal[pal != 0]
+k = math.ceil(len(pal) * 0.2 / 10)
+print("N", len(pal), "k", k)
+t = {}
+labs, info = rh.minibatch_kmeans([pal], [k], return_info=True, timing=t)
+print("init ms", t["init_ms"], "us/pick", t["init_ms"] * 1e3 / k)
+out = (ctypes.c_ulonglong * 16)()
+rh._raw.rhccq_debug_stamps.argtypes = [ctypes.c_void_p]
+print("rc", rh._raw.rhccq_debug_stamps(out))
+v = np.array(list(out), dtype=np.float64) / (k - 1)
+names = ["search(wave0)", "barrier A", "enumerate", "barrier B", "evaluate", "barrier C", "argmax+commit", "barrier D"]
+tot = v[:8].sum()
+for n, x in zip(names, v[:8]):
+    print(f"{n:18s} {x:10.0f} cycles/pick  {100*x/tot:5.1f}%")
+print("total cycles/pick (thread 0)", tot)
+print("items/pick", v[10], "picks not kept", v[11], "picks overflow", v[12])
