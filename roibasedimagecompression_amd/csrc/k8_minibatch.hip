@@ -117,6 +117,7 @@ struct InitTables {
 
 #ifdef RHCCQ_STAMPS   // diagnostic build only (tools/stamps.py): per-phase cycle shares of the init chain
 __device__ unsigned long long g_init_stamps[16];
+__device__ unsigned long long g_wave_stamps[4][16];       // [phase][wave]: cycles each wave spent in the phase
 #define STAMP(slot)                                  \
   do {                                               \
     const unsigned long long _t = clock64();        \
@@ -686,7 +687,7 @@ struct JShared {
   uint32_t ckey[kTMaxI];
   uint32_t cna[kTMaxI];
   uint32_t ckp[kTMaxI][4];
-  int n_items, overflow, n_touch2[2];
+  int n_items, overflow, n_touch2[2], n_hits;
 };
 
 // sample pair, Morton order: x = key | (dpos & 255) << 24 ; y = (c' & 0x7ffff) | (dpos >> 8) << 19, c' = closest - |key|^2
@@ -718,39 +719,40 @@ __device__ __forceinline__ unsigned j_eval4(uint32_t ck, int na, const uint4& a,
   return (unsigned)(max(i0, 0) + max(i1, 0)) + (unsigned)(max(i2, 0) + max(i3, 0));
 }
 
-// commit of one sample against the new centre; returns its true closest distance afterwards
-__device__ __forceinline__ unsigned j_commit1(uint32_t ck, int na, uint32_t x, uint32_t y, int m, uint2* samp, uint2* dsamp, uint32_t* dsum,
-                                             uint32_t* dssum) {
-  const int dot2 = 2 * (int)__builtin_amdgcn_udot4(ck, x, 0u, false);
-  int cp = j_cprime(y);
-  const int imp = cp - na + dot2;
-  const unsigned nx = norm2_key(x & 0xffffffu);
+// commit of one improved sample (rare: ~30 per pick): both copies of the sample, the draw-order sums
+__device__ __forceinline__ void j_store1(int imp, int newcp, unsigned nx, uint32_t x, uint32_t y, int m, uint2* samp, uint2* dsamp, uint32_t* dsum,
+                                         uint32_t* dssum) {
   if (imp > 0) {
-    cp = na - dot2;                                       // new c' = d - |x|^2
     const uint32_t dpos = j_dpos(x, y);
-    samp[m].y = ((uint32_t)cp & 0x7ffffu) | (y & 0xfff80000u);
-    dsamp[dpos].y = (uint32_t)(cp + (int)nx);
+    samp[m].y = ((uint32_t)newcp & 0x7ffffu) | (y & 0xfff80000u);
+    dsamp[dpos].y = (uint32_t)(newcp + (int)nx);
     atomicSub(&dsum[dpos >> 6], (unsigned)imp);
     atomicSub(&dssum[dpos >> 10], (unsigned)imp);
   }
-  return (unsigned)(cp + (int)nx);
 }
 
 // one row of 16 lanes = one block of 64 samples (lane j holds samples 4j .. 4j+3 in a, b): lower closest[] against
-// the new centre, refresh the block's max, note its super-block as touched
+// the new centre, refresh the block's max, note its super-block as touched.  Everything but the stores is computed
+// unconditionally (straight-line code: the chain is bound by instruction issue, and divergent branches cost more than
+// the few operations they would skip).
 __device__ __forceinline__ void j_commit_row(bool on, int b, uint32_t ck, int na, const uint4& a, const uint4& bb, uint2* samp, uint2* dsamp,
                                              uint4* blk, uint32_t* dsum, uint32_t* dssum, int* touch, int* n_touch) {
   const int j = threadIdx.x & 15;
-  unsigned mx = 0;
-  if (on) {
+  const int e0 = 2 * (int)__builtin_amdgcn_udot4(ck, a.x, 0u, false), e1 = 2 * (int)__builtin_amdgcn_udot4(ck, a.z, 0u, false);
+  const int e2 = 2 * (int)__builtin_amdgcn_udot4(ck, bb.x, 0u, false), e3 = 2 * (int)__builtin_amdgcn_udot4(ck, bb.z, 0u, false);
+  const int c0 = j_cprime(a.y), c1 = j_cprime(a.w), c2 = j_cprime(bb.y), c3 = j_cprime(bb.w);
+  const int i0 = c0 - na + e0, i1 = c1 - na + e1, i2 = c2 - na + e2, i3 = c3 - na + e3;       // improvements (> 0: the sample moves)
+  const unsigned n0 = norm2_key(a.x & 0xffffffu), n1 = norm2_key(a.z & 0xffffffu), n2 = norm2_key(bb.x & 0xffffffu), n3 = norm2_key(bb.z & 0xffffffu);
+  const int w0 = i0 > 0 ? na - e0 : c0, w1 = i1 > 0 ? na - e1 : c1, w2 = i2 > 0 ? na - e2 : c2, w3 = i3 > 0 ? na - e3 : c3;   // new c' = d - |x|^2
+  if (on && max(max(i0, i1), max(i2, i3)) > 0) {
     const int m0 = (b << 6) + 4 * j;
-    const unsigned t0 = j_commit1(ck, na, a.x, a.y, m0, samp, dsamp, dsum, dssum);
-    const unsigned t1 = j_commit1(ck, na, a.z, a.w, m0 + 1, samp, dsamp, dsum, dssum);
-    const unsigned t2 = j_commit1(ck, na, bb.x, bb.y, m0 + 2, samp, dsamp, dsum, dssum);
-    const unsigned t3 = j_commit1(ck, na, bb.z, bb.w, m0 + 3, samp, dsamp, dsum, dssum);
-    mx = max(max(t0, t1), max(t2, t3));
+    j_store1(i0, w0, n0, a.x, a.y, m0, samp, dsamp, dsum, dssum);
+    j_store1(i1, w1, n1, a.z, a.w, m0 + 1, samp, dsamp, dsum, dssum);
+    j_store1(i2, w2, n2, bb.x, bb.y, m0 + 2, samp, dsamp, dsum, dssum);
+    j_store1(i3, w3, n3, bb.z, bb.w, m0 + 3, samp, dsamp, dsum, dssum);
   }
-  mx = dpp_row_max(mx);
+  unsigned mx = max(max((unsigned)(w0 + (int)n0), (unsigned)(w1 + (int)n1)), max((unsigned)(w2 + (int)n2), (unsigned)(w3 + (int)n3)));
+  mx = dpp_row_max(on ? mx : 0u);
   if (on && j == 0) {
     blk[b].w = mx;
     const int slot = atomicAdd(n_touch, 1);
@@ -816,6 +818,7 @@ __global__ __launch_bounds__(kJThreads) void mbk_init2_kernel(const uint32_t* __
   __shared__ uint32_t dsum[kInitLdsBlocks];              // per draw block: sum of closest
   __shared__ uint32_t dssum[kInitLdsSuper];
   __shared__ uint32_t items[kJMaxItems];
+  __shared__ uint32_t hits[kTMaxI * kInitLdsSuper];      // (candidate, super-block) pairs whose box test passed
   __shared__ int s_touch[2 * kJTouch];
   const MbkP P = probs[blockIdx.x];
   const int tid = threadIdx.x, lane = tid & 63;
@@ -872,7 +875,7 @@ __global__ __launch_bounds__(kJThreads) void mbk_init2_kernel(const uint32_t* __
     psum += sum;
   }
   psum = block_sum<unsigned long long>(psum, sh.red64);
-  if (tid == 0) { cho[0] = P.first; sh.n_touch2[0] = 0; sh.n_touch2[1] = 0; sh.pot = psum; sh.n_items = 0; sh.overflow = 0; }
+  if (tid == 0) { cho[0] = P.first; sh.n_touch2[0] = 0; sh.n_touch2[1] = 0; sh.pot = psum; sh.n_items = 0; sh.n_hits = 0; sh.overflow = 0; }
   if (tid < kTMaxI) sh.delta[tid] = 0;
   if (tid < T && k > 1) sh.R[tid] = (unsigned long long)ceil(rand[P.rand_off + tid] * (double)psum);
   __syncthreads();
@@ -882,8 +885,15 @@ __global__ __launch_bounds__(kJThreads) void mbk_init2_kernel(const uint32_t* __
 #ifdef RHCCQ_STAMPS
   unsigned long long _acc[16] = {0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0};
   unsigned long long _last = clock64();
+  unsigned long long _wacc[4] = {0, 0, 0, 0}, _wt = 0;
+#define WBEGIN() _wt = clock64()
+#define WEND(ph) _wacc[ph] += clock64() - _wt
+#else
+#define WBEGIN() do {} while (0)
+#define WEND(ph) do {} while (0)
 #endif
   for (int c = 1; c < k; ++c) {
+    WBEGIN();
     // the next pick's uniforms are a cold line in HBM: fetch them now, use them at the end of the pick
     double u_next = 0.0;
     if (tid < T && c + 1 < k) u_next = rand[P.rand_off + (size_t)c * T + tid];
@@ -938,12 +948,35 @@ __global__ __launch_bounds__(kJThreads) void mbk_init2_kernel(const uint32_t* __
         }
       }
       if (!found) ck = dsamp[cand].x;
+      const CandP cp = cand_pairs(ck);
       if (lane == 0) {
         sh.cand[t] = cand;
         sh.ckey[t] = ck;
         sh.cna[t] = norm2_key(ck);
-        const CandP cp = cand_pairs(ck);
         sh.ckp[t][0] = cp.r; sh.ckp[t][1] = cp.g; sh.ckp[t][2] = cp.b;
+      }
+      // ... and, while the candidate is in registers, the super-blocks it may improve (their maxima may be mid-refresh by
+      // the idle waves: a stale, larger maximum is conservative); two chunks of 64 per round, one list append for both
+      for (int ch = 0; ch < nch; ch += 2) {
+        const int s0 = ch * 64 + lane, s1 = s0 + 64;
+        bool h0 = false, h1 = false;
+        if (s0 < nsb) {
+          const uint4 se = sup[s0];
+          h0 = box_dist2(cp, se.x, se.y, se.z) < se.w;
+        }
+        if (s1 < nsb) {
+          const uint4 se = sup[s1];
+          h1 = box_dist2(cp, se.x, se.y, se.z) < se.w;
+        }
+        const unsigned long long m0 = __ballot(h0), m1 = __ballot(h1);
+        const int c0 = __popcll(m0), c1 = __popcll(m1);
+        if (c0 + c1) {
+          int base = 0;
+          if (lane == 0) base = atomicAdd(&sh.n_hits, c0 + c1);
+          base = __builtin_amdgcn_readfirstlane(base);
+          if (h0) hits[base + __popcll(m0 & below)] = ((uint32_t)t << 24) | (uint32_t)s0;
+          if (h1) hits[base + c0 + __popcll(m1 & below)] = ((uint32_t)t << 24) | (uint32_t)s1;
+        }
       }
     } else {
       // the other waves refresh the super-block maxima the previous winner touched (a stale, larger maximum is
@@ -955,15 +988,26 @@ __global__ __launch_bounds__(kJThreads) void mbk_init2_kernel(const uint32_t* __
         if ((i & 15) == 0) sup[sb].w = m;
       }
     }
+    WEND(0);
     STAMP(0);
     __syncthreads();
     STAMP(1);
-    // ================= phase 2: which blocks can each candidate improve? =====================================
-    // (candidate, 64 super-blocks) units; hits are expanded to blocks at once and appended to the shared item list
-    for (int u = wave, t = 0, ch = wave; u < T * nch; u += kJWaves, ch += kJWaves) {
-      while (ch >= nch) { ch -= nch; ++t; }                // unit u = (candidate t, chunk ch)
-      const CandP cp{sh.ckp[t][0], sh.ckp[t][1], sh.ckp[t][2]};
-      j_enumerate(cp, ch * 64, nsb, nb, sup, blk, [&](unsigned long long mb, int b, bool hb) {
+    WBEGIN();
+    // ================= phase 2: hit super-blocks -> blocks ====================================================
+    // four (candidate, super-block) hits per wave instruction stream, one row of lanes each, one lane per block
+    {
+      const int n_hits = sh.n_hits;
+      for (int h0 = 4 * wave; h0 < n_hits; h0 += 4 * kJWaves) {
+        const uint32_t hw = h0 + rq < n_hits ? hits[h0 + rq] : 0xffffffffu;
+        const int t = (int)(hw >> 24) & (kTMaxI - 1);
+        const int b = (int)(hw & 0xffffffu) * 16 + rj;
+        bool hb = hw != 0xffffffffu && b < nb;
+        if (hb) {
+          const CandP cp{sh.ckp[t][0], sh.ckp[t][1], sh.ckp[t][2]};
+          const uint4 be = blk[b];
+          hb = box_dist2(cp, be.x, be.y, be.z) < be.w;
+        }
+        const unsigned long long mb = __ballot(hb);
         const int cnt = __popcll(mb);
         if (cnt) {
           int base = 0;
@@ -972,11 +1016,13 @@ __global__ __launch_bounds__(kJThreads) void mbk_init2_kernel(const uint32_t* __
           if (base + cnt > max_items) { if (lane == 0) sh.overflow = 1; }
           else if (hb) items[base + __popcll(mb & below)] = ((uint32_t)t << 24) | (uint32_t)b;
         }
-      });
+      }
     }
+    WEND(1);
     STAMP(2);
     __syncthreads();
     STAMP(3);
+    WBEGIN();
     // ================= phase 3: potentials ===================================================================
     const bool use_list = sh.overflow == 0;
     const int n_items = use_list ? sh.n_items : 0;
@@ -987,25 +1033,30 @@ __global__ __launch_bounds__(kJThreads) void mbk_init2_kernel(const uint32_t* __
     uint4 ka[kJKeep], kb[kJKeep];
     uint32_t kw[kJKeep];
     if (use_list) {
+      // (wave-uniform guards: an unused slot costs two scalar instructions; a row beyond the list re-reads the last item
+      // and contributes nothing -- no divergent control flow inside a slot)
 #pragma unroll
       for (int s = 0; s < kJKeep; ++s) {
-        const int ii = 4 * (wave + s * kJWaves) + rq;
-        kw[s] = ii < n_items ? items[ii] : 0xffffffffu;
+        kw[s] = 0xffffffffu;
         ka[s] = make_uint4(0, 0, 0, 0);
         kb[s] = ka[s];
-        if (kw[s] != 0xffffffffu) {
-          const uint4* p4 = reinterpret_cast<const uint4*>(samp + ((kw[s] & 0xffffffu) << 6) + 4 * rj);
+        if (4 * (wave + s * kJWaves) < n_items) {
+          const int ii = 4 * (wave + s * kJWaves) + rq;
+          const uint32_t w = items[min(ii, n_items - 1)];
+          const uint4* p4 = reinterpret_cast<const uint4*>(samp + ((w & 0xffffffu) << 6) + 4 * rj);
           ka[s] = p4[0];
           kb[s] = p4[1];
+          kw[s] = ii < n_items ? w : (w | 0xf0000000u);    // candidate numbers are < 16: the high nibble marks a padding row
         }
       }
 #pragma unroll
       for (int s = 0; s < kJKeep; ++s) {
-        const bool on = kw[s] != 0xffffffffu;
-        const int t = on ? (int)(kw[s] >> 24) : 0;
-        unsigned imp = on ? j_eval4(sh.ckey[t], (int)sh.cna[t], ka[s], kb[s]) : 0u;
-        imp = dpp_row_sum(imp);
-        if (on && rj == 0 && imp) atomicAdd(&sh.delta[t], (unsigned long long)imp);
+        if (4 * (wave + s * kJWaves) < n_items) {
+          const int t = (int)(kw[s] >> 24) & (kTMaxI - 1);
+          unsigned imp = j_eval4(sh.ckey[t], (int)sh.cna[t], ka[s], kb[s]);
+          imp = dpp_row_sum((kw[s] >> 28) ? 0u : imp);
+          if (rj == 0 && imp) atomicAdd(&sh.delta[t], (unsigned long long)imp);
+        }
       }
       for (int o = wave + kJKeep * kJWaves; o < n_ops; o += kJWaves) {   // more items than the registers hold
         const int ii = 4 * o + rq;
@@ -1042,6 +1093,7 @@ __global__ __launch_bounds__(kJThreads) void mbk_init2_kernel(const uint32_t* __
         if (lane == 0) sh.delta[t] = acc;
       }
     }
+    WEND(2);
     STAMP(4);
 #ifdef RHCCQ_STAMPS
     _acc[10] += (unsigned long long)n_items;
@@ -1050,6 +1102,7 @@ __global__ __launch_bounds__(kJThreads) void mbk_init2_kernel(const uint32_t* __
 #endif
     __syncthreads();
     STAMP(5);
+    WBEGIN();
     // ================= phase 4: greedy choice + commit =======================================================
     // largest reduction == smallest potential; the first candidate wins ties
     const unsigned long long dv = lane < T ? sh.delta[lane] : 0ull;
@@ -1063,9 +1116,11 @@ __global__ __launch_bounds__(kJThreads) void mbk_init2_kernel(const uint32_t* __
     if (use_list && kept) {
 #pragma unroll
       for (int s = 0; s < kJKeep; ++s) {
-        const bool mine = kw[s] != 0xffffffffu && (int)(kw[s] >> 24) == best;
-        if (__ballot(mine))
-          j_commit_row(mine, (int)(kw[s] & 0xffffffu), kbest, nabest, ka[s], kb[s], samp, dsamp, blk, dsum, dssum, touch_w, n_touch_w);
+        if (4 * (wave + s * kJWaves) < n_items) {
+          const bool mine = (int)(kw[s] >> 24) == best;     // (a padding row's high nibble never matches)
+          if (__ballot(mine))
+            j_commit_row(mine, (int)(kw[s] & 0xffffffu), kbest, nabest, ka[s], kb[s], samp, dsamp, blk, dsum, dssum, touch_w, n_touch_w);
+        }
       }
     } else if (use_list) {
       for (int o = wave; o < n_ops; o += kJWaves) {
@@ -1097,8 +1152,9 @@ __global__ __launch_bounds__(kJThreads) void mbk_init2_kernel(const uint32_t* __
         });
       }
     }
-    if (tid == 0) { cho[c] = sh.cand[best]; sh.pot = pot - bd; sh.n_items = 0; sh.overflow = 0; sh.n_touch2[(c + 1) & 1] = 0; }
+    if (tid == 0) { cho[c] = sh.cand[best]; sh.pot = pot - bd; sh.n_items = 0; sh.n_hits = 0; sh.overflow = 0; sh.n_touch2[(c + 1) & 1] = 0; }
     if (tid < T) sh.R[tid] = (unsigned long long)ceil(u_next * (double)(pot - bd));
+    WEND(3);
     STAMP(6);
     __syncthreads();
     STAMP(7);
@@ -1117,6 +1173,8 @@ __global__ __launch_bounds__(kJThreads) void mbk_init2_kernel(const uint32_t* __
 #ifdef RHCCQ_STAMPS
   if (tid == 0 && blockIdx.x == gridDim.x - 1)
     for (int i = 0; i < 16; ++i) g_init_stamps[i] += _acc[i];
+  if (lane == 0 && blockIdx.x == gridDim.x - 1)
+    for (int i = 0; i < 4; ++i) atomicAdd(&g_wave_stamps[i][wave], _wacc[i]);
 #endif
   for (int j = tid; j < k; j += kJThreads) {
     const uint32_t kk = dsamp[cho[j]].x;
@@ -2139,6 +2197,11 @@ static int layout_work(rhccq_ctx* ctx, const rhccq_mbk_problem* probs, int n_pro
 int rhccq_debug_upd_stamps(unsigned long long* out16_host) {
   if (hipDeviceSynchronize() != hipSuccess) return -2;
   if (hipMemcpyFromSymbol(out16_host, HIP_SYMBOL(g_upd_stamps), sizeof(unsigned long long) * 16) != hipSuccess) return -2;
+  return 0;
+}
+int rhccq_debug_wave_stamps(unsigned long long* out64_host) {
+  if (hipDeviceSynchronize() != hipSuccess) return -2;
+  if (hipMemcpyFromSymbol(out64_host, HIP_SYMBOL(g_wave_stamps), sizeof(unsigned long long) * 64) != hipSuccess) return -2;
   return 0;
 }
 int rhccq_debug_stamps(unsigned long long* out16_host) {

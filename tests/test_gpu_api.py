@@ -159,3 +159,51 @@ def test_mirrored_api_under_a_non_default_stream():
     d = get_all_unique_colors(g["img0"], (0, 0))                             # and back on the default stream
     assert rh._bound == torch.cuda.current_stream().cuda_stream
     torch.cuda.synchronize()
+
+
+def test_config0_lenna512_reference_chain():
+    """BASELINE.json configs[0]: the whole 512x512 Lenna PNG, 64 segments, tiers (20, 10), through the mirrored notebook chain,
+    against the REFERENCE's own outputs (tests/golden/g12_lenna512.*, make_golden_lenna512.py; no oracle in between).
+    Tier per level: level 1 (both classes) and level 2 (both classes) bit-identical palettes and index maps (A); final level:
+    every pixel's colour identical, palette order permuted (A': the reference appends the k-means children of oversize
+    clusters in thread-completion order, this build in label order) -- so the decoded image is the reference's, byte for byte."""
+    import hashlib
+    import json
+    from PIL import Image
+    from encoder.compression.subregions import subregion_quantization
+    from encoder.compression.regions import region_quantization
+    from encoder.compression.image import quantize_image
+    g = np.load(os.path.join(G, "g12_lenna512.npz"))
+    meta = json.load(open(os.path.join(G, "g12_lenna512.json")))
+    img = np.asarray(Image.open(os.path.join(G, "Lenna.png")).convert("RGB"), dtype=np.uint8)
+    H, W = img.shape[:2]
+    qs = [int(v) for v in g["q"]]
+    l1 = []
+    for key, q, t in (("lab_roi", qs[0], "ROI"), ("lab_non", qs[1], "nonROI")):
+        lab = g[key].astype(np.int32) + 1
+        mask = lab > 0
+        rows, cols = np.where(mask)
+        bbox = (int(rows.min()), int(cols.min()), int(rows.max()) + 1, int(cols.max()) + 1)
+        sl = (slice(bbox[0], bbox[2]), slice(bbox[1], bbox[3]))
+        l1.append(subregion_quantization(img, [{"bbox": bbox, "bbox_mask": mask[sl]}], quality=q, subregion_type=t,
+                                         segmenter=lambda im, m, s=lab[sl]: s))
+
+    def same(nm, seg):
+        p, i = arrs(seg)
+        lv = meta["levels"][nm]
+        assert np.array_equal(p, g[f"{nm}_pal"]), (nm, "palette")
+        assert hashlib.sha256(i.astype(np.int32).tobytes()).hexdigest() == lv["indices_sha256"], (nm, "indices")
+        assert list(seg["top_left"]) == lv["top_left"] and list(seg["shape"]) == lv["shape"], nm
+    same("roi1", l1[0][0][0])
+    same("non1", l1[1][0][0])
+    q2 = [min(q * 2, 100) for q in qs]
+    roi2 = region_quantization(l1[0], quality=q2[0], original_image_height=H, original_image_width=W)
+    non2 = region_quantization(l1[1], quality=q2[1], original_image_height=H, original_image_width=W)
+    same("roi2", roi2[0])
+    same("non2", non2[0])
+    fin = quantize_image(roi2 + non2, quality=min(sum(q2), 100), original_image_height=H, original_image_width=W)
+    p, i = arrs(fin)
+    gp, gi = g["fin_pal"], g["fin_idx"].astype(np.int64).reshape(-1)
+    assert len(p) == len(gp) == meta["levels"]["fin"]["colours"]
+    assert np.array_equal(p[i], gp[gi])                      # the decoded frame is the reference's
+    assert np.array_equal(np.unique(p, axis=0), np.unique(gp, axis=0))

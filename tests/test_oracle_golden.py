@@ -322,3 +322,29 @@ def test_quality_metrics_restatement_against_the_definition():
     assert abs(m["psnr"] - 10 * np.log10(255.0 ** 2 / mse)) < 1e-12
     assert abs(float(m["mse"]) - mse) < 1e-3 and m["mse"].dtype == np.float32
     assert m["max_error"] == np.abs(x.astype(int) - y.astype(int)).max()
+
+
+@pytest.mark.skipif(os.environ.get("RHCCQ_SLOW") != "1", reason="80 s of numpy: set RHCCQ_SLOW=1 (the GPU suite checks G12 directly)")
+def test_g12_lenna512_chain_tiers():
+    """configs[0] (whole Lenna, 64 segments, tiers 20/10) through the oracle vs the reference's own outputs: levels 1-2 exact,
+    final frame identical with the palette permuted (A')."""
+    import hashlib
+    from PIL import Image
+    g = load("g12_lenna512.npz")
+    meta = json.load(open(os.path.join(G, "g12_lenna512.json")))
+    img = np.asarray(Image.open(os.path.join(G, "Lenna.png")).convert("RGB"), dtype=np.uint8)
+    classes = []
+    for key in ("lab_roi", "lab_non"):
+        lab = g[key].astype(np.int32) + 1
+        mask = lab > 0
+        rows, cols = np.where(mask)
+        bbox = (int(rows.min()), int(cols.min()), int(rows.max()) + 1, int(cols.max()) + 1)
+        sl = (slice(bbox[0], bbox[2]), slice(bbox[1], bbox[3]))
+        classes.append([{"bbox": bbox, "bbox_mask": mask[sl], "seglabels": lab[sl]}])
+    ref = O.encode_frame(img, classes, [20, 10])
+    for nm, r in (("roi1", ref["level1"][0][0]), ("non1", ref["level1"][1][0]), ("roi2", ref["level2"][0]), ("non2", ref["level2"][1])):
+        assert np.array_equal(np.asarray(r["palette"]).reshape(-1, 3), g[f"{nm}_pal"]), nm
+        assert hashlib.sha256(np.asarray(r["indices"]).reshape(-1).astype(np.int32).tobytes()).hexdigest() == meta["levels"][nm]["indices_sha256"], nm
+    p = np.asarray(ref["final"]["palette"]).reshape(-1, 3)
+    i = np.asarray(ref["final"]["indices"]).reshape(-1)
+    assert np.array_equal(p[i], g["fin_pal"][g["fin_idx"].astype(np.int64).reshape(-1)])

@@ -28,3 +28,9 @@ for n, x in zip(names, v[:8]):
     print(f"{n:18s} {x:10.0f} cycles/pick  {100*x/tot:5.1f}%")
 print("total cycles/pick (thread 0)", tot)
 print("items/pick", v[10], "picks not kept", v[11], "picks overflow", v[12])
+out = (ctypes.c_ulonglong * 64)()
+rh._raw.rhccq_debug_wave_stamps.argtypes = [ctypes.c_void_p]
+print("rc", rh._raw.rhccq_debug_wave_stamps(out))
+w = np.array(list(out), dtype=np.float64).reshape(4, 16) / (k - 1)
+for ph, name in enumerate(["search+E1", "E2", "evaluate", "commit"]):
+    print(f"{name:10s} per wave:", " ".join(f"{x:5.0f}" for x in w[ph]))
