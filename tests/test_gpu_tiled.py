@@ -83,3 +83,51 @@ def test_tiled_two_ranks_equals_single_gpu(size):
         assert np.array_equal(pal, single["palette"])
         full[r0:r0 + h, c0:c0 + w] = idx
     assert np.array_equal(full, sidx.astype(np.int64))
+
+
+def _nccl_worker(rank, world, port, ret):
+    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), HSA_ENABLE_IPC_MODE_LEGACY="0")
+    torch.cuda.set_device(rank)
+    dist.init_process_group("nccl", rank=rank, world_size=world, device_id=torch.device("cuda", rank))
+    try:
+        from roibasedimagecompression_amd.frame import ClassSpec
+        from roibasedimagecompression_amd.ops import Rhccq
+        from roibasedimagecompression_amd.parallel import TiledFrameEncoder, tile_grid
+        img, (lr, nr, br), (ln, nn, bn) = _inputs("small")
+        H, W = img.shape[:2]
+        rh = Rhccq(rank)
+        tiles = tile_grid(H, W, 1, world)
+        r0, c0, h, w = tiles[rank]
+        sl = (slice(r0, r0 + h), slice(c0, c0 + w))
+        specs = [ClassSpec(torch.from_numpy(np.ascontiguousarray(lr[sl])).to(rh.device), np.zeros(nr, np.int64), [br], 20),
+                 ClassSpec(torch.from_numpy(np.ascontiguousarray(ln[sl])).to(rh.device), np.zeros(nn, np.int64), [bn], 10)]
+        enc = TiledFrameEncoder(rh, (H, W), tiles[rank]).set_tiles(tiles)
+        out = enc.encode(torch.from_numpy(np.ascontiguousarray(img[sl])).to(rh.device), specs)
+        idx = out["indices"].cpu().numpy()
+        ret[rank] = (out["palette"], idx.view(np.uint16) if out["indices_dtype"] == "uint16" else idx, tiles[rank])
+    finally:
+        dist.destroy_process_group()
+
+
+@pytest.mark.skipif(torch.cuda.device_count() < 2, reason="needs two GPUs: the RCCL path (the one-GPU box runs the same code over gloo)")
+def test_tiled_two_ranks_over_rccl():
+    """the tile-parallel exchange over backend `nccl` (= RCCL over xGMI), payloads staying on the device, two GPUs"""
+    from roibasedimagecompression_amd.frame import ClassSpec, FrameEncoder
+    from roibasedimagecompression_amd.ops import Rhccq
+    img, (lr, nr, br), (ln, nn, bn) = _inputs("small")
+    H, W = img.shape[:2]
+    rh = Rhccq(0)
+    specs = [ClassSpec(torch.from_numpy(lr).to(rh.device), np.zeros(nr, np.int64), [br], 20),
+             ClassSpec(torch.from_numpy(ln).to(rh.device), np.zeros(nn, np.int64), [bn], 10)]
+    single = FrameEncoder(rh).encode(torch.from_numpy(img).to(rh.device), specs)
+    sidx = single["indices"].cpu().numpy()
+    if single["indices_dtype"] == "uint16":
+        sidx = sidx.view(np.uint16)
+    ret = mp.Manager().dict()
+    mp.spawn(_nccl_worker, args=(2, _free_port(), ret), nprocs=2, join=True)
+    full = np.zeros((H, W), np.int64)
+    for rank in (0, 1):
+        pal, idx, (r0, c0, h, w) = ret[rank]
+        assert np.array_equal(pal, single["palette"])
+        full[r0:r0 + h, c0:c0 + w] = idx
+    assert np.array_equal(full, sidx.astype(np.int64))
