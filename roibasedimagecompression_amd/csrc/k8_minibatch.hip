@@ -1566,6 +1566,12 @@ __global__ __launch_bounds__(kUpdThreads) void mbk_update_kernel(const uint32_t*
   double since = st_since + (double)bs;
   const bool do_reassign = st_nzero > 0.0 || since >= 10.0 * (double)k;
   if (do_reassign) since = 0.0;
+#ifdef RHCCQ_STAMPS
+  const unsigned long long _t_role = clock64();
+#define ROLE_END(r) do { if (p == 0) atomicAdd(&g_upd_stamps[8 + (r)], clock64() - _t_role); } while (0)
+#else
+#define ROLE_END(r) do {} while (0)
+#endif
   if (role == 1) {
     // ---- batch inertia + sklearn _mini_batch_convergence (EWA early stopping) ------------------------------
     if (wave != 0) return;
@@ -1596,6 +1602,7 @@ __global__ __launch_bounds__(kUpdThreads) void mbk_update_kernel(const uint32_t*
     }
     if (step + 1 >= n_steps_max && stop == 0.0) stop = 2.0;
     if (stop != 0.0) { st[4] = stop; st[11] = (double)(step + 1); }
+    ROLE_END(1);
     return;
   }
   if (role == 2) {
@@ -1605,6 +1612,7 @@ __global__ __launch_bounds__(kUpdThreads) void mbk_update_kernel(const uint32_t*
     if (tid == 0) {
       if (c < 0) st[4] = 3.0;                            // word table exhausted (the host sizes it so that this cannot happen)
       else st[st_slot(kStCursor, step + 1)] = (double)c;
+      ROLE_END(2);
     }
     return;
   }
@@ -1833,6 +1841,7 @@ __global__ __launch_bounds__(kUpdThreads) void mbk_update_kernel(const uint32_t*
     }
   }
   USTAMP(5);
+  if (tid == 0) ROLE_END(0);
 }
 
 // ------------------------------------------------------------------------------------------------

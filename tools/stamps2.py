@@ -34,3 +34,10 @@ print("rc", rh._raw.rhccq_debug_wave_stamps(out))
 w = np.array(list(out), dtype=np.float64).reshape(4, 16) / (k - 1)
 for ph, name in enumerate(["search+E1", "E2", "evaluate", "commit"]):
     print(f"{name:10s} per wave:", " ".join(f"{x:5.0f}" for x in w[ph]))
+out2 = (ctypes.c_ulonglong * 16)()
+rh._raw.rhccq_debug_upd_stamps.argtypes = [ctypes.c_void_p]
+print("rc", rh._raw.rhccq_debug_upd_stamps(out2))
+u = np.array(list(out2), dtype=np.float64)
+calls = max(u[15], 1)
+print("update kernel, problem 0: steps", int(calls), "cycles per step: role0", round(u[8] / calls), "role1", round(u[9] / calls), "role2", round(u[10] / calls),
+      "| role 0 phases:", [round(x / calls) for x in u[:6]])
