@@ -1210,25 +1210,83 @@ __device__ __forceinline__ bool mbk_stopped(const double* st, long long step, lo
   const long long bs = n < 1000 ? n : 1000;
   return (stop_at != 0.0 && (double)step >= stop_at) || st[4] == 3.0 || step >= (100 * n) / bs;
 }
+// Batch inertia of step `step` + sklearn _mini_batch_convergence (EWA early stopping), one wave.  The 1 000 terms (fold
+// kernel, against the centres before the update) are added ONE AFTER THE OTHER in batch order, as sklearn's
+// single-threaded _inertia_dense does -- a chain of ~1 000 dependent float64 additions, ~10 us.  Nothing of step `step`
+// needs its outcome, only the NEXT update does, so the chain rides in an extra workgroup of the next step's E-step
+// kernel (and in a kernel of its own behind the last step of a launch sequence).
+__device__ __forceinline__ void mbk_inertia_block(const MbkP& P, double* st, long long step, const double* __restrict__ pper_p, double* s_per) {
+  const int lane = threadIdx.x;
+  if (lane >= 64) return;
+  const long long n = P.n;
+  const int bs = (int)min((long long)1000, n);
+  const long long n_steps_max = (100 * n) / bs;
+  for (int i = lane; i < kBatch; i += 64) s_per[i] = i < bs ? pper_p[i] : 0.0;    // rows beyond the batch: + 0.0 changes nothing
+  __builtin_amdgcn_s_waitcnt(0);
+  __builtin_amdgcn_wave_barrier();
+  if (lane != 0) return;
+  double inertia = 0.0;
+  for (int b = 0; b < kBatch; b += 8) {
+    const double4 u = *reinterpret_cast<const double4*>(&s_per[b]), v = *reinterpret_cast<const double4*>(&s_per[b + 4]);
+    inertia = inertia + u.x; inertia = inertia + u.y; inertia = inertia + u.z; inertia = inertia + u.w;
+    inertia = inertia + v.x; inertia = inertia + v.y; inertia = inertia + v.z; inertia = inertia + v.w;
+  }
+  st[5] = (double)(step + 1);
+  double stop = 0.0;
+  const double binert = inertia / (double)bs;
+  if (step + 1 != 1) {
+    double ewa;
+    if (st[6] == 0.0) { ewa = binert; st[6] = 1.0; }
+    else {
+      double a = (double)bs * 2.0 / ((double)n + 1.0);
+      a = a < 1.0 ? a : 1.0;
+      ewa = st[0] * (1.0 - a) + binert * a;
+    }
+    st[0] = ewa;
+    if (st[7] == 0.0 || ewa < st[1]) { st[2] = 0.0; st[1] = ewa; st[7] = 1.0; }
+    else st[2] += 1.0;
+    if (st[2] >= 10.0) stop = 1.0;
+  }
+  if (step + 1 >= n_steps_max && stop == 0.0) stop = 2.0;
+  if (stop != 0.0) { st[4] = stop; st[11] = (double)(step + 1); }
+}
+
+// the inertia of the last step of a launch sequence (nothing follows it to ride on)
+__global__ __launch_bounds__(64) void mbk_inertia_kernel(const MbkP* __restrict__ probs, double* __restrict__ state, long long step,
+                                                         const double* __restrict__ pper) {
+  __shared__ double s_per[kBatch];
+  const int p = blockIdx.x;
+  const MbkP P = probs[p];
+  double* st = state + p * 16;
+  if (step < 0 || mbk_stopped(st, step, P.n)) return;
+  mbk_inertia_block(P, st, step, pper + (size_t)p * kBatch, s_per);
+}
+
 // kSplit threads share one batch point, each scanning a contiguous 1/kSplit of the tile's centres: with a single
 // straggler problem still running there are only ~160 workgroups for 256 CUs and a thread's serial walk over 512
 // centres (one wave per SIMD, ~8 cycles per dependent f64 instruction) is the whole step; splitting the walk keeps
 // the arithmetic and the first-arg-min order (lower slices win ties) and shortens the chain.
 template <int kSplit>
 __global__ __launch_bounds__(256) void mbk_batch_estep_kernel(const uint32_t* __restrict__ keys, const MbkP* __restrict__ probs,
-                                                              const double* __restrict__ centres, const double* __restrict__ state,
+                                                              const double* __restrict__ centres, double* __restrict__ state,
                                                               long long step, const uint32_t* __restrict__ bkeys, double* __restrict__ pdist,
-                                                              int32_t* __restrict__ pidx, const long long* __restrict__ part_off) {
+                                                              int32_t* __restrict__ pidx, const long long* __restrict__ part_off,
+                                                              const double* __restrict__ pper_prev) {
   constexpr int kPts = 256 / kSplit, kSlice = kTileC / kSplit;
   const int p = blockIdx.y;
   const MbkP P = probs[p];                               // independent table reads, issued together
   const long long po = part_off[p];
+  __shared__ double sc[kTileC * 4];
+  if (blockIdx.x == gridDim.x - 1) {                     // the extra workgroup: inertia + EWA rule of the PREVIOUS step
+    if (pper_prev != nullptr && !mbk_stopped(state + p * 16, step - 1, P.n))
+      mbk_inertia_block(P, state + p * 16, step - 1, pper_prev + (size_t)p * kBatch, sc);
+    return;
+  }
   if (mbk_stopped(state + p * 16, step, P.n)) return;
   const int n_tiles = (int)((P.k + kTileC - 1) / kTileC);
   const int tile = blockIdx.x / (kPtChunks * kSplit), chunk = blockIdx.x % (kPtChunks * kSplit);
   if (tile >= n_tiles) return;
   const int bs = (int)min((long long)1000, P.n);
-  __shared__ double sc[kTileC * 4];
   __shared__ double s_bd[kSplit > 1 ? 256 : 1];
   __shared__ int s_bj[kSplit > 1 ? 256 : 1];
   const int j0 = tile * kTileC, nj = (int)min((long long)kTileC, P.k - j0);
@@ -1452,8 +1510,10 @@ __device__ __forceinline__ long long replay_permutation(const uint32_t* __restri
       const long long wi = c + lane, so = wi - stage_base;
       const uint32_t w = (so >= 0 && so < kStageWords) ? sh.stage[so] : words[wi];
       const unsigned long long below = (1ull << lane) - 1ull;
-      unsigned long long rejm = 0ull;                    // confirmed rejections of this window
-      int known = 0;                                     // lanes below `known` are settled
+      // fixed point of "lane t faces i_cur - t + (rejections before t)": lane t's verdict only depends on the lanes below
+      // it, so every sweep settles at least one more lane and a sweep that changes nothing has found THE solution; most
+      // verdicts do not depend on the few rejections before them, so 2-4 sweeps do (a lane-by-lane walk needed ~17)
+      unsigned long long rejm = 0ull;
       int i_t;
       uint32_t m;
       bool valid;
@@ -1461,12 +1521,9 @@ __device__ __forceinline__ long long replay_permutation(const uint32_t* __restri
         i_t = i_cur - lane + __popcll(rejm & below);
         valid = i_t >= 1;
         m = valid ? (0xffffffffu >> __clz((unsigned)i_t)) : 0u;
-        unsigned long long nm = __ballot(valid && (w & m) > (unsigned)i_t);
-        nm &= known >= 64 ? 0ull : ~((1ull << known) - 1ull);
-        if (!nm) break;
-        const int t1 = __ffsll((long long)nm) - 1;
-        rejm |= 1ull << t1;
-        known = t1 + 1;
+        const unsigned long long nm = __ballot(valid && (w & m) > (unsigned)i_t);
+        if (nm == rejm) break;
+        rejm = nm;
       }
       const bool acc = valid && !((rejm >> lane) & 1ull);
       if (acc) sh.jswap[i_t] = (unsigned short)(w & m);
@@ -1486,9 +1543,14 @@ __device__ __forceinline__ long long replay_permutation(const uint32_t* __restri
   const long long out = sh.cursor;
   if (out >= 0 && tid < n_take) {
     int pos = tid;
-    for (int i = 1; i < bs; ++i) {
-      const int j = sh.jswap[i];
-      pos = pos == i ? j : (pos == j ? i : pos);
+    for (int i0 = 0; i0 < bs; i0 += 8) {                   // eight swaps per LDS read (entry 0 is no swap)
+      const uint4 v = *reinterpret_cast<const uint4*>(&sh.jswap[i0]);
+      const unsigned jj[8] = {v.x & 0xffffu, v.x >> 16, v.y & 0xffffu, v.y >> 16, v.z & 0xffffu, v.z >> 16, v.w & 0xffffu, v.w >> 16};
+#pragma unroll
+      for (int q = 0; q < 8; ++q) {
+        const int i = i0 + q, j = (int)jj[q];
+        if (i >= 1 && i < bs) pos = pos == i ? j : (pos == j ? i : pos);
+      }
     }
     sh.perm[tid] = pos;
   }
@@ -1532,21 +1594,19 @@ __device__ unsigned long long g_upd_stamps[16];
 #define USTAMP(slot) do {} while (0)
 #endif
 
-// One mini-batch step after its E-step (sklearn _mini_batch_step + _mini_batch_convergence): THREE workgroups per problem
-// (blockIdx.y = role), on three CUs, because the step is a chain of latencies and these three chains are independent:
+// One mini-batch step after its E-step (sklearn _mini_batch_step): TWO workgroups per problem (blockIdx.y = role), on two
+// CUs, because the step is a chain of latencies and these chains are independent:
 //   role 0  centre update (update_center_dense) and, in the rare steps that reassign low-count centres, the reassignment
 //           with its choice() replay followed by the next batch's draw;
-//   role 1  the batch inertia -- 1 000 terms added one after the other, as sklearn's single-threaded _inertia_dense does
-//           (the terms come from the fold kernel, evaluated against the centres before the update) -- and the EWA rule;
-//   role 2  the next step's batch (randint replay + colour gather) whenever this step does not reassign (then the stream
+//   role 1  the next step's batch (randint replay + colour gather) whenever this step does not reassign (then the stream
 //           position is known before the step starts).
+// (The third chain, batch inertia + EWA rule, rides in the next step's E-step kernel: mbk_inertia_block.)
 __global__ __launch_bounds__(kUpdThreads) void mbk_update_kernel(const uint32_t* __restrict__ keys, const MbkP* __restrict__ probs,
                                                                  double* __restrict__ centres, double* __restrict__ weights,
                                                                  double* __restrict__ state, long long step,
                                                                  const uint32_t* __restrict__ words, long long n_words,
                                                                  const uint32_t* __restrict__ bkeys_cur, uint32_t* __restrict__ bkeys_next,
-                                                                 const double* __restrict__ pper, const int32_t* __restrict__ pidx,
-                                                                 const long long* __restrict__ part_off) {
+                                                                 const int32_t* __restrict__ pidx, const long long* __restrict__ part_off) {
   __shared__ UpdShared sh;
   const int p = blockIdx.x, role = blockIdx.y, tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
   double* st = state + p * kStateStride;
@@ -1558,7 +1618,6 @@ __global__ __launch_bounds__(kUpdThreads) void mbk_update_kernel(const uint32_t*
   const int k = (int)P.k;
   const long long n = P.n;
   const int bs = (int)min((long long)1000, n);
-  const long long n_steps_max = (100 * n) / bs;
   long long cursor = (long long)st_cursor;
   // reassignment decision uses the weights BEFORE this step's update (sklearn _random_reassign):
   // n_zero = number of zero-weight centres, maintained by the reassignment sweep (it can only be non-zero
@@ -1573,46 +1632,13 @@ __global__ __launch_bounds__(kUpdThreads) void mbk_update_kernel(const uint32_t*
 #define ROLE_END(r) do {} while (0)
 #endif
   if (role == 1) {
-    // ---- batch inertia + sklearn _mini_batch_convergence (EWA early stopping) ------------------------------
-    if (wave != 0) return;
-    for (int i = lane; i < kBatch; i += 64) sh.per[i] = i < bs ? pper[(size_t)p * kBatch + i] : 0.0;
-    __syncthreads();                                     // (only this wave is left in the workgroup)
-    if (lane != 0) return;
-    double inertia = 0.0;
-    for (int b = 0; b < kBatch; b += 8) {                // rows beyond the batch hold +0.0: x + 0 = x
-      const double4 u = *reinterpret_cast<const double4*>(&sh.per[b]), v = *reinterpret_cast<const double4*>(&sh.per[b + 4]);
-      inertia = inertia + u.x; inertia = inertia + u.y; inertia = inertia + u.z; inertia = inertia + u.w;
-      inertia = inertia + v.x; inertia = inertia + v.y; inertia = inertia + v.z; inertia = inertia + v.w;
-    }
-    st[5] = (double)(step + 1);
-    double stop = 0.0;
-    const double binert = inertia / (double)bs;
-    if (step + 1 != 1) {
-      double ewa;
-      if (st[6] == 0.0) { ewa = binert; st[6] = 1.0; }
-      else {
-        double a = (double)bs * 2.0 / ((double)n + 1.0);
-        a = a < 1.0 ? a : 1.0;
-        ewa = st[0] * (1.0 - a) + binert * a;
-      }
-      st[0] = ewa;
-      if (st[7] == 0.0 || ewa < st[1]) { st[2] = 0.0; st[1] = ewa; st[7] = 1.0; }
-      else st[2] += 1.0;
-      if (st[2] >= 10.0) stop = 1.0;
-    }
-    if (step + 1 >= n_steps_max && stop == 0.0) stop = 2.0;
-    if (stop != 0.0) { st[4] = stop; st[11] = (double)(step + 1); }
-    ROLE_END(1);
-    return;
-  }
-  if (role == 2) {
     // ---- the next step's batch: minibatch_indices = random_state.randint(0, n_samples, batch_size) ------------
     if (do_reassign) return;                             // the stream position depends on this step's choice(): role 0 draws
     const long long c = draw_batch(keys, P, words, n_words, cursor, bkeys_next + (size_t)p * kBatch, sh.lab, sh.ired, &sh.cursor);
     if (tid == 0) {
       if (c < 0) st[4] = 3.0;                            // word table exhausted (the host sizes it so that this cannot happen)
       else st[st_slot(kStCursor, step + 1)] = (double)c;
-      ROLE_END(2);
+      ROLE_END(1);
     }
     return;
   }
@@ -1719,15 +1745,21 @@ __global__ __launch_bounds__(kUpdThreads) void mbk_update_kernel(const uint32_t*
     const bool use_hist = nbins <= kHistBins;
     for (int i = tid; i < kHistBins; i += kUpdThreads) sh.hist[i] = 0;
     __syncthreads();
-    int cnt = 0;
-    for (int j = tid; j < k; j += kUpdThreads) {
+    int cnt = 0, c0 = 0, c1 = 0;                           // candidates; of them with weight 0 / 1 (the hot bins of the first
+    for (int j = tid; j < k; j += kUpdThreads) {           // steps: ~k centres share them -- counted in registers, not by atomics)
       const double w = W[j];
       if (w < thr) {
         ++cnt;
-        if (use_hist) atomicAdd(&sh.hist[(int)w], 1);
+        if (w == 0.0) ++c0;
+        else if (w == 1.0) ++c1;
+        else if (use_hist) atomicAdd(&sh.hist[(int)w], 1);
       }
     }
     cnt = block_sum_i(cnt, sh);
+    c0 = block_sum_i(c0, sh);
+    c1 = block_sum_i(c1, sh);
+    if (tid == 0 && use_hist) { sh.hist[0] = c0; if (kHistBins > 1 && thr > 1.0) sh.hist[1] = c1; }
+    __syncthreads();
     // more than batch/2 candidates: sklearn keeps np.argsort(weights)[:batch/2] -- an unstable sort over tied counts;
     // CANONICAL: the stable order (weight, index), the one choice of this path that is not sklearn's own
     const bool capped = cnt > 0.5 * (double)bs;
@@ -2017,13 +2049,19 @@ __device__ __forceinline__ void grid_scan_shell(int r_lo, int r_hi, int cx, int 
 // batch E-step through the grid (many problems in flight: the brute-force E-step would be the bottleneck);
 // writes the same (distance, label) the tiled kernel + tile reduction produce, into tile 0 of the partials
 __global__ __launch_bounds__(256) void mbk_batch_estep_grid_kernel(const uint32_t* __restrict__ keys, const MbkP* __restrict__ probs,
-                                                                   const double* __restrict__ centres, const double* __restrict__ state,
+                                                                   const double* __restrict__ centres, double* __restrict__ state,
                                                                    long long step, const uint32_t* __restrict__ bkeys,
-                                                                   const uint32_t* __restrict__ cell_start,
+                                                                   const double* __restrict__ pper_prev, const uint32_t* __restrict__ cell_start,
                                                                    const uint32_t* __restrict__ order, double* __restrict__ pdist,
                                                                    int32_t* __restrict__ pidx, const long long* __restrict__ part_off) {
   const int p = blockIdx.y;
   const MbkP P = probs[p];
+  if (blockIdx.x == gridDim.x - 1) {                     // the extra workgroup: inertia + EWA rule of the PREVIOUS step
+    __shared__ double s_per[kBatch];
+    if (pper_prev != nullptr && !mbk_stopped(state + p * 16, step - 1, P.n))
+      mbk_inertia_block(P, state + p * 16, step - 1, pper_prev + (size_t)p * kBatch, s_per);
+    return;
+  }
   if (mbk_stopped(state + p * 16, step, P.n)) return;
   const int bs = (int)min((long long)1000, P.n);
   const int b = blockIdx.x * 4 + (threadIdx.x >> 6);     // one wave per batch point
@@ -2132,7 +2170,7 @@ int64_t rhccq_mbk_work_bytes(const rhccq_mbk_problem* probs, int32_t n_prob) {
   size_t ksum = 0;
   for (int i = 0; i < n_prob; ++i) ksum += (size_t)probs[i].k;
   bytes += align256((size_t)n_prob * (kGridCells + 1) * 4) + align256((size_t)n_prob * kGridCells * 4) + align256(ksum * 4);
-  bytes += 2 * align256((size_t)n_prob * kBatch * 4) + align256((size_t)n_prob * kBatch * 8);
+  bytes += 2 * align256((size_t)n_prob * kBatch * 4) + 2 * align256((size_t)n_prob * kBatch * 8);
   return (int64_t)bytes;
 }
 
@@ -2146,7 +2184,7 @@ struct WorkView {
   uint32_t* cursor;       // [n_prob][cells] (spare)
   uint32_t* order;        // [sum k] centre indices grouped by cell (problem-relative)
   uint32_t* bkeys[2];     // [n_prob][1024] colours of the batch rows of even / odd steps (written by the draws)
-  double* pper;           // [n_prob][1024] the rows' inertia terms (fold kernel -> role 1 of the update)
+  double* pper[2];        // [n_prob][1024] the rows' inertia terms of even / odd steps (fold kernel -> mbk_inertia_block)
   long long max_k;
 };
 
@@ -2189,7 +2227,8 @@ static int layout_work(rhccq_ctx* ctx, const rhccq_mbk_problem* probs, int n_pro
   }
   v->bkeys[0] = (uint32_t*)base; base += align256((size_t)n_prob * kBatch * 4);
   v->bkeys[1] = (uint32_t*)base; base += align256((size_t)n_prob * kBatch * 4);
-  v->pper = (double*)base;
+  v->pper[0] = (double*)base; base += align256((size_t)n_prob * kBatch * 8);
+  v->pper[1] = (double*)base;
   v->max_k = 0;
   for (int i = 0; i < n_prob; ++i) v->max_k = probs[i].k > v->max_k ? probs[i].k : v->max_k;
   if (int e = put(ctx, v->probs, hp, sizeof(MbkP) * n_prob)) return e;
@@ -2355,15 +2394,17 @@ int rhccq_mbk_steps(rhccq_ctx* ctx, const uint32_t* keys, const rhccq_mbk_proble
   for (int s = 0; s < n_steps; ++s) {
     const long long step = step0 + s;
     const uint32_t* bk = v.bkeys[step & 1];
+    // the previous step's inertia terms (none for the first step of this call: the last step of a call has a kernel of its own)
+    const double* pprev = s > 0 ? (const double*)v.pper[(step - 1) & 1] : (const double*)nullptr;
     if (use_grid) {
       hipLaunchKernelGGL(grid_build_kernel, dim3(n_prob), dim3(1024), 0, ctx->stream, v.probs, centres, v.cell_start, v.order,
                          (const double*)state, step);
-      hipLaunchKernelGGL(mbk_batch_estep_grid_kernel, dim3(250, n_prob), dim3(256), 0, ctx->stream, keys, v.probs, centres, state, step, bk,
-                         v.cell_start, v.order, v.pdist, v.pidx, v.part_off);
+      hipLaunchKernelGGL(mbk_batch_estep_grid_kernel, dim3(250 + 1, n_prob), dim3(256), 0, ctx->stream, keys, v.probs, centres, state, step, bk,
+                         pprev, v.cell_start, v.order, v.pdist, v.pidx, v.part_off);
     } else {
 #define RHCCQ_ESTEP_LAUNCH(SS)                                                                                                             \
-  hipLaunchKernelGGL(mbk_batch_estep_kernel<SS>, dim3(max_tiles * kPtChunks * SS, n_prob), dim3(256), 0, ctx->stream, keys, v.probs, centres, \
-                     state, step, bk, v.pdist, v.pidx, v.part_off)
+  hipLaunchKernelGGL(mbk_batch_estep_kernel<SS>, dim3(max_tiles * kPtChunks * SS + 1, n_prob), dim3(256), 0, ctx->stream, keys, v.probs, centres, \
+                     state, step, bk, v.pdist, v.pidx, v.part_off, pprev)
       switch (estep_split) {
         case 8: RHCCQ_ESTEP_LAUNCH(8); break;
         case 4: RHCCQ_ESTEP_LAUNCH(4); break;
@@ -2374,10 +2415,13 @@ int rhccq_mbk_steps(rhccq_ctx* ctx, const uint32_t* keys, const rhccq_mbk_proble
     }
     // arg-min over the centre tiles (tiled E-step) and every row's inertia term against the centres before the update
     hipLaunchKernelGGL(mbk_fold_tiles_kernel, dim3((1000 + 15) / 16, n_prob), dim3(64), 0, ctx->stream, v.probs, (const double*)state, step,
-                       (const double*)centres, bk, v.pdist, v.pidx, v.part_off, v.pper, use_grid ? 0 : 1);
-    hipLaunchKernelGGL(mbk_update_kernel, dim3(n_prob, 3), dim3(kUpdThreads), 0, ctx->stream, keys, v.probs, centres, weights, state, step,
-                       words, (long long)n_words, bk, v.bkeys[(step + 1) & 1], (const double*)v.pper, (const int32_t*)v.pidx, v.part_off);
+                       (const double*)centres, bk, v.pdist, v.pidx, v.part_off, v.pper[step & 1], use_grid ? 0 : 1);
+    hipLaunchKernelGGL(mbk_update_kernel, dim3(n_prob, 2), dim3(kUpdThreads), 0, ctx->stream, keys, v.probs, centres, weights, state, step,
+                       words, (long long)n_words, bk, v.bkeys[(step + 1) & 1], (const int32_t*)v.pidx, v.part_off);
   }
+  if (n_steps > 0)
+    hipLaunchKernelGGL(mbk_inertia_kernel, dim3(n_prob), dim3(64), 0, ctx->stream, v.probs, state, step0 + n_steps - 1,
+                       (const double*)v.pper[(step0 + n_steps - 1) & 1]);
   RHCCQ_LAUNCH_CHECK(ctx);
   return 0;
 }
