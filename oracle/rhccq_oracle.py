@@ -13,14 +13,14 @@ Parity pins (see DESIGN.md "Oracle"):
   * integer / index work (unique colours, parameters, eps-components, floor-means,
     merge, remap, dtype choice, container bytes) is bit-exact against those vectors
     (Tier A);
-  * the two k-means branches reach into scikit-learn 1.7.2 (unpinned by the
-    reference, requirements.txt:6).  Their *algorithm* is restated here with a
-    canonical, order-independent arithmetic ("KM64", below) that the HIP kernels
-    reproduce bit-for-bit.  Against scikit-learn itself the KMeans split reproduces
-    the same partition on most golden cases (Tier A when it does, Tier B = same
-    palette size / equivalent PSNR otherwise); MiniBatchKMeans is Tier B only,
-    because scikit-learn's own result depends on an unstable argsort over tied
-    counts and on a data-dependent position in the MT19937 stream.
+  * the two k-means branches reach into scikit-learn 1.7.2 (unpinned by the reference, requirements.txt:6).  KMeans
+    (oversize-cluster split): restated with the "KM64" arithmetic below; against scikit-learn itself it reproduces the
+    same partition on most golden cases (Tier A when it does, Tier B = same palette size / equivalent PSNR otherwise).
+    MiniBatchKMeans (every segment of >= 10 000 colours): restated operation for operation -- RandomState(42) consumed as
+    sklearn consumes it, k-means++ in draw order, batch-ordered centre updates, sequential inertia -- and pinned bit for
+    bit against scikit-learn's own fit with its ONE unportable step (an unstable np.argsort over tied counts) forced
+    stable (tests/golden/make_golden_mbk.py, G11); wherever that step does not trigger (k < 500) the untouched fit, i.e.
+    the reference's own result, is reproduced.
 
 Canonical k-means arithmetic "KM64" (shared with csrc/):
   * points are integer colours p in [0,255]^3;
@@ -39,7 +39,7 @@ Canonical k-means arithmetic "KM64" (shared with csrc/):
     label = first arg-min; new centre = (exact integer sum of member p)/count - m;
     convergence exactly as sklearn._kmeans_single_lloyd (labels unchanged, or
     sum_j |dc_j|^2 <= tol with tol = 1e-4 * mean(var)), max_iter = 300.
-  * MiniBatch: see minibatch_kmeans_labels().
+  * MiniBatch: see minibatch_kmeans_labels() (numpy) and oracle/mbk_oracle.c (the same in C, for sizes numpy cannot reach).
 
 Each function cites the reference lines it restates (paths relative to the reference
 root).
