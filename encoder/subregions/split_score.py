@@ -1,8 +1,4 @@
-"""Placeholder for a stage UPSTREAM/DOWNSTREAM of the MI355X hot path (SURVEY.md 8f "next" rows).  When the reference
-checkout sits behind this repository on sys.path its own module of this name is executed instead (roibasedimagecompression_amd/_shim.py);
-otherwise the names exist so that the reference's import lines resolve and raise when called."""
-from roibasedimagecompression_amd._shim import defer_to_downstream, upstream
-
-if defer_to_downstream(__name__, __file__) is None:
-    calculate_split_score = upstream("calculate_split_score")
-    normalize_result = upstream("normalize_result")
+"""Drop-in for the reference's encoder/subregions/split_score.py: same names, MI355X implementation in
+roibasedimagecompression_amd.api.split_score (parity unpinned: scikit-image semantics restated)."""
+from roibasedimagecompression_amd.api.split_score import (calculate_optimal_segments, calculate_split_score,  # noqa: F401
+                                                          normalize_result)

@@ -241,6 +241,19 @@ int64_t rhccq_ssim7_blocks(int32_t H, int32_t W);
 int rhccq_ssim7_sums(rhccq_ctx* ctx, const uint8_t* a, const uint8_t* b, int32_t H, int32_t W, double* partial,
                      int64_t n_blocks);
 
+/* ---- split score of a region (encoder/subregions/split_score.py:15-142 calculate_split_score) ------------
+ * One pass over the region image (uint8 RGB interleaved, device) and its mask (uint8, 0 / non-0, may be NULL: then
+ * gray > 0.01 as the reference does): gray + CIE-Lab per pixel (scikit-image's rgb2gray / rgb2lab, float64), Sobel magnitude
+ * of the four planes ('reflect' borders), uniform LBP(8,1) code of the gray plane (zeros outside the image).
+ * partial (device, double[n_blocks][12]) receives per workgroup tile the masked sums {count, L, L^2, a, a^2, b, b^2,
+ * sum over Lab planes of sqrt(2 sobel^2), sobel(gray), sobel(gray)^2, gray, gray^2}; hist42 (device, int32[42]) the LBP
+ * histogram (10 bins) followed by the intensity histogram (32 bins over [0, 1]).  The host turns them into the three
+ * scores (roibasedimagecompression_amd/api/split_score.py).  PARITY UNPINNED: scikit-image is absent from the build
+ * container; the algorithms are restated from their published definitions. */
+int64_t rhccq_split_stats_blocks(int32_t H, int32_t W);
+int rhccq_split_stats(rhccq_ctx* ctx, const uint8_t* rgb, int32_t H, int32_t W, const uint8_t* mask, double* partial,
+                      int64_t n_blocks, int32_t* hist42);
+
 /* ---- EXTENSION (no reference counterpart; named by BASELINE.json's north_star only): pixel-space DBSCAN ----
  * Features (x, y, L, a, b); q is a neighbour of p when dx^2 + dy^2 <= radius^2 (radius 0..4) and
  * dL^2 + da^2 + db^2 + spatial_weight^2 (dx^2 + dy^2) <= eps^2 (float32, operation order fixed in

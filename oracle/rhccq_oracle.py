@@ -60,7 +60,7 @@ __all__ = [
     "minibatch_kmeans_labels", "minibatch_kmeans_native", "kmeanspp_picks_native", "cluster_palette", "merge_components", "segment_crop",
     "level1_region", "region_quantization", "quantize_image", "optimal_index_dtype",
     "encode_frame", "pack_container", "container_bytes", "load_container", "decode_container",
-    "dct_quant_blocks",
+    "dct_quant_blocks", "split_score", "normalize_result", "sk_rgb2lab", "sk_rgb2gray", "sk_sobel", "sk_lbp_uniform_8_1",
 ]
 
 MINIBATCH_THRESHOLD = 10000  # clustering.py:205
@@ -915,6 +915,104 @@ def quality_metrics(original, reconstructed):
     for i, ch in enumerate("rgb"):
         m[f"mse_{ch}"] = np.mean((of[..., i] - rf[..., i]) ** 2)
     return m
+
+
+# --------------------------------------------------------------------------------------
+# Split score (encoder/subregions/split_score.py:15-142), SURVEY 8f-2.  PARITY UNPINNED: the reference calls
+# scikit-image (rgb2lab, rgb2gray, filters.sobel, feature.local_binary_pattern), absent from the build container and unpinned
+# in requirements.txt; these functions restate scikit-image's published algorithms.
+# --------------------------------------------------------------------------------------
+def sk_rgb2gray(rgb_u8):
+    """skimage.color.rgb2gray on a uint8 image: img_as_float (v / 255) then the Rec. 709 weights 0.2125, 0.7154, 0.0721"""
+    f = rgb_u8.astype(np.float64) / 255.0
+    return (f[..., 0] * 0.2125 + f[..., 1] * 0.7154) + f[..., 2] * 0.0721
+
+
+def sk_rgb2lab(rgb_u8):
+    """skimage.color.rgb2lab (D65, 2 degree observer): sRGB companding, CIE RGB -> XYZ matrix, white-point scaling,
+    f(t) = cbrt(t) above 0.008856 else 7.787 t + 16/116"""
+    a = rgb_u8.astype(np.float64) / 255.0
+    lin = np.where(a > 0.04045, np.power((a + 0.055) / 1.055, 2.4), a / 12.92)
+    M = np.array([[0.412453, 0.357580, 0.180423], [0.212671, 0.715160, 0.072169], [0.019334, 0.119193, 0.950227]])
+    r, g, b = lin[..., 0], lin[..., 1], lin[..., 2]
+    xyz = [(M[i, 0] * r + M[i, 1] * g) + M[i, 2] * b for i in range(3)]
+    white = (0.95047, 1.0, 1.08883)
+    f = []
+    for v, w in zip(xyz, white):
+        t = v / w
+        f.append(np.where(t > 0.008856, np.cbrt(t), 7.787 * t + 16.0 / 116.0))
+    return np.stack([116.0 * f[1] - 16.0, 500.0 * (f[0] - f[1]), 200.0 * (f[1] - f[2])], axis=-1)
+
+
+def sk_sobel(img):
+    """skimage.filters.sobel of a 2-D float image: sqrt((h^2 + v^2) / 2), h / v = the [1,2,1]/4 smoothed central differences,
+    borders by scipy.ndimage's 'reflect' (d c b a | a b c d | d c b a)"""
+    p = np.pad(img, 1, mode="symmetric")
+    sm_r = (p[:-2, :] + 2.0 * p[1:-1, :] + p[2:, :]) / 4.0          # smoothed along rows, for the column difference
+    sm_c = (p[:, :-2] + 2.0 * p[:, 1:-1] + p[:, 2:]) / 4.0
+    v = sm_r[:, 2:] - sm_r[:, :-2]
+    h = sm_c[2:, :] - sm_c[:-2, :]
+    return np.sqrt((h * h + v * v) / 2.0)
+
+
+def sk_lbp_uniform_8_1(gray):
+    """skimage.feature.local_binary_pattern(gray, 8, 1, method='uniform'): 8 points on the unit circle (coordinates rounded
+    to 5 decimals), bilinear interpolation with zeros outside the image, bit = (value - centre >= 0); at most two 0/1
+    transitions around the circle -> number of ones, else 9"""
+    H, W = gray.shape
+    pad = np.zeros((H + 4, W + 4))
+    pad[2:-2, 2:-2] = gray
+    bits = []
+    for pnt in range(8):
+        rp = np.round(-np.sin(2 * np.pi * pnt / 8), 5)
+        cp = np.round(np.cos(2 * np.pi * pnt / 8), 5)
+        r0, c0 = int(np.floor(rp)), int(np.floor(cp))
+        r1, c1 = int(np.ceil(rp)), int(np.ceil(cp))
+        dr, dc = rp - r0, cp - c0
+
+        def px(dy, dx):
+            return pad[2 + dy:2 + dy + H, 2 + dx:2 + dx + W]
+        top = (1 - dc) * px(r0, c0) + dc * px(r0, c1)
+        bottom = (1 - dc) * px(r1, c0) + dc * px(r1, c1)
+        val = (1 - dr) * top + dr * bottom
+        bits.append((val - gray >= 0).astype(np.int32))
+    bits = np.stack(bits)
+    changes = sum(np.abs(bits[i] - bits[(i + 1) % 8]) for i in range(8))
+    return np.where(changes <= 2, bits.sum(0), 9)
+
+
+def split_score(region_image, mask=None):
+    """calculate_split_score (split_score.py:15-142): (overall, colour, texture) in [0, 1]"""
+    gray = sk_rgb2gray(region_image)
+    if mask is None:
+        mask = gray > 0.01
+    mask = np.asarray(mask, bool)
+    if mask.sum() < 100:
+        return 0.0, 0.0, 0.0
+    lab = sk_rgb2lab(region_image)
+    stds = [np.std(lab[mask, c]) for c in range(3)]
+    color_variance = (stds[0] / 100 + stds[1] / 128 + stds[2] / 128) / 3
+    gm = 0
+    for c in range(3):
+        s = sk_sobel(lab[:, :, c])
+        gm = gm + np.sqrt(s ** 2 + s ** 2)                   # split_score.py:47-50 takes the same filter for "x" and "y"
+    gradient_score = np.mean(gm[mask]) / 3
+    color_score = float(np.clip(0.7 * color_variance + 0.3 * gradient_score, 0, 1))
+    lbp = sk_lbp_uniform_8_1(gray)[mask]
+    hist, _ = np.histogram(lbp, bins=10, range=(0, 10), density=True)
+    lbp_score = np.clip(-np.sum(hist * np.log2(hist + 1e-8)) / 3.0, 0, 1)
+    grad_score = np.clip(np.var(sk_sobel(gray)[mask]) * 50, 0, 1)
+    mg = gray[mask]
+    hist, _ = np.histogram(mg, bins=32, range=(0, 1), density=True)
+    entropy_score = np.clip(-np.sum(hist * np.log2(hist + 1e-8)) / 5.0, 0, 1)
+    std_score = np.clip(np.std(mg) * 2, 0, 1)
+    texture_score = float(np.clip((lbp_score + grad_score + entropy_score + std_score) / 4, 0, 1))
+    return 0.4 * color_score + 0.6 * texture_score, color_score, texture_score
+
+
+def normalize_result(score, window_size):
+    """split_score.py:143-144"""
+    return window_size / (1 + math.exp(-12 * (score - 0.5)))
 
 
 # --------------------------------------------------------------------------------------

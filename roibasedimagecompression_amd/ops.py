@@ -661,6 +661,18 @@ class Rhccq:
         self._check(self.lib.rhccq_ssim7_sums(self.ctx, self._p(a), self._p(b), H, W, self._p(part), nb), "ssim7")
         return part.cpu().numpy().sum(axis=0) / float((H - 6) * (W - 6))
 
+    # -- split score (split_score.py:15-142) ----------------------------------------------------------
+    def split_stats(self, rgb, mask=None):
+        """rgb uint8[H,W,3] device, mask uint8[H,W] device or None -> (sums float64[12], lbp_hist int64[10], gray_hist int64[32])"""
+        assert rgb.dtype == torch.uint8 and rgb.is_contiguous() and rgb.shape[-1] == 3
+        H, W = int(rgb.shape[0]), int(rgb.shape[1])
+        nb = int(self.lib.rhccq_split_stats_blocks(H, W))
+        part = self.empty((nb, 12), torch.float64)
+        hist = self.empty((42,), torch.int32)
+        self._check(self.lib.rhccq_split_stats(self.ctx, self._p(rgb), H, W, self._p(mask), self._p(part), nb, self._p(hist)), "split_stats")
+        h = hist.cpu().numpy().astype(np.int64)
+        return part.cpu().numpy().sum(axis=0), h[:10], h[10:]
+
     # -- K6 / decode ------------------------------------------------------------------------------
     def remap(self, idx, lut):
         out = torch.empty_like(idx)

@@ -207,3 +207,43 @@ def test_config0_lenna512_reference_chain():
     assert len(p) == len(gp) == meta["levels"]["fin"]["colours"]
     assert np.array_equal(p[i], gp[gi])                      # the decoded frame is the reference's
     assert np.array_equal(np.unique(p, axis=0), np.unique(gp, axis=0))
+
+
+def test_split_score_vs_oracle():
+    """encoder/subregions/split_score.py:15-142 on the device vs the numpy restatement (scikit-image's rgb2lab / rgb2gray /
+    sobel / uniform LBP(8,1) from their published definitions -- PARITY UNPINNED, scikit-image is not in the build container).
+    The two integer histograms must be identical (the gray plane is the same arithmetic on both sides); the float64
+    statistics agree to rounding (device pow / cbrt vs numpy's: tolerance 1e-9 on the scores)."""
+    from oracle import rhccq_oracle as O
+    from encoder.subregions.split_score import calculate_split_score, normalize_result, calculate_optimal_segments
+    from roibasedimagecompression_amd import synth
+    rng = np.random.default_rng(8)
+    cases = []
+    for H, W, kind, seed in ((96, 128, "photo", 3), (57, 91, "poster", 5), (200, 130, "photo", 9), (33, 40, "photo", 11)):
+        img = synth.photo(H, W, seed, sigma=4.0) if kind == "photo" else synth.poster(H, W, seed)
+        m = np.zeros((H, W), bool)
+        m[H // 8:H - H // 6, W // 7:W - W // 5] = True
+        m &= rng.random((H, W)) > 0.1                      # ragged mask
+        cases += [(img, None), (img, m)]
+    dark = synth.photo(64, 64, 2).copy()
+    dark[:20] = 0                                          # mask=None excludes near-black pixels (gray <= 0.01)
+    cases.append((dark, None))
+    cases.append((np.full((40, 40, 3), 90, np.uint8), None))
+    for img, m in cases:
+        got = calculate_split_score(img, m)
+        want = O.split_score(img, m)
+        assert np.allclose(got, want, rtol=0, atol=1e-9), (got, want)
+    tiny = np.zeros((30, 30), bool)
+    tiny[:5, :5] = True
+    assert calculate_split_score(cases[0][0][:30, :30], tiny) == (0.0, 0.0, 0.0)           # < 100 masked pixels
+    assert normalize_result(0.5, 82) == O.normalize_result(0.5, 82) == 41.0
+    assert calculate_optimal_segments(0.5, 4000) == 50
+    # the integer histograms, exactly
+    import torch
+    from roibasedimagecompression_amd.ops import default_context
+    rh = default_context()
+    img, m = cases[1]
+    sums, lbp, gh = rh.split_stats(torch.from_numpy(img).to(rh.device), torch.from_numpy(m.view(np.uint8)).to(rh.device))
+    assert np.array_equal(lbp, np.bincount(O.sk_lbp_uniform_8_1(O.sk_rgb2gray(img))[m], minlength=10))
+    assert np.array_equal(gh, np.histogram(O.sk_rgb2gray(img)[m], bins=32, range=(0, 1))[0])
+    assert sums[0] == m.sum()

@@ -348,3 +348,29 @@ def test_g12_lenna512_chain_tiers():
     p = np.asarray(ref["final"]["palette"]).reshape(-1, 3)
     i = np.asarray(ref["final"]["indices"]).reshape(-1)
     assert np.array_equal(p[i], g["fin_pal"][g["fin_idx"].astype(np.int64).reshape(-1)])
+
+
+def test_split_score_restatement_properties():
+    """split_score.py:15-142 restated from scikit-image's published definitions (PARITY UNPINNED: scikit-image is absent here).
+    Checks that do not need it: the Sobel restatement equals scipy.ndimage's convolution with skimage's kernels and 'reflect'
+    borders; Lab of white / black / red are the known values; LBP of a flat image is all-ones (code 8) in the interior;
+    a flat region scores ~0, a busy one higher; fewer than 100 masked pixels -> zeros."""
+    from scipy import ndimage as ndi
+    sys.path.insert(0, os.path.join(os.path.dirname(__file__), ".."))
+    from roibasedimagecompression_amd import synth
+    img = synth.photo(72, 88, 3, sigma=4.0)
+    g = O.sk_rgb2gray(img)
+    K = np.array([[1, 2, 1], [0, 0, 0], [-1, -2, -1]]) / 4.0
+    h, v = ndi.convolve(g, K, mode="reflect"), ndi.convolve(g, K.T, mode="reflect")
+    assert np.abs(np.sqrt((h * h + v * v) / 2) - O.sk_sobel(g)).max() < 1e-14
+    lab = O.sk_rgb2lab(np.array([[[255, 255, 255], [0, 0, 0], [255, 0, 0]]], np.uint8))[0]
+    assert np.allclose(lab[0], [100.0, -0.00245, 0.00465], atol=1e-4) and np.allclose(lab[1], 0.0)
+    assert np.allclose(lab[2], [53.2406, 80.0923, 67.2028], atol=1e-3)
+    flat = np.full((20, 20, 3), 120, np.uint8)
+    assert (O.sk_lbp_uniform_8_1(O.sk_rgb2gray(flat))[1:-1, 1:-1] == 8).all()
+    s_flat, s_busy = O.split_score(np.full((64, 64, 3), 77, np.uint8)), O.split_score(img)
+    assert s_flat[0] < 0.05 and s_busy[0] > 0.3 and all(0.0 <= x <= 1.0 for x in s_flat + s_busy)
+    m = np.zeros((72, 88), bool)
+    m[:9, :9] = True
+    assert O.split_score(img, m) == (0.0, 0.0, 0.0)
+    assert O.normalize_result(0.5, 82) == 41.0
