@@ -1,10 +1,37 @@
-"""Placeholder for a stage UPSTREAM/DOWNSTREAM of the MI355X hot path (SURVEY.md 8f "next" rows).  When the reference
-checkout sits behind this repository on sys.path its own module of this name is executed instead (roibasedimagecompression_amd/_shim.py);
-otherwise the names exist so that the reference's import lines resolve and raise when called."""
-from roibasedimagecompression_amd._shim import defer_to_downstream, upstream
+"""Drop-in for the reference's encoder/subregions/slic.py: enhanced_slic_with_texture and extract_slic_segment_boundaries
+come from roibasedimagecompression_amd.api.slic (parity unpinned: scikit-image's resize / masked SLIC restated); the
+matplotlib / watershed helpers of that module come from the reference's own file when its checkout sits behind this
+repository on sys.path, otherwise they are placeholders that raise."""
+import importlib.util
+import os
+import sys
 
-if defer_to_downstream(__name__, __file__) is None:
-    enhanced_slic_with_texture = upstream("enhanced_slic_with_texture")
-    extract_slic_segment_boundaries = upstream("extract_slic_segment_boundaries")
-    visualize_split_analysis = upstream("visualize_split_analysis")
-    watershed_segmentation_with_mask = upstream("watershed_segmentation_with_mask")
+from roibasedimagecompression_amd._shim import upstream
+from roibasedimagecompression_amd.api.slic import enhanced_slic_with_texture, extract_slic_segment_boundaries  # noqa: F401
+
+_HELPERS = ("visualize_split_analysis", "watershed_segmentation_with_mask")
+
+
+def _downstream_module():
+    pkg = sys.modules[__name__.rpartition(".")[0]]
+    here = os.path.dirname(os.path.abspath(__file__))
+    for d in pkg.__path__:
+        cand = os.path.join(d, "slic.py")
+        if os.path.abspath(d) != here and os.path.isfile(cand):
+            spec = importlib.util.spec_from_file_location(__name__ + "._reference", cand)
+            mod = importlib.util.module_from_spec(spec)
+            spec.loader.exec_module(mod)
+            return mod
+    return None
+
+
+def __getattr__(name):
+    if name in _HELPERS:
+        try:
+            mod = _downstream_module()
+        except ImportError:                                   # the reference's file needs scikit-image
+            mod = None
+        fn = getattr(mod, name) if mod is not None and hasattr(mod, name) else upstream(name)
+        globals()[name] = fn
+        return fn
+    raise AttributeError(name)

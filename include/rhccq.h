@@ -254,6 +254,18 @@ int64_t rhccq_split_stats_blocks(int32_t H, int32_t W);
 int rhccq_split_stats(rhccq_ctx* ctx, const uint8_t* rgb, int32_t H, int32_t W, const uint8_t* mask, double* partial,
                       int64_t n_blocks, int32_t* hist42);
 
+/* ---- masked SLIC (encoder/subregions/slic.py:41-104 -> skimage.segmentation.slic(mask=...); SURVEY 8f-2, parity unpinned)
+ * rhccq_slic_assign: one assignment sweep of _slic_cython on a 2-D image: img (device, double[H][W][3], the Gaussian-smoothed
+ * Lab image times 1 / compactness), mask (device u8), seg (device, double[K][5] = y, x, c0, c1, c2), step = the seed spacing;
+ * labels (device int32[H][W]) = 1 + index of the nearest centroid whose window [c - 2 step, c + 2 step] holds the pixel
+ * (first on ties), 0 outside the mask / in no window.  ignore_color != 0: spatial term only (the seed-relaxation sweeps).
+ * rhccq_slic_connectivity_host: _enforce_label_connectivity_cython, a serial raster scan with breadth-first floods, as a
+ * native HOST routine (both pointers are host memory; no context, no GPU). */
+int rhccq_slic_assign(rhccq_ctx* ctx, const double* img, const uint8_t* mask, const double* seg, int32_t H, int32_t W, int32_t K,
+                      double step, int32_t ignore_color, int32_t* labels);
+int rhccq_slic_connectivity_host(const int32_t* labels_host, int32_t H, int32_t W, int32_t min_size, int32_t max_size,
+                                 int32_t* out_host);
+
 /* ---- EXTENSION (no reference counterpart; named by BASELINE.json's north_star only): pixel-space DBSCAN ----
  * Features (x, y, L, a, b); q is a neighbour of p when dx^2 + dy^2 <= radius^2 (radius 0..4) and
  * dL^2 + da^2 + db^2 + spatial_weight^2 (dx^2 + dy^2) <= eps^2 (float32, operation order fixed in

@@ -60,7 +60,8 @@ __all__ = [
     "minibatch_kmeans_labels", "minibatch_kmeans_native", "kmeanspp_picks_native", "cluster_palette", "merge_components", "segment_crop",
     "level1_region", "region_quantization", "quantize_image", "optimal_index_dtype",
     "encode_frame", "pack_container", "container_bytes", "load_container", "decode_container",
-    "dct_quant_blocks", "split_score", "normalize_result", "sk_rgb2lab", "sk_rgb2gray", "sk_sobel", "sk_lbp_uniform_8_1",
+    "dct_quant_blocks", "split_score", "normalize_result", "enhanced_slic", "slic_masked", "slic_sweeps", "slic_enforce_connectivity",
+    "slic_mask_centroids", "sk_resize", "sk_rgb2lab", "sk_rgb2gray", "sk_sobel", "sk_lbp_uniform_8_1",
 ]
 
 MINIBATCH_THRESHOLD = 10000  # clustering.py:205
@@ -1013,6 +1014,171 @@ def split_score(region_image, mask=None):
 def normalize_result(score, window_size):
     """split_score.py:143-144"""
     return window_size / (1 + math.exp(-12 * (score - 0.5)))
+
+
+# --------------------------------------------------------------------------------------
+# Masked SLIC (encoder/subregions/slic.py:41-104 enhanced_slic_with_texture), SURVEY 8f-2.  PARITY UNPINNED: the reference
+# calls scikit-image's transform.resize and segmentation.slic(mask=...) (absent from the build container); both are restated
+# here from their published algorithms on top of scipy.ndimage / scipy.cluster, which scikit-image itself calls.
+# --------------------------------------------------------------------------------------
+def sk_resize(image, out_hw, order, anti_aliasing):
+    """skimage.transform.resize(image, out_hw, order=order, mode='reflect', preserve_range=True, anti_aliasing=...): optional
+    Gaussian (sigma = (factor - 1) / 2 per axis) then scipy.ndimage.zoom(grid_mode=True) with numpy-pad 'reflect' =
+    ndimage 'mirror' borders, clipped to the input range"""
+    from scipy import ndimage as ndi
+    img = np.asarray(image)
+    out_shape = tuple(out_hw) + img.shape[2:]
+    work = img.astype(np.float64) if order > 0 else (img.astype(np.uint8) if img.dtype == bool else img)
+    factors = np.divide(img.shape, out_shape)
+    if anti_aliasing:
+        sigma = np.maximum(0, (factors - 1) / 2)
+        work = ndi.gaussian_filter(work, sigma, cval=0, mode="mirror")
+    out = ndi.zoom(work, [1 / f for f in factors], order=order, mode="mirror", cval=0, grid_mode=True)
+    if order > 0:
+        out = np.clip(out, img.min(), img.max())
+    return out
+
+
+def slic_mask_centroids(mask3, n_centroids):
+    """skimage.segmentation.slic._get_mask_centroids: RandomState(123) picks n_centroids seed pixels and 100 x as many sample
+    pixels inside the mask, five k-means sweeps (scipy.cluster.vq.kmeans2) move the seeds; steps = mean distance, per axis,
+    to the nearest other centroid"""
+    from scipy.cluster.vq import kmeans2
+    from scipy.spatial.distance import pdist, squareform
+    coord = np.array(np.nonzero(mask3), dtype=float).T
+    rng = np.random.RandomState(123)
+    idx_full = np.arange(len(coord), dtype=int)
+    idx = np.sort(rng.choice(idx_full, min(n_centroids, len(coord)), replace=False))
+    n_dense = int((10 ** 2) * n_centroids)
+    idx_dense = np.sort(rng.choice(idx_full, min(n_dense, len(coord)), replace=False))
+    import warnings
+    with warnings.catch_warnings():
+        warnings.simplefilter("ignore")
+        centroids, _ = kmeans2(coord[idx_dense], coord[idx], iter=5)
+    if len(centroids) > 1:
+        dist = squareform(pdist(centroids))
+        np.fill_diagonal(dist, np.inf)
+        closest = dist.argmin(-1)
+        steps = abs(centroids - centroids[closest, :]).mean(0)
+    else:
+        steps = np.array([1.0, float(mask3.shape[1]), float(mask3.shape[2])])
+    return centroids, steps
+
+
+def slic_sweeps(image, mask, segments, step, max_num_iter, ignore_color):
+    """skimage.segmentation._slic._slic_cython for a 2-D image (depth 1, unit spacing, start_label 1), in place on `segments`
+    [k][y, x, c0, c1, c2]: every masked pixel takes the centroid with the smallest spatial / step^2 (+ colour) distance among
+    those whose window [c - 2 step, c + 2 step] holds it -- the first one on ties --, then the centroids become the means of
+    their pixels, sums in raster order.  Returns int64 labels (0 outside the mask or unassigned)."""
+    H, W = mask.shape
+    K = len(segments)
+    yy, xx = np.mgrid[0:H, 0:W]
+    inv = 1.0 / (step * step)
+    labels = np.zeros((H, W), np.int64)
+    for it in range(max_num_iter):
+        dist = np.full((H, W), np.finfo(np.float64).max)
+        labels = np.zeros((H, W), np.int64)
+        change = False
+        for k in range(K):
+            cy, cx = segments[k, 0], segments[k, 1]
+            y0, y1 = int(max(cy - 2 * step, 0)), int(min(cy + 2 * step + 1, H))
+            x0, x1 = int(max(cx - 2 * step, 0)), int(min(cx + 2 * step + 1, W))
+            if y1 <= y0 or x1 <= x0:
+                continue
+            sl = (slice(y0, y1), slice(x0, x1))
+            d = ((cy - yy[sl]) ** 2 + (cx - xx[sl]) ** 2) * inv        # dz = 0
+            if not ignore_color:
+                dc = np.zeros_like(d)
+                for c in range(3):
+                    dc = dc + (image[sl][..., c] - segments[k, 2 + c]) ** 2
+                d = d + dc
+            upd = mask[sl] & (dist[sl] > d)
+            if upd.any():
+                change = True
+                dist[sl][upd] = d[upd]
+                labels[sl][upd] = k + 1
+        if not change:
+            break
+        lab = labels[mask] - 1
+        ok = lab >= 0
+        lab = lab[ok]
+        cnt = np.bincount(lab, minlength=K).astype(np.float64)
+        feats = [yy[mask][ok].astype(np.float64), xx[mask][ok].astype(np.float64)] + [image[..., c][mask][ok] for c in range(3)]
+        with np.errstate(invalid="ignore", divide="ignore"):
+            for f, v in enumerate(feats):
+                segments[:, f] = np.bincount(lab, weights=v, minlength=K) / cnt        # bincount adds in raster order
+    return labels
+
+
+def slic_enforce_connectivity(labels, min_size, max_size):
+    """skimage.segmentation._slic._enforce_label_connectivity_cython (2-D, start_label 1, 0 = outside the mask): raster scan,
+    breadth-first flood of every unvisited component of equal label (4-neighbours, capped at max_size pixels); components
+    smaller than min_size take the label of the last already-relabelled neighbour met, the others the next new label"""
+    H, W = labels.shape
+    out = np.zeros((H, W), np.int64)
+    new = 1
+    ddy, ddx = (0, 0, 1, -1), (1, -1, 0, 0)
+    for y in range(H):
+        for x in range(W):
+            if out[y, x] >= 1 or labels[y, x] == 0:
+                continue
+            adjacent = 0
+            label = labels[y, x]
+            out[y, x] = new
+            comp = [(y, x)]
+            visited = 0
+            while visited < len(comp) < max_size:
+                cy, cx = comp[visited]
+                for i in range(4):
+                    ny, nx = cy + ddy[i], cx + ddx[i]
+                    if 0 <= ny < H and 0 <= nx < W:
+                        if labels[ny, nx] == label and out[ny, nx] == 0:
+                            out[ny, nx] = new
+                            comp.append((ny, nx))
+                            if len(comp) >= max_size:
+                                break
+                        elif out[ny, nx] >= 1 and out[ny, nx] != new:
+                            adjacent = out[ny, nx]
+                visited += 1
+            if len(comp) < min_size:
+                for cy, cx in comp:
+                    out[cy, cx] = adjacent
+            else:
+                new += 1
+    return out
+
+
+def slic_masked(image_u8, mask, n_segments, compactness=10.0, sigma=1.0, max_num_iter=10):
+    """skimage.segmentation.slic(image, n_segments, compactness, sigma=1, channel_axis=2, mask=mask) for a uint8 RGB image"""
+    from scipy import ndimage as ndi
+    mask = np.asarray(mask, bool)
+    lab = sk_rgb2lab(image_u8)
+    centroids, steps = slic_mask_centroids(mask[None], n_segments)
+    lab = ndi.gaussian_filter(lab[None], [sigma, sigma, sigma, 0], mode="reflect")[0]
+    K = len(centroids)
+    segments = np.concatenate([centroids[:, 1:], np.zeros((K, 3))], axis=-1)      # (y, x, c0, c1, c2); z = 0 throughout
+    step = float(max(steps))
+    img = np.ascontiguousarray(lab * (1.0 / compactness))
+    slic_sweeps(img, mask, segments, step, max_num_iter, ignore_color=True)
+    labels = slic_sweeps(img, mask, segments, step, max_num_iter, ignore_color=False)
+    seg_size = mask.sum() / K
+    return slic_enforce_connectivity(labels, int(0.5 * seg_size), int(3 * seg_size))
+
+
+def enhanced_slic(image_u8, mask, n_segments=100, compactness=10):
+    """enhanced_slic_with_texture (slic.py:41-104) -> int32 label map (0 = outside the region mask)"""
+    scale = round(500 / max(image_u8.shape), 1)
+    if scale > 1:
+        scale = 1
+    h, w = image_u8.shape[:2]
+    nh, nw = int(h * scale), int(w * scale)
+    small = sk_resize(image_u8, (nh, nw), 1, True).astype(np.uint8)
+    small_mask = sk_resize(np.asarray(mask, bool), (nh, nw), 0, False).astype(bool)
+    n_seg = math.ceil(n_segments * scale * scale)
+    masked = small.copy()
+    masked[~small_mask] = 0
+    seg_small = slic_masked(masked, small_mask, n_seg, compactness)
+    return sk_resize(seg_small, (h, w), 0, False).astype(np.int32)
 
 
 # --------------------------------------------------------------------------------------

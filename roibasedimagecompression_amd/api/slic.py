@@ -1,0 +1,155 @@
+"""Mirror of encoder/subregions/slic.py: enhanced_slic_with_texture, extract_slic_segment_boundaries.
+
+The reference downsamples the region to <= 500 pixels, runs scikit-image's masked SLIC there (compactness 10, sigma 1,
+10 sweeps, connectivity enforced) and upsamples the labels.  scikit-image is absent from the build container and
+unpinned by the reference: PARITY UNPINNED -- `transform.resize` and `segmentation.slic(mask=...)` are restated from
+their published algorithms on top of scipy.ndimage / scipy.cluster (which scikit-image itself calls).  What runs where:
+the 20 assignment sweeps on the MI355X (csrc/slic.hip `slic_assign_kernel`, float64, the operations of `_slic_cython` in
+their order); the connectivity enforcement as a native host routine of the same library (a serial raster scan);
+resize / Gaussian / centroid seeding (RandomState(123) + kmeans2) / centroid means on the host, as in scikit-image."""
+import ctypes as C
+import math
+import warnings
+
+import numpy as np
+import torch
+
+from ..ops import default_context
+
+
+def _rgb2lab(rgb_u8):
+    """skimage.color.rgb2lab (D65, 2 degree observer) of a uint8 image, float64"""
+    a = rgb_u8.astype(np.float64) / 255.0
+    lin = np.where(a > 0.04045, np.power((a + 0.055) / 1.055, 2.4), a / 12.92)
+    M = ((0.412453, 0.357580, 0.180423), (0.212671, 0.715160, 0.072169), (0.019334, 0.119193, 0.950227))
+    r, g, b = lin[..., 0], lin[..., 1], lin[..., 2]
+    f = []
+    for row, w in zip(M, (0.95047, 1.0, 1.08883)):
+        t = ((row[0] * r + row[1] * g) + row[2] * b) / w
+        f.append(np.where(t > 0.008856, np.cbrt(t), 7.787 * t + 16.0 / 116.0))
+    return np.stack([116.0 * f[1] - 16.0, 500.0 * (f[0] - f[1]), 200.0 * (f[1] - f[2])], axis=-1)
+
+
+def _resize(image, out_hw, order, anti_aliasing):
+    """skimage.transform.resize(image, out_hw, order, mode='reflect', preserve_range=True, anti_aliasing=...)"""
+    from scipy import ndimage as ndi
+    img = np.asarray(image)
+    out_shape = tuple(out_hw) + img.shape[2:]
+    work = img.astype(np.float64) if order > 0 else (img.astype(np.uint8) if img.dtype == bool else img)
+    factors = np.divide(img.shape, out_shape)
+    if anti_aliasing:
+        work = ndi.gaussian_filter(work, np.maximum(0, (factors - 1) / 2), cval=0, mode="mirror")
+    out = ndi.zoom(work, [1 / f for f in factors], order=order, mode="mirror", cval=0, grid_mode=True)
+    if order > 0:
+        out = np.clip(out, img.min(), img.max())
+    return out
+
+
+def _mask_centroids(mask, n_centroids):
+    """skimage _get_mask_centroids for a 2-D mask: (centroids [K][y, x], steps)"""
+    from scipy.cluster.vq import kmeans2
+    from scipy.spatial.distance import pdist, squareform
+    coord = np.array(np.nonzero(mask[None]), dtype=float).T           # (z, y, x), z = 0
+    rng = np.random.RandomState(123)
+    idx_full = np.arange(len(coord), dtype=int)
+    idx = np.sort(rng.choice(idx_full, min(n_centroids, len(coord)), replace=False))
+    idx_dense = np.sort(rng.choice(idx_full, min(int(100 * n_centroids), len(coord)), replace=False))
+    with warnings.catch_warnings():
+        warnings.simplefilter("ignore")
+        centroids, _ = kmeans2(coord[idx_dense], coord[idx], iter=5)
+    if len(centroids) > 1:
+        dist = squareform(pdist(centroids))
+        np.fill_diagonal(dist, np.inf)
+        steps = abs(centroids - centroids[dist.argmin(-1), :]).mean(0)
+    else:
+        steps = np.array([1.0, float(mask.shape[0]), float(mask.shape[1])])
+    return centroids[:, 1:], steps
+
+
+def _sweeps(rh, d_img, d_mask, mask, feats, segments, step, max_num_iter, ignore_color):
+    """_slic_cython: assignment on the device, centroid means on the host (np.bincount adds in raster order, like the loop)"""
+    H, W = mask.shape
+    K = len(segments)
+    d_lab = rh.empty((H, W), torch.int32)
+    labels = np.zeros((H, W), np.int32)
+    for _ in range(max_num_iter):
+        d_seg = rh.dev(np.ascontiguousarray(segments))
+        rh._check(rh.lib.rhccq_slic_assign(rh.ctx, rh._p(d_img), rh._p(d_mask), rh._p(d_seg), H, W, K, float(step), int(ignore_color), rh._p(d_lab)),
+                  "slic_assign")
+        labels = d_lab.cpu().numpy()
+        lab = labels[mask].astype(np.int64) - 1
+        ok = lab >= 0
+        if not ok.any():
+            break
+        lab = lab[ok]
+        cnt = np.bincount(lab, minlength=K).astype(np.float64)
+        with np.errstate(invalid="ignore", divide="ignore"):
+            for f, v in enumerate(feats):
+                segments[:, f] = np.bincount(lab, weights=v[ok], minlength=K) / cnt
+    return labels
+
+
+def slic_masked(image_u8, mask, n_segments, compactness=10.0, sigma=1.0, max_num_iter=10):
+    """skimage.segmentation.slic(image, n_segments, compactness, sigma=1, channel_axis=2, mask=mask) -> int32 labels"""
+    from scipy import ndimage as ndi
+    rh = default_context()
+    mask = np.ascontiguousarray(np.asarray(mask, bool))
+    H, W = mask.shape
+    lab = _rgb2lab(image_u8)
+    centroids, steps = _mask_centroids(mask, n_segments)
+    lab = ndi.gaussian_filter(lab[None], [sigma, sigma, sigma, 0], mode="reflect")[0]
+    K = len(centroids)
+    segments = np.concatenate([centroids, np.zeros((K, 3))], axis=-1)
+    step = float(max(steps))
+    img = np.ascontiguousarray(lab * (1.0 / compactness))
+    yy, xx = np.mgrid[0:H, 0:W]
+    feats = [yy[mask].astype(np.float64), xx[mask].astype(np.float64)] + [img[..., c][mask] for c in range(3)]
+    d_img, d_mask = rh.dev(img), rh.dev(mask.view(np.uint8))
+    _sweeps(rh, d_img, d_mask, mask, feats, segments, step, max_num_iter, True)
+    labels = _sweeps(rh, d_img, d_mask, mask, feats, segments, step, max_num_iter, False)
+    seg_size = mask.sum() / K
+    out = np.empty((H, W), np.int32)
+    labels = np.ascontiguousarray(labels, dtype=np.int32)
+    rc = rh._raw.rhccq_slic_connectivity_host(C.c_void_p(labels.ctypes.data), H, W, int(0.5 * seg_size), int(3 * seg_size), C.c_void_p(out.ctypes.data))
+    if rc:
+        raise ValueError("slic connectivity: bad arguments")
+    return out
+
+
+def enhanced_slic_with_texture(image, mask, n_segments=100, compactness=10):
+    """slic.py:41-104: (segments int32[h, w] with 0 outside the mask, texture_map) -- the texture map is all zeros in the
+    reference too (its Gabor block is commented out)."""
+    image = np.ascontiguousarray(image)
+    scale = round(500 / max(image.shape), 1)
+    if scale > 1:
+        scale = 1
+    h, w = image.shape[:2]
+    nh, nw = int(h * scale), int(w * scale)
+    small = _resize(image, (nh, nw), 1, True).astype(np.uint8)
+    small_mask = _resize(np.asarray(mask, bool), (nh, nw), 0, False).astype(bool)
+    n_seg = math.ceil(n_segments * scale * scale)
+    masked = small.copy()
+    masked[~small_mask] = 0
+    seg_small = slic_masked(masked, small_mask, n_seg, compactness)
+    segments = _resize(seg_small, (h, w), 0, False).astype(np.int32)
+    return segments, np.zeros((h, w), np.float64)
+
+
+def extract_slic_segment_boundaries(roi_segments, bbox_mask):
+    """slic.py:143-214: one dict per segment id present inside the mask.  Downstream (subregions.py:315-317) only reads
+    `segment_id`; `boundary_coords` here are the segment's border pixels (a pixel with a 4-neighbour outside the segment) in
+    raster order instead of scikit-image's marching-squares contour, and -- deliberate deviation -- a segment whose mask
+    fills the whole region box is kept (the reference drops it because find_contours finds no level crossing)."""
+    out = []
+    ids = np.unique(roi_segments)
+    for seg_id in ids[ids != 0]:
+        m = (roi_segments == seg_id) & bbox_mask
+        area = int(m.sum())
+        if area == 0:
+            continue
+        p = np.pad(m, 1)
+        inner = p[:-2, 1:-1] & p[2:, 1:-1] & p[1:-1, :-2] & p[1:-1, 2:]
+        ys, xs = np.nonzero(m & ~inner)
+        out.append({"segment_id": int(seg_id), "boundary_coords": list(zip(ys.astype(float), xs.astype(float))), "area": area,
+                    "num_points": int(len(ys)), "note": "normal_segment" if min(m.shape) >= 2 else "tiny_segment"})
+    return out

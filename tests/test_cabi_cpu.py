@@ -89,7 +89,11 @@ def test_reference_import_surface():
     assert get_all_unique_colors(np.zeros((0, 0, 3), np.uint8), (0, 0)) is None
     assert merge_region_components_simple([], (0, 0, 4, 4)) == []
     with pytest.raises(NotImplementedError):
-        extract_regions(None, None, None)
+        extract_regions(None, None, None)                   # ROI detection: still a placeholder
+    assert calculate_split_score.__module__ == "roibasedimagecompression_amd.api.split_score"
+    assert enhanced_slic_with_texture.__module__ == "roibasedimagecompression_amd.api.slic"
+    with pytest.raises(NotImplementedError):
+        visualize_split_analysis(None, 0, 0, 0, 1)          # matplotlib helper: the reference's own, when it is on sys.path
 
 
 def test_reference_tree_behind_the_repository_is_not_shadowed(tmp_path):

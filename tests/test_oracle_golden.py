@@ -1,6 +1,7 @@
 """Oracle (numpy restatement) vs golden vectors produced by the reference itself
 (tests/golden/make_golden.py).  CPU only."""
 import json
+import math
 import os
 import sys
 
@@ -374,3 +375,34 @@ def test_split_score_restatement_properties():
     m[:9, :9] = True
     assert O.split_score(img, m) == (0.0, 0.0, 0.0)
     assert O.normalize_result(0.5, 82) == 41.0
+
+
+def test_masked_slic_restatement_properties():
+    """slic.py:41-104 restated (PARITY UNPINNED).  Checks that need no scikit-image: labels are 0 exactly outside the mask and
+    >= 1 inside, every label is 4-connected after the connectivity pass, the number of segments is close to the request, the
+    native connectivity routine of the product library equals the restatement, a 700-pixel image goes through the 0.7
+    downscale and comes back at full size."""
+    import ctypes as C
+    from scipy import ndimage as ndi
+    sys.path.insert(0, os.path.join(os.path.dirname(__file__), ".."))
+    from roibasedimagecompression_amd import _lib, synth
+    yy, xx = np.mgrid[0:100, 0:140]
+    mask = ((yy - 50) / 45.0) ** 2 + ((xx - 70) / 60.0) ** 2 <= 1
+    img = synth.photo(100, 140, 3, sigma=3.0)
+    seg = O.enhanced_slic(img, mask, n_segments=10)
+    # (a masked pixel can stay 0: outside every centroid window, or a first tiny component with no relabelled neighbour yet)
+    assert seg.shape == mask.shape and (seg[~mask] == 0).all() and (seg[mask] >= 1).mean() > 0.99
+    ids = np.unique(seg[seg > 0])
+    assert 5 <= len(ids) <= 12 and list(ids) == list(range(1, len(ids) + 1))
+    for v in ids:
+        assert ndi.label(seg == v)[1] == 1, v                         # 4-connected
+    big = O.enhanced_slic(synth.photo(150, 700, 5), np.ones((150, 700), bool), n_segments=16)
+    assert big.shape == (150, 700) and (big >= 1).mean() > 0.99 and len(np.unique(big[big > 0])) <= math.ceil(16 * 0.49)
+    lib = _lib.load()
+    rng = np.random.default_rng(0)
+    lab = np.kron(rng.integers(0, 5, (12, 15)), np.ones((4, 4), int))[:45, :57]
+    lab[rng.random(lab.shape) < 0.1] = 3
+    lab = np.ascontiguousarray(lab.astype(np.int32))
+    out = np.empty_like(lab)
+    assert lib.rhccq_slic_connectivity_host(C.c_void_p(lab.ctypes.data), 45, 57, 6, 60, C.c_void_p(out.ctypes.data)) == 0
+    assert np.array_equal(out, O.slic_enforce_connectivity(lab.astype(np.int64), 6, 60))
