@@ -20,6 +20,7 @@ constexpr int kKmThreads = 1024;
 constexpr int kKmWaves = kKmThreads / 64;
 constexpr int kKmCentLds = 1024;   // centres kept in LDS up to this k
 constexpr int kTMax = 16;
+constexpr int kKmPts = 4;          // points a thread holds in registers per pass of the Lloyd E-step
 
 struct KmShared {
   unsigned long long red64[kKmWaves * kTMax];
@@ -205,21 +206,41 @@ __global__ __launch_bounds__(kKmThreads) void kmeans_kernel(const uint32_t* __re
     if (tid == 0) sh.flag = 0;
     __syncthreads();
     int changed = 0;
-    for (int i = tid; i < n; i += kKmThreads) {
-      const uint32_t kk = P[i];
-      const double x0 = (double)key_r(kk) - m0, x1 = (double)key_g(kk) - m1, x2 = (double)key_b(kk) - m2;
-      double bd = km64_dist(x0, x1, x2, C);
-      int bj = 0;
-      for (int j = 1; j < k; ++j) {
-        const double d = km64_dist(x0, x1, x2, C + 4 * j);
-        if (d < bd) { bd = d; bj = j; }
+    // E-step, centres in the OUTER loop: a thread keeps up to kKmPts of its points in registers and reads every centre
+    // once for all of them (the first version walked the centres once per point: with all threads reading the same
+    // centre the LDS broadcast reads, two b128 per pair, were the whole iteration).  Same per-pair arithmetic, centres
+    // still visited in ascending order: the first arg-min is unchanged.
+    for (int i0 = tid; i0 < n; i0 += kKmThreads * kKmPts) {
+      double x0[kKmPts], x1[kKmPts], x2[kKmPts], bd[kKmPts];
+      int bj[kKmPts];
+      uint32_t kk[kKmPts];
+#pragma unroll
+      for (int q = 0; q < kKmPts; ++q) {
+        const int i = i0 + q * kKmThreads;
+        kk[q] = i < n ? P[i] : 0u;
+        x0[q] = (double)key_r(kk[q]) - m0; x1[q] = (double)key_g(kk[q]) - m1; x2[q] = (double)key_b(kk[q]) - m2;
+        bd[q] = INFINITY;
+        bj[q] = 0;
       }
-      if ((uint32_t)bj != aux[i]) changed = 1;
-      aux[i] = (uint32_t)bj;
-      atomicAdd(&S[bj * 4 + 0], key_r(kk));
-      atomicAdd(&S[bj * 4 + 1], key_g(kk));
-      atomicAdd(&S[bj * 4 + 2], key_b(kk));
-      atomicAdd(&S[bj * 4 + 3], 1u);
+      for (int j = 0; j < k; ++j) {
+        const double c0 = C[4 * j], c1 = C[4 * j + 1], c2 = C[4 * j + 2], cs = C[4 * j + 3];
+#pragma unroll
+        for (int q = 0; q < kKmPts; ++q) {
+          const double d = cs + (-2.0 * km64_dot(x0[q], x1[q], x2[q], c0, c1, c2));
+          if (d < bd[q]) { bd[q] = d; bj[q] = j; }
+        }
+      }
+#pragma unroll
+      for (int q = 0; q < kKmPts; ++q) {
+        const int i = i0 + q * kKmThreads;
+        if (i >= n) continue;
+        if ((uint32_t)bj[q] != aux[i]) changed = 1;
+        aux[i] = (uint32_t)bj[q];
+        atomicAdd(&S[bj[q] * 4 + 0], key_r(kk[q]));
+        atomicAdd(&S[bj[q] * 4 + 1], key_g(kk[q]));
+        atomicAdd(&S[bj[q] * 4 + 2], key_b(kk[q]));
+        atomicAdd(&S[bj[q] * 4 + 3], 1u);
+      }
     }
     if (changed) sh.flag = 1;                           // benign race: all writers store 1
     __syncthreads();
