@@ -1,4 +1,4 @@
-"""decoder/uncompression/comparison.py of the reference: `calculate_quality_metrics` runs on the MI355X
+"""decoder/uncompression/comparison.py of the reference: `calculate_quality_metrics` and `calculate_adaptive_quality_metrics` run on the MI355X
 (roibasedimagecompression_amd/api/comparison.py).  The OpenCV / matplotlib helpers of that module come from the reference's own
 file when its checkout sits behind this repository on sys.path (they are looked up there lazily); otherwise they are
 placeholders that raise."""
@@ -7,10 +7,9 @@ import os
 import sys
 
 from roibasedimagecompression_amd._shim import upstream
-from roibasedimagecompression_amd.api.comparison import calculate_quality_metrics  # noqa: F401
+from roibasedimagecompression_amd.api.comparison import calculate_adaptive_quality_metrics, calculate_quality_metrics  # noqa: F401
 
-_HELPERS = ("create_difference_visualization", "print_quality_report", "plot_comparison", "calculate_adaptive_quality_metrics",
-            "print_adaptive_metrics")
+_HELPERS = ("create_difference_visualization", "print_quality_report", "plot_comparison", "print_adaptive_metrics")
 
 
 def _downstream_module():

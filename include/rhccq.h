@@ -233,6 +233,11 @@ int rhccq_decode(rhccq_ctx* ctx, const void* idx, int32_t idx_elem_bytes, int64_
  * sums5 (device): [0..2] sum of squared differences per channel, [3] sum of |differences|, [4] max |difference|
  * -> MSE / RMSE / MAE / max error / per-channel MSE / PSNR (comparison.py:40,63-78) on the host. */
 int rhccq_error_sums(rhccq_ctx* ctx, const uint8_t* a, const uint8_t* b, int64_t n_pixels, uint64_t* sums5);
+/* calculate_adaptive_quality_metrics (comparison.py:345-536): tab768 (device, uint64[256][3]) row e = {pixels, sum of squared
+ * differences over the 3 channels, sum of |differences|} of the pixels whose largest channel error is e; maxerr (device,
+ * uint8[n_pixels], may be NULL) = that largest channel error per pixel (the outlier mask for the masked SSIM).  Percentiles,
+ * outlier thresholds, the metrics of every pixel subset the reference forms and its error histogram follow on the host. */
+int rhccq_error_tables(rhccq_ctx* ctx, const uint8_t* a, const uint8_t* b, int64_t n_pixels, uint64_t* tab768, uint8_t* maxerr);
 /* structural_similarity(a, b, data_range=255, channel_axis=2, win_size=7) (comparison.py:47-49; algorithm of
  * scikit-image, unpinned by the reference): partial (device) receives, per workgroup tile, the sum over its
  * window centres of S for each channel; mean SSIM = sum(partial) / ((H-6)*(W-6)) averaged over the channels.

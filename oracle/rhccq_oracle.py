@@ -60,7 +60,7 @@ __all__ = [
     "minibatch_kmeans_labels", "minibatch_kmeans_native", "kmeanspp_picks_native", "cluster_palette", "merge_components", "segment_crop",
     "level1_region", "region_quantization", "quantize_image", "optimal_index_dtype",
     "encode_frame", "pack_container", "container_bytes", "load_container", "decode_container",
-    "dct_quant_blocks", "split_score", "normalize_result", "enhanced_slic", "slic_masked", "slic_sweeps", "slic_enforce_connectivity",
+    "dct_quant_blocks", "adaptive_quality_metrics", "split_score", "normalize_result", "enhanced_slic", "slic_masked", "slic_sweeps", "slic_enforce_connectivity",
     "slic_mask_centroids", "sk_resize", "sk_rgb2lab", "sk_rgb2gray", "sk_sobel", "sk_lbp_uniform_8_1",
 ]
 
@@ -915,6 +915,64 @@ def quality_metrics(original, reconstructed):
     m["max_error"] = np.max(np.abs(of - rf))
     for i, ch in enumerate("rgb"):
         m[f"mse_{ch}"] = np.mean((of[..., i] - rf[..., i]) ** 2)
+    return m
+
+
+def adaptive_quality_metrics(original, reconstructed):
+    """calculate_adaptive_quality_metrics (comparison.py:345-536), numpy statement for statement; SSIM through
+    structural_similarity_win7 (scikit-image restated: parity unpinned)"""
+    of, rf = original.astype(np.float32), reconstructed.astype(np.float32)
+    abs_error = np.abs(of - rf)
+    e = np.max(abs_error, axis=2).flatten()
+    st = {"min": float(np.min(e)), "max": float(np.max(e)), "mean": float(np.mean(e)), "median": float(np.median(e)), "std": float(np.std(e)),
+          "q75": float(np.percentile(e, 75)), "q90": float(np.percentile(e, 90)), "q95": float(np.percentile(e, 95)), "q99": float(np.percentile(e, 99))}
+    q1, q3 = np.percentile(e, 25), np.percentile(e, 75)
+    thr = {"iqr": q3 + 2.5 * (q3 - q1), "percentile": np.percentile(e, 99)}
+    with np.errstate(divide="ignore", invalid="ignore"):
+        z = (e - st["mean"]) / st["std"]
+    thr["adaptive"] = st["median"] + 3 * st["std"] if st["mean"] > st["median"] * 1.5 else st["mean"] + 2.5 * st["std"]
+    masks = {"iqr": e > thr["iqr"], "zscore": np.abs(z) > 3.0, "percentile": e > thr["percentile"], "adaptive": e > thr["adaptive"]}
+    thr["zscore"] = st["mean"] + 3.0 * st["std"]
+    best_method, best = None, None
+    for name, mk in masks.items():
+        if 0.1 <= np.sum(mk) / len(e) * 100 <= 10.0:
+            best_method, best = name, mk
+            break
+    if best_method is None:
+        best_method, best = "adaptive", masks["adaptive"]
+    oc = int(np.sum(best))
+    m = {"error_distribution": st,
+         "outlier_detection": {"method": best_method, "threshold": float(thr[best_method]), "outlier_count": oc,
+                               "outlier_percentage": float(oc / len(e) * 100), "inlier_count": int(len(e) - oc),
+                               "inlier_percentage": float(100 - oc / len(e) * 100)}}
+    mse_all = np.mean((of - rf) ** 2)
+    m["all_pixels"] = {"psnr": 10 * np.log10(255 * 255 / mse_all) if mse_all > 0 else float("inf"), "mse": float(mse_all),
+                       "rmse": float(np.sqrt(mse_all)), "mae": float(np.mean(abs_error)), "max_error": st["max"], "pixel_count": int(len(e))}
+    if 0 < oc < len(e):
+        oi, ri = of.reshape(-1, 3)[~best], rf.reshape(-1, 3)[~best]
+        mi = np.mean((oi - ri) ** 2)
+        m["without_outliers"] = {"psnr": 10 * np.log10(255 * 255 / mi) if mi > 0 else float("inf"), "mse": float(mi), "rmse": float(np.sqrt(mi)),
+                                 "mae": float(np.mean(np.abs(oi - ri))), "max_error": float(np.max(np.abs(oi - ri))), "pixel_count": int(len(oi))}
+    for p in (99, 95, 90, 75):
+        t = np.percentile(e, p)
+        mk = e <= t
+        op, rp = of.reshape(-1, 3)[mk], rf.reshape(-1, 3)[mk]
+        if len(op) > 0:
+            mp = np.mean((op - rp) ** 2)
+            m[f"percentile_{p}"] = {"psnr": 10 * np.log10(255 * 255 / mp) if mp > 0 else float("inf"), "mse": float(mp),
+                                    "max_error_included": float(t), "pixel_count": int(len(op)), "percentage": float(p)}
+    try:
+        m["ssim"] = {"full": float(np.mean([structural_similarity_win7(original[..., c], reconstructed[..., c]) for c in range(3)]))}
+        if 0 < oc < len(e):
+            h, w = original.shape[:2]
+            om, rm = original.copy(), reconstructed.copy()
+            om[best.reshape(h, w)] = 128
+            rm[best.reshape(h, w)] = 128
+            m["ssim"]["without_outliers"] = float(np.mean([structural_similarity_win7(om[..., c], rm[..., c]) for c in range(3)]))
+    except ValueError:
+        m["ssim"] = {"full": 0}
+    hist, edges = np.histogram(e, bins=50)
+    m["error_histogram"] = {"bins": hist.tolist(), "bin_edges": edges.tolist()}
     return m
 
 

@@ -56,6 +56,7 @@ PROTOTYPES = {
     "rhccq_px_neighbours": (c_int32, [c_void_p, c_void_p, c_int32, c_int32, c_int32, C.c_float, C.c_float, c_int32, c_void_p, c_void_p, c_void_p]),
     "rhccq_px_expand": (c_int32, [c_void_p, c_void_p, c_int32, c_int32, c_int32, C.c_float, C.c_float, c_void_p, c_void_p, c_void_p]),
     "rhccq_error_sums": (c_int32, [c_void_p, c_void_p, c_void_p, c_int64, c_void_p]),
+    "rhccq_error_tables": (c_int32, [c_void_p, c_void_p, c_void_p, c_int64, c_void_p, c_void_p]),
     "rhccq_ssim7_blocks": (c_int64, [c_int32, c_int32]),
     "rhccq_ssim7_sums": (c_int32, [c_void_p, c_void_p, c_void_p, c_int32, c_int32, c_void_p, c_int64]),
     "rhccq_split_stats_blocks": (c_int64, [c_int32, c_int32]),

@@ -117,6 +117,36 @@ __global__ __launch_bounds__(256) void ssim7_kernel(const uint8_t* __restrict__ 
   }
 }
 
+// ---- error tables by worst-channel error: tab[e] = {pixels, sum of squared differences (3 channels), sum of |differences|}
+// over the pixels whose largest channel error is e (0..255).  Everything calculate_adaptive_quality_metrics
+// (comparison.py:345-536) derives -- percentiles, outlier thresholds, metrics of the pixels below a threshold, the error
+// histogram -- is a function of these 256 rows.
+__global__ __launch_bounds__(256) void error_tables_kernel(const uint8_t* __restrict__ a, const uint8_t* __restrict__ b, long long n_px,
+                                                           unsigned long long* __restrict__ tab /* [256][3] */, uint8_t* __restrict__ maxerr) {
+  __shared__ unsigned long long s_tab[256][3];
+  for (int i = threadIdx.x; i < 256 * 3; i += 256) (&s_tab[0][0])[i] = 0ull;
+  __syncthreads();
+  for (long long p = (long long)blockIdx.x * 256 + threadIdx.x; p < n_px; p += (long long)gridDim.x * 256) {
+    unsigned e = 0, sq = 0, ab = 0;
+#pragma unroll
+    for (int c = 0; c < 3; ++c) {
+      const unsigned d = (unsigned)abs((int)a[p * 3 + c] - (int)b[p * 3 + c]);
+      e = max(e, d);
+      sq += d * d;
+      ab += d;
+    }
+    atomicAdd(&s_tab[e][0], 1ull);
+    atomicAdd(&s_tab[e][1], (unsigned long long)sq);
+    atomicAdd(&s_tab[e][2], (unsigned long long)ab);
+    if (maxerr) maxerr[p] = (uint8_t)e;
+  }
+  __syncthreads();
+  for (int i = threadIdx.x; i < 256 * 3; i += 256) {
+    const unsigned long long v = (&s_tab[0][0])[i];
+    if (v) atomicAdd(&tab[i], v);
+  }
+}
+
 }  // namespace rhccq
 
 using namespace rhccq;
@@ -132,6 +162,18 @@ int rhccq_error_sums(rhccq_ctx* ctx, const uint8_t* a, const uint8_t* b, int64_t
   blocks = blocks < 1 ? 1 : (blocks > 2048 ? 2048 : blocks);
   hipLaunchKernelGGL(error_sums_kernel, dim3((unsigned)blocks), dim3(256), 0, ctx->stream, a, b, (long long)n_pixels,
                      (unsigned long long*)sums5);
+  RHCCQ_LAUNCH_CHECK(ctx);
+  return 0;
+}
+
+int rhccq_error_tables(rhccq_ctx* ctx, const uint8_t* a, const uint8_t* b, int64_t n_pixels, uint64_t* tab768, uint8_t* maxerr) {
+  if (!ctx || !a || !b || !tab768 || n_pixels < 0) return rhccq_fail(ctx, RHCCQ_E_ARG, "error_tables: bad argument");
+  RHCCQ_HIP(ctx, hipMemsetAsync(tab768, 0, 768 * sizeof(uint64_t), ctx->stream));
+  if (n_pixels == 0) return 0;
+  long long blocks = (n_pixels + 255) / 256;
+  blocks = blocks > 2048 ? 2048 : blocks;
+  hipLaunchKernelGGL(error_tables_kernel, dim3((unsigned)blocks), dim3(256), 0, ctx->stream, a, b, (long long)n_pixels,
+                     (unsigned long long*)tab768, maxerr);
   RHCCQ_LAUNCH_CHECK(ctx);
   return 0;
 }

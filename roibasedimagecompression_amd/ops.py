@@ -651,6 +651,14 @@ class Rhccq:
         self._check(self.lib.rhccq_error_sums(self.ctx, self._p(a), self._p(b), a.numel() // 3, self._p(sums)), "error_sums")
         return sums.cpu().numpy()
 
+    def error_tables(self, a, b, want_maxerr=False):
+        """a, b: uint8[H,W,3] device -> int64[256][3] rows by worst-channel error (+ uint8[H,W] per-pixel worst error)"""
+        assert a.dtype == torch.uint8 and b.dtype == torch.uint8 and a.shape == b.shape and a.is_contiguous() and b.is_contiguous()
+        tab = self.empty((256, 3), torch.int64)
+        me = self.empty(tuple(a.shape[:2]), torch.uint8) if want_maxerr else None
+        self._check(self.lib.rhccq_error_tables(self.ctx, self._p(a), self._p(b), a.numel() // 3, self._p(tab), self._p(me)), "error_tables")
+        return tab.cpu().numpy(), me
+
     def ssim7(self, a, b):
         """mean SSIM per channel (float64[3]) with skimage's defaults for win_size=7, data_range=255."""
         H, W = int(a.shape[0]), int(a.shape[1])

@@ -288,3 +288,36 @@ def test_masked_slic_vs_oracle_and_default_subregion_path():
     p, i = arrs(got[0][0])
     assert np.array_equal(p, np.asarray(ref[0]["palette"]).reshape(-1, 3))
     assert np.array_equal(i, np.asarray(ref[0]["indices"]).reshape(-1))
+
+
+def test_adaptive_quality_metrics_vs_oracle():
+    """comparison.py:345-536 calculate_adaptive_quality_metrics on the device (one pass -> a 256-row table by worst-channel
+    error; the reference's formulas on the host) vs the numpy statement-for-statement restatement: same keys and nesting,
+    integers (counts, histogram bins, chosen method) identical, floats to 2e-6 relative (the reference averages float32
+    arrays pairwise, the device sums exact integers), SSIM to 1e-9 (parity unpinned: scikit-image restated)."""
+    from decoder.uncompression.comparison import calculate_adaptive_quality_metrics
+    from oracle import rhccq_oracle as O
+    from roibasedimagecompression_amd import synth
+    rng = np.random.default_rng(12)
+
+    def check(got, want, path=""):
+        assert set(got) == set(want), (path, set(got) ^ set(want))
+        for k, w in want.items():
+            g = got[k]
+            if isinstance(w, dict):
+                check(g, w, path + k + ".")
+            elif isinstance(w, list):
+                assert len(g) == len(w) and np.allclose(g, w, rtol=2e-6, atol=1e-9), path + k
+                if k == "bins":
+                    assert list(g) == list(w)
+            elif isinstance(w, str) or isinstance(w, (int, np.integer)) and not isinstance(w, bool):
+                assert g == w, (path + k, g, w)
+            else:
+                assert abs(float(g) - float(w)) <= 2e-6 * abs(float(w)) + 1e-9 or (np.isinf(g) and np.isinf(w)), (path + k, g, w)
+    for H, W, spread, spikes in ((97, 131, 9, 40), (64, 80, 3, 0), (120, 90, 2, 600)):
+        a = synth.photo(H, W, 5)
+        b = np.clip(a.astype(np.int32) + rng.integers(-spread, spread + 1, a.shape), 0, 255).astype(np.uint8)
+        for _ in range(spikes):                                       # a few gross outliers
+            y, x = int(rng.integers(0, H)), int(rng.integers(0, W))
+            b[y, x] = 255 - b[y, x]
+        check(calculate_adaptive_quality_metrics(a, b), O.adaptive_quality_metrics(a, b))
