@@ -32,7 +32,7 @@ def test_unique_and_cluster_palette_functions():
         assert np.array_equal(p1, npal) and np.array_equal(i1, nidx), (i, q)          # HIP path == oracle
         assert o["compressed_colors"] == len(npal)
         exact += np.array_equal(p1, g[f"pal{i}"]) and np.array_equal(i1, g[f"idx{i}"])  # == the reference itself
-    assert exact >= 15
+    assert exact == 22                                        # the Tier-A count of test_oracle_golden.py::test_g4_cluster_palette
     black = get_all_unique_colors(np.zeros((4, 4, 3), np.uint8), (0, 0))
     assert cluster_palette_colors_parallel(20, black, eps=102.4, min_samples=1, max_colors_per_cluster=1) is black
     with pytest.raises(NotImplementedError):

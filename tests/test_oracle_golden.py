@@ -76,7 +76,9 @@ def test_g9_kmeans_split_partition_rate():
         assert max(len(s) for s in subs) <= max(mc, 2)
         assert len(subs) == lab.max() + 1 or not ok
     print(report)
-    assert same / total >= 0.6, report
+    # 11 of 13 identical; the two others (k = n = 146 on an already quantised palette, k = 27 on a 6-level lattice) are
+    # cases where k-means++ candidate potentials tie exactly (diagnosed against sklearn's own picks)
+    assert same == 11 and total == 13, report
 
 
 def psnr(a, b):
@@ -109,12 +111,17 @@ def test_g4_cluster_palette():
             tiers["A'"] += 1
             continue
         tiers["B"] += 1
-        assert abs(len(npal) - len(gp)) <= 0.1 * len(gp) + 2, (i, q, len(npal), len(gp))
+        assert q >= 40, (i, q)                                  # every level-1 preset of the pipeline (q = 10, 20) is Tier A
+        assert abs(len(npal) - len(gp)) <= 0.05 * len(gp), (i, q, len(npal), len(gp))      # observed: <= 4.8 %
         ref = psnr(gp[gi], img.reshape(-1, 3))
         mine = psnr(npal[nidx], img.reshape(-1, 3))
-        assert abs(ref - mine) < 0.25, (i, q, ref, mine)
+        assert abs(ref - mine) < 0.23, (i, q, ref, mine)       # observed: <= 0.22 dB
     print("g4 tiers", tiers, "low-q exact", low_q_exact)
-    assert low_q_exact >= 11
+    # the observed split (sklearn 1.7.2 / numpy 2.2.6 fixtures): the B cases are KMeans splits whose k-means++ potentials tie
+    # exactly in integer arithmetic (q >= 40: many small clusters on lattice-like palettes); sklearn's pick there follows the
+    # summation order of OpenBLAS' dgemv for the host CPU
+    assert tiers == {"A": 22, "A'": 5, "B": 9}, tiers
+    assert low_q_exact == 12
     assert tiers["A"] + tiers["A'"] >= 18
 
 
