@@ -1190,7 +1190,7 @@ __global__ __launch_bounds__(kJThreads) void mbk_init2_kernel(const uint32_t* __
 constexpr int kBatch = 1024;        // padded batch (sklearn batch_size = 1000)
 constexpr int kTileC = 512;         // centres per workgroup in the batch E-step (16 KB of LDS; 1024 halves the partials the
                                     // update folds but leaves too few workgroups: measured 9 % slower per step)
-constexpr int kPtChunks = kBatch / 256;   // a workgroup takes 256 of the batch points
+constexpr int kPtChunks = kBatch / 512;   // a workgroup takes 512 / split of the batch rows (two per thread)
 
 // Per-problem state, double[16] (see rhccq_mbk_steps).  Every kernel of step `step` (the launch index, equal for all
 // problems of a call sequence) reads only slots that no kernel of the same launch writes:
@@ -1272,7 +1272,9 @@ __global__ __launch_bounds__(256) void mbk_batch_estep_kernel(const uint32_t* __
                                                               long long step, const uint32_t* __restrict__ bkeys, double* __restrict__ pdist,
                                                               int32_t* __restrict__ pidx, const long long* __restrict__ part_off,
                                                               const double* __restrict__ pper_prev) {
-  constexpr int kPts = 256 / kSplit, kSlice = kTileC / kSplit;
+  // a thread owns TWO batch rows and one slice of the tile's centres: every centre it reads from LDS (a broadcast read, and
+  // with four workgroups per CU the LDS pipe was the limit) serves two distance evaluations
+  constexpr int kT = 256 / kSplit, kPts = 2 * kT, kSlice = kTileC / kSplit;
   const int p = blockIdx.y;
   const MbkP P = probs[p];                               // independent table reads, issued together
   const long long po = part_off[p];
@@ -1287,8 +1289,8 @@ __global__ __launch_bounds__(256) void mbk_batch_estep_kernel(const uint32_t* __
   const int tile = blockIdx.x / (kPtChunks * kSplit), chunk = blockIdx.x % (kPtChunks * kSplit);
   if (tile >= n_tiles) return;
   const int bs = (int)min((long long)1000, P.n);
-  __shared__ double s_bd[kSplit > 1 ? 256 : 1];
-  __shared__ int s_bj[kSplit > 1 ? 256 : 1];
+  __shared__ double s_bd[kSplit > 1 ? 512 : 1];
+  __shared__ int s_bj[kSplit > 1 ? 512 : 1];
   const int j0 = tile * kTileC, nj = (int)min((long long)kTileC, P.k - j0);
   for (int i = threadIdx.x; i < nj * 4; i += blockDim.x) {
     const double v = centres[(P.koff + j0) * 4 + i];
@@ -1297,34 +1299,39 @@ __global__ __launch_bounds__(256) void mbk_batch_estep_kernel(const uint32_t* __
   __syncthreads();
   double* pd = pdist + po + (size_t)tile * kBatch;
   int32_t* pi = pidx + po + (size_t)tile * kBatch;
-  const int pt = threadIdx.x % kPts, slice = threadIdx.x / kPts;
-  const int b = chunk * kPts + pt;
-  double bd = INFINITY;
-  int bj = 0x7fffffff;
-  if (b < bs) {
-    const uint32_t kk = bkeys[(size_t)p * kBatch + b];       // colour of batch row b (drawn by the previous update)
-    const double x0 = (double)key_r(kk), x1 = (double)key_g(kk), x2 = (double)key_b(kk);
+  const int pt = threadIdx.x % kT, slice = threadIdx.x / kT;
+  const int b0 = chunk * kPts + pt, b1 = b0 + kT;
+  double bd0 = INFINITY, bd1 = INFINITY;
+  int bj0 = 0x7fffffff, bj1 = 0x7fffffff;
+  if (b0 < bs) {
+    const uint32_t k0 = bkeys[(size_t)p * kBatch + b0], k1 = bkeys[(size_t)p * kBatch + min(b1, bs - 1)];   // rows drawn by the previous update
+    const double x0 = (double)key_r(k0), x1 = (double)key_g(k0), x2 = (double)key_b(k0);
+    const double y0 = (double)key_r(k1), y1 = (double)key_g(k1), y2 = (double)key_b(k1);
     const int ja = slice * kSlice, jb = min(ja + kSlice, nj);
     for (int j = ja; j < jb; ++j) {
-      const double d = sc[j * 4 + 3] + km64_dot(x0, x1, x2, sc[j * 4], sc[j * 4 + 1], sc[j * 4 + 2]);
-      if (d < bd) { bd = d; bj = j; }
+      const double c0 = sc[j * 4], c1 = sc[j * 4 + 1], c2 = sc[j * 4 + 2], cs = sc[j * 4 + 3];
+      const double d0 = cs + km64_dot(x0, x1, x2, c0, c1, c2);
+      const double d1 = cs + km64_dot(y0, y1, y2, c0, c1, c2);
+      if (d0 < bd0) { bd0 = d0; bj0 = j; }
+      if (d1 < bd1) { bd1 = d1; bj1 = j; }
     }
   }
   if (kSplit > 1) {
-    s_bd[threadIdx.x] = bd;
-    s_bj[threadIdx.x] = bj;
+    s_bd[threadIdx.x] = bd0; s_bd[256 + threadIdx.x] = bd1;
+    s_bj[threadIdx.x] = bj0; s_bj[256 + threadIdx.x] = bj1;
     __syncthreads();
     if (slice == 0) {
 #pragma unroll
       for (int q = 1; q < kSplit; ++q) {                  // ascending slices = ascending centre index: strict '<'
-        const double od = s_bd[q * kPts + pt];
-        if (od < bd) { bd = od; bj = s_bj[q * kPts + pt]; }
+        const double o0 = s_bd[q * kT + pt], o1 = s_bd[256 + q * kT + pt];
+        if (o0 < bd0) { bd0 = o0; bj0 = s_bj[q * kT + pt]; }
+        if (o1 < bd1) { bd1 = o1; bj1 = s_bj[256 + q * kT + pt]; }
       }
     }
   }
-  if (slice == 0 && b < bs) {
-    pd[b] = bd;
-    pi[b] = j0 + bj;
+  if (slice == 0) {
+    if (b0 < bs) { pd[b0] = bd0; pi[b0] = j0 + bj0; }
+    if (b1 < bs) { pd[b1] = bd1; pi[b1] = j0 + bj1; }
   }
 }
 

@@ -588,7 +588,7 @@ class Rhccq:
             # brute force has fewer and shorter launches per step
             mode = {"tiles": 1, "grid": 2}.get(estep) or (2 if int(k_arr[running].sum()) >= 200000 else 1)
             # few workgroups left (a straggler problem): several threads share a batch point in the tiled E-step
-            wgs = int(((k_arr[running] + 511) // 512).sum()) * 4
+            wgs = int(((k_arr[running] + 511) // 512).sum()) * 2
             split = estep_split or next((sp for sp in (1, 2, 4, 8) if wgs * sp >= 1536), 8)
             words = self._mt_words_dev(cur_max + (ns + 2) * WORDS_PER_STEP)     # a step consumes at most WORDS_PER_STEP
             self._check(self.lib.rhccq_mbk_steps(self.ctx, self._p(keys), probs, n_prob, step, ns, self._p(words), words.numel(),
