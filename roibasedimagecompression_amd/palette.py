@@ -50,15 +50,26 @@ def _cluster_resident(rh, jobs, idxs, results):
         parts.append(nbk)
         ks.append(math.ceil(int(nbk.numel()) * (jb["quality"] / 100) / 10))
     labs = rh.minibatch_kmeans(parts, ks, return_device=True)
-    for s, nbk, k, lab in zip(idxs, parts, ks, labs):
+    # member sums of every cluster of every job in ONE launch and ONE copy (labels offset by the jobs' cluster offsets)
+    koff = np.concatenate([[0], np.cumsum(ks)]).astype(np.int64)
+    if len(parts) > 1:
+        all_keys = torch.cat(parts)
+        all_lab = torch.cat([lab + int(koff[i]) for i, lab in enumerate(labs)])
+    else:
+        all_keys, all_lab = parts[0], labs[0]
+    _, sums_dev = rh.cluster_means(all_keys, all_lab, int(koff[-1]))
+    sums_all = sums_dev.cpu().numpy().astype(np.int64)
+    luts, plans = [], []
+    for i, (s, nbk, k, lab) in enumerate(zip(idxs, parts, ks, labs)):
         jb = jobs[s]
-        _, sums = rh.cluster_means(nbk, lab, k)
-        sums = sums.cpu().numpy().astype(np.int64)
+        sums = sums_all[koff[i]:koff[i + 1]]
         cnt = sums[:, 3]
         if (cnt > jb["mc"]).any():                         # needs k-means splitting: host path
             jb["keys"] = jb["keys_dev"].cpu().numpy().view(np.uint32)
             jb["_labels"] = lab.cpu().numpy()
             fallback.append(s)
+            luts.append(np.zeros(k, np.int32))
+            plans.append(None)
             continue
         present = cnt > 0
         nblack = 1 if jb["has_black"] else 0
@@ -67,11 +78,18 @@ def _cluster_resident(rh, jobs, idxs, results):
         c = np.maximum(cnt[present], 1)
         means = ((sums[present, 0] // c) << 16) | ((sums[present, 1] // c) << 8) | (sums[present, 2] // c)
         new_keys = np.concatenate([np.zeros(nblack, np.uint32), means.astype(np.uint32)])
-        lut = ((nblack + leaf) & 0xFFFF).astype(np.int32)   # uint16 mapping_array (clustering.py:373)
-        mapped = rh.remap(lab, rh.dev(lut))
+        luts.append(((nblack + leaf) & 0xFFFF).astype(np.int32))    # uint16 mapping_array (clustering.py:373)
+        plans.append((new_keys, nblack, int(present.sum())))
+    # label -> new palette index of every job in one gather
+    mapped_all = rh.remap(all_lab, rh.dev(np.concatenate(luts)))
+    offs = np.concatenate([[0], np.cumsum([int(p.numel()) for p in parts])]).astype(np.int64)
+    for i, s in enumerate(idxs):
+        if plans[i] is None:
+            continue
+        new_keys, nblack, n_present = plans[i]
+        mapped = mapped_all[offs[i]:offs[i + 1]]
         mapping_dev = torch.cat([torch.zeros(1, dtype=torch.int32, device=rh.device), mapped]) if nblack else mapped
-        results[s] = (new_keys, None, {"branch": "minibatch", "n_clusters": int(present.sum()), "n_large": 0,
-                                       "mapping_dev": mapping_dev})
+        results[s] = (new_keys, None, {"branch": "minibatch", "n_clusters": n_present, "n_large": 0, "mapping_dev": mapping_dev})
     return fallback
 
 
