@@ -78,7 +78,7 @@ def subregion_quantization(image_rgb, subregions, quality=10, subregion_type=Non
         return [[] for _ in subregions]
     cls = ClassSpec(torch.from_numpy(labels).to(rh.device), seg_region, bboxes, quality)
     enc = FrameEncoder(rh)
-    S = enc.prepare(torch.from_numpy(image_rgb).to(rh.device), [cls])
+    S = enc.prepare(torch.from_numpy(np.array(image_rgb, dtype=np.uint8, order="C")).to(rh.device), [cls])
     regs = enc.level1(S)[0]
     out = []
     for comp in regs:
