@@ -1,17 +1,14 @@
-"""Placeholder for a stage UPSTREAM/DOWNSTREAM of the MI355X hot path (SURVEY.md 8f "next" rows).  When the reference
-checkout sits behind this repository on sys.path its own module of this name is executed instead (roibasedimagecompression_amd/_shim.py);
-otherwise the names exist so that the reference's import lines resolve and raise when called."""
-from roibasedimagecompression_amd._shim import defer_to_downstream, upstream
+"""Drop-in for the reference's encoder/ROI/roi.py.  The region extraction -- extract_roi_nonroi, extract_regions,
+extract_connected_regions(_fast), fuse_adjacent_regions_optimized, process_regions_with_reassignment -- runs on the MI355X
+(roibasedimagecompression_amd.api.roi; connected components PARITY UNPINNED in their numbering, see there).  The heuristics
+that produce the region map (get_regions, process_and_unify_borders, ...: OpenCV filters and morphology) come from the
+reference's own file when its checkout sits behind this repository on sys.path and OpenCV is installed, otherwise they are
+placeholders that raise."""
+from roibasedimagecompression_amd._shim import downstream_getattr
+from roibasedimagecompression_amd.api.roi import (extract_connected_regions, extract_connected_regions_fast,  # noqa: F401
+                                                  extract_regions, extract_roi_nonroi, fuse_adjacent_regions_optimized,
+                                                  process_regions_with_reassignment)
 
-if defer_to_downstream(__name__, __file__) is None:
-    get_regions = upstream("get_regions")
-    extract_regions = upstream("extract_regions")
-    remove_small_noise_regions = upstream("remove_small_noise_regions")
-    detect_meaningful_borders = upstream("detect_meaningful_borders")
-    protect_border_regions = upstream("protect_border_regions")
-    fill_closed_regions = upstream("fill_closed_regions")
-    extract_roi_nonroi = upstream("extract_roi_nonroi")
-    visualize_roi_nonroi_comparison = upstream("visualize_roi_nonroi_comparison")
-    process_and_unify_borders = upstream("process_and_unify_borders")
-    directional_region_unification = upstream("directional_region_unification")
-    extract_connected_regions_fast = upstream("extract_connected_regions_fast")
+__getattr__ = downstream_getattr(__name__, __file__, (
+    "get_regions", "remove_small_noise_regions", "detect_meaningful_borders", "protect_border_regions", "fill_closed_regions",
+    "visualize_roi_nonroi_comparison", "process_and_unify_borders", "directional_region_unification", "plot_regions"))

@@ -1240,6 +1240,97 @@ def enhanced_slic(image_u8, mask, n_segments=100, compactness=10):
 
 
 # --------------------------------------------------------------------------------------
+# SURVEY 8f-1, region extraction of the ROI stage (encoder/ROI/roi.py:45-103,285-360,685-718).  extract_roi_nonroi is
+# numpy + scipy.ndimage in the reference too (pinned: same library calls).  Connected components: the PARTITION is pinned
+# by scipy.ndimage.label; OpenCV's NUMBERING is PARITY UNPINNED (cv2 absent here): restated from its published
+# algorithms -- connectedComponentsWithStats(connectivity=8) runs a 2x2-block scan (Grana's BBDT, Bolelli's Spaghetti from
+# 4.5.2; also their row-striped parallel forms), provisional labels are created in block-raster order, unions keep the
+# smaller one and flattenL renumbers in increasing provisional order => components are numbered by their first 2x2 block
+# in block-raster order; connectivity=4 scans pixel by pixel => by first pixel.
+# --------------------------------------------------------------------------------------
+def cv_connected_components_with_stats(mask, connectivity=8, numbering="opencv"):
+    """-> (num_labels, labels int32[H,W], stats int32[num_labels,5] = LEFT, TOP, WIDTH, HEIGHT, AREA); label 0 = background"""
+    from scipy import ndimage
+    m = np.asarray(mask) != 0
+    H, W = m.shape
+    st = np.ones((3, 3), bool) if connectivity == 8 else np.array([[0, 1, 0], [1, 1, 1], [0, 1, 0]], bool)
+    lab, n = ndimage.label(m, structure=st)                     # numbered by first pixel in raster order
+    lab = lab.astype(np.int32)
+    ys, xs = np.nonzero(lab)
+    l = lab[ys, xs]
+    if n and connectivity == 8 and numbering == "opencv":
+        big = np.iinfo(np.int64).max
+        top = np.full(n + 1, big)
+        np.minimum.at(top, l, ys)
+        sel = (ys >> 1) == (top[l] >> 1)                        # pixels in the component's first block row
+        bx = np.full(n + 1, big)
+        np.minimum.at(bx, l[sel], xs[sel] >> 1)
+        key = (top[1:] >> 1) * ((W + 1) >> 1) + bx[1:]
+        order = np.argsort(key, kind="stable")
+        rank = np.zeros(n + 1, np.int32)
+        rank[order + 1] = np.arange(1, n + 1, dtype=np.int32)
+        lab = rank[lab]
+        l = lab[ys, xs]
+    stats = np.zeros((n + 1, 5), np.int32)
+    by, bx_ = np.nonzero(lab == 0)
+    groups = [(0, by, bx_)] if len(by) else []
+    if n:
+        o = np.argsort(l, kind="stable")
+        cuts = np.searchsorted(l[o], np.arange(1, n + 2))
+        groups += [(k + 1, ys[o[cuts[k]:cuts[k + 1]]], xs[o[cuts[k]:cuts[k + 1]]]) for k in range(n)]
+    for k, gy, gx in groups:
+        stats[k] = (gx.min(), gy.min(), gx.max() - gx.min() + 1, gy.max() - gy.min() + 1, len(gy))
+    return n + 1, lab, stats
+
+
+def extract_connected_regions_fast(mask, original_image):
+    """roi.py:285-360: one dict per component, in label order; 'coords' in raster order (the reference's come out of an
+    unstable argsort over the labels: any order within a region)."""
+    num, labels, stats = cv_connected_components_with_stats(np.asarray(mask).astype(np.uint8), 8)
+    out = []
+    for lab in range(1, num):
+        x, y, w, h, area = (int(v) for v in stats[lab])
+        single = labels == lab
+        coords = np.column_stack(np.nonzero(single))
+        full = np.zeros_like(original_image)
+        full[single] = original_image[single]
+        out.append({"mask": single, "full_image": full, "bbox_image": original_image[y:y + h, x:x + w], "bbox_mask": single[y:y + h, x:x + w],
+                    "bbox": (y, x, y + h, x + w), "area": area, "coords": coords, "label": lab})
+    return out
+
+
+def roi_min_region_size(image_rgb):
+    """roi.py:47-49 (the SIZE of the array: H * W * 3)"""
+    return math.ceil(image_rgb.size / math.pow(10, math.ceil(math.log(image_rgb.size, 10)) - 3))
+
+
+def extract_regions(image_rgb, roi_mask, nonroi_mask):
+    """roi.py:45-103: components of both masks; ROI components below the minimum size move to the END of the non-ROI list"""
+    mn = roi_min_region_size(image_rgb)
+    roi = extract_connected_regions_fast(roi_mask, image_rgb)
+    non = extract_connected_regions_fast(nonroi_mask, image_rgb)
+    small = [r for r in roi if r["area"] < mn]
+    if small:
+        for r in small:
+            r["type"] = "nonroi"
+        non.extend(small)
+        roi = [r for r in roi if r["area"] >= mn]
+    return roi, non
+
+
+def extract_roi_nonroi(original_image, region_map, buffer_size=3):
+    """roi.py:685-718"""
+    from scipy import ndimage
+    roi_core, non_core = region_map == 1, region_map == 0
+    buffer_zone = ndimage.binary_dilation(roi_core, iterations=buffer_size) & ndimage.binary_dilation(non_core, iterations=buffer_size)
+    roi_mask, non_mask = roi_core | buffer_zone, non_core | buffer_zone
+    roi_image, non_image = original_image.copy(), original_image.copy()
+    roi_image[~roi_mask] = 0
+    non_image[~non_mask] = 0
+    return roi_image, non_image, roi_mask, non_mask
+
+
+# --------------------------------------------------------------------------------------
 # EXTENSION (no reference counterpart, SURVEY 8a-13): block DCT-II + per-region quantisation
 # --------------------------------------------------------------------------------------
 def dct_quant_blocks(plane, block, qstep_map):

@@ -46,3 +46,39 @@ def upstream(name):
                                   "repository on sys.path and its own module is used (see INTEGRATION.md)")
     fn.__name__ = name
     return fn
+
+
+def downstream_getattr(module_name, module_file, helpers):
+    """Module-level `__getattr__` of a mirror that implements PART of a reference module: the names in `helpers` come from
+    the reference's own file when it sits further along the package's __path__ (and its imports resolve), otherwise they
+    are placeholders that raise when called."""
+    state = {}
+
+    def load():
+        if "mod" in state:
+            return state["mod"]
+        state["mod"] = None
+        pkg = sys.modules.get(module_name.rpartition(".")[0])
+        here = os.path.dirname(os.path.abspath(module_file))
+        leaf = module_name.rpartition(".")[2]
+        for d in list(getattr(pkg, "__path__", [])):
+            cand = os.path.join(d, leaf + ".py")
+            if os.path.abspath(d) != here and os.path.isfile(cand):
+                spec = importlib.util.spec_from_file_location(module_name + "._reference", cand)
+                mod = importlib.util.module_from_spec(spec)
+                try:
+                    spec.loader.exec_module(mod)
+                except ImportError:                              # the reference's file needs OpenCV / scikit-image
+                    mod = None
+                state["mod"] = mod
+                break
+        return state["mod"]
+
+    def getattr_(name):
+        if name in helpers:
+            mod = load()
+            fn = getattr(mod, name) if mod is not None and hasattr(mod, name) else upstream(name)
+            sys.modules[module_name].__dict__[name] = fn
+            return fn
+        raise AttributeError(name)
+    return getattr_

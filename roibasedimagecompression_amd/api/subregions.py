@@ -56,15 +56,23 @@ def subregion_quantization(image_rgb, subregions, quality=10, subregion_type=Non
     image_rgb = np.ascontiguousarray(image_rgb, dtype=np.uint8)
     H, W = image_rgb.shape[:2]
     seg_fn = segmenter or _reference_segmenter
-    labels = np.zeros((H, W), np.int32)
-    seg_region, bboxes = [], []
+    # one label map per LAYER: regions of one call may overlap (extract_regions appends the small ROI components, buffer zone
+    # included, to the non-ROI list, roi.py:76-84); the reference treats every region on its own, so an overlapping region
+    # goes to the first layer in which its pixels are still free
+    layers = []
     nxt = 0
     for ri, region in enumerate(subregions):
         minr, minc, maxr, maxc = (int(v) for v in region["bbox"])
         mask = np.asarray(region["bbox_mask"], dtype=bool)
         seg = np.asarray(seg_fn(image_rgb[minr:maxr, minc:maxc], mask))
-        bboxes.append((minr, minc, maxr, maxc))
-        view = labels[minr:maxr, minc:maxc]
+        layer = next((l for l in layers if not l["labels"][minr:maxr, minc:maxc][mask].any()), None)
+        if layer is None:
+            layer = {"labels": np.zeros((H, W), np.int32), "seg_region": [], "bboxes": [], "regions": [], "n": 0}
+            layers.append(layer)
+        local = len(layer["bboxes"])
+        layer["bboxes"].append((minr, minc, maxr, maxc))
+        layer["regions"].append(ri)
+        view = layer["labels"][minr:maxr, minc:maxc]
         for sid in np.unique(seg):                       # ascending ids, 0 = background (slic.py:158-160)
             if sid == 0:
                 continue
@@ -72,17 +80,19 @@ def subregion_quantization(image_rgb, subregions, quality=10, subregion_type=Non
             if not m.any():
                 continue
             nxt += 1
-            view[m] = nxt
-            seg_region.append(ri)
+            layer["n"] += 1
+            view[m] = layer["n"]
+            layer["seg_region"].append(local)
     if nxt == 0:
         return [[] for _ in subregions]
-    cls = ClassSpec(torch.from_numpy(labels).to(rh.device), seg_region, bboxes, quality)
+    layers = [l for l in layers if l["n"]]
+    specs = [ClassSpec(torch.from_numpy(l["labels"]).to(rh.device), l["seg_region"], l["bboxes"], quality) for l in layers]
     enc = FrameEncoder(rh)
-    S = enc.prepare(torch.from_numpy(np.array(image_rgb, dtype=np.uint8, order="C")).to(rh.device), [cls])
-    regs = enc.level1(S)[0]
-    out = []
-    for comp in regs:
-        out.append([] if comp is None else [_comp_to_dict(enc, S, comp, quality)])
+    S = enc.prepare(torch.from_numpy(np.array(image_rgb, dtype=np.uint8, order="C")).to(rh.device), specs)
+    out = [[] for _ in subregions]
+    for l, regs in zip(layers, enc.level1(S)):
+        for ri, comp in zip(l["regions"], regs):
+            out[ri] = [] if comp is None else [_comp_to_dict(enc, S, comp, quality)]
     if debug:
         log.info("%s: %d regions, %d segments", subregion_type or "subregions", len(subregions), nxt)
     return out

@@ -681,6 +681,63 @@ class Rhccq:
         h = hist.cpu().numpy().astype(np.int64)
         return part.cpu().numpy().sum(axis=0), h[:10], h[10:]
 
+    # -- ROI stage: connected components, buffer zone ---------------------------------------------------
+    def ccl(self, mask, connectivity=8, cap=4096, numbering="opencv"):
+        """mask uint8 / bool [H,W] device -> (n, labels int32[H,W] device, stats np.int32[n + 1, 5]) with cv2's conventions:
+        label 0 = background, components numbered as cv2.connectedComponentsWithStats numbers them (csrc/ccl.hip), stats
+        columns CC_STAT_LEFT, TOP, WIDTH, HEIGHT, AREA.  numbering="raster": components numbered by their first pixel in
+        raster order (scipy.ndimage.label, skimage.measure.label)."""
+        if mask.dtype == torch.bool:
+            mask = mask.view(torch.uint8)
+        assert mask.dtype == torch.uint8 and mask.dim() == 2 and mask.is_contiguous()
+        H, W = int(mask.shape[0]), int(mask.shape[1])
+        wb = int(self.lib.rhccq_ccl_work_bytes(H, W))
+        work = self.empty((wb,), torch.uint8)
+        parent = self.empty((H * W,), torch.int32)
+        cid = self.empty((H * W,), torch.int32)
+        count = self.empty((1,), torch.int32)
+        while True:
+            stats = self.empty((cap + 1, 6), torch.int32)
+            self._check(self.lib.rhccq_ccl_roots(self.ctx, self._p(mask), H, W, int(connectivity), 0 if numbering == "opencv" else 1, self._p(work), wb, self._p(parent),
+                                                 self._p(cid), cap, self._p(stats), self._p(count)), "ccl_roots")
+            n = int(count.cpu()[0])
+            if n <= cap:
+                break
+            cap = n
+        st = stats.cpu().numpy()
+        rows, bg = st[:n], st[cap]
+        order = np.argsort(rows[:, 5], kind="stable")                       # keys are unique: one component per 2x2 block / root
+        rank = np.empty(max(n, 1), np.int32)
+        rank[order] = np.arange(1, n + 1, dtype=np.int32)
+        labels = self.empty((H, W), torch.int32)
+        self._check(self.lib.rhccq_ccl_relabel(self.ctx, self._p(parent), self._p(cid), self._p(self.dev(rank)), H * W, self._p(labels)), "ccl_relabel")
+        out = np.zeros((n + 1, 5), np.int32)
+        srt = np.concatenate([bg[None], rows[order]]) if n else bg[None]
+        has = srt[:, 0] > 0
+        out[has, 0] = srt[has, 1]
+        out[has, 1] = srt[has, 3]
+        out[has, 2] = srt[has, 2] - srt[has, 1] + 1
+        out[has, 3] = srt[has, 4] - srt[has, 3] + 1
+        out[has, 4] = srt[has, 0]
+        return n, labels, out
+
+    def ccl_select(self, labels, lut):
+        """labels int32[H,W] device, lut uint8[n + 1] (numpy) -> uint8[H,W] device = lut[labels]"""
+        out = self.empty(tuple(labels.shape), torch.uint8)
+        self._check(self.lib.rhccq_ccl_select(self.ctx, self._p(labels), self._p(self.dev(np.asarray(lut, np.uint8))), labels.numel(), self._p(out)), "ccl_select")
+        return out
+
+    def roi_buffer(self, region_map, rgb, buffer_size=3):
+        """extract_roi_nonroi on the device: -> (roi_image, nonroi_image uint8[H,W,3], roi_mask, nonroi_mask bool[H,W])"""
+        assert region_map.dtype == torch.uint8 and rgb.dtype == torch.uint8 and region_map.is_contiguous() and rgb.is_contiguous()
+        H, W = int(rgb.shape[0]), int(rgb.shape[1])
+        assert tuple(region_map.shape) == (H, W) and rgb.shape[-1] == 3
+        rm, nm = self.empty((H, W), torch.uint8), self.empty((H, W), torch.uint8)
+        ri, ni = torch.empty_like(rgb), torch.empty_like(rgb)
+        self._check(self.lib.rhccq_roi_buffer(self.ctx, self._p(region_map), self._p(rgb), H, W, int(buffer_size), self._p(rm), self._p(nm),
+                                              self._p(ri), self._p(ni)), "roi_buffer")
+        return ri, ni, rm.view(torch.bool), nm.view(torch.bool)
+
     # -- K6 / decode ------------------------------------------------------------------------------
     def remap(self, idx, lut):
         out = torch.empty_like(idx)

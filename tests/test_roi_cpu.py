@@ -1,0 +1,95 @@
+"""CPU checks of the oracle's region-extraction restatements (encoder/ROI/roi.py:45-103,285-360,685-718).
+PARITY UNPINNED for OpenCV's label numbering (cv2 is absent from the build container): what is checked here is the
+restated rule against a literal flood fill in block-raster order, the partition against scipy, and extract_roi_nonroi
+(scipy + numpy in the reference too) against the L1-ball definition of its dilations."""
+import os
+import sys
+
+import numpy as np
+import pytest
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, ROOT)
+from oracle import rhccq_oracle as O  # noqa: E402
+
+
+def masks():
+    rng = np.random.default_rng(5)
+    out = [("empty", np.zeros((5, 7), bool)), ("full", np.ones((6, 9), bool)), ("one", np.ones((1, 1), bool)),
+           ("row", rng.random((1, 70)) < 0.5), ("col", rng.random((70, 1)) < 0.5)]
+    for i, (h, w, d) in enumerate([(17, 23, 0.3), (40, 130, 0.45), (64, 64, 0.6), (33, 200, 0.2), (90, 67, 0.52)]):
+        out.append((f"rand{i}", rng.random((h, w)) < d))
+    yy, xx = np.mgrid[0:48, 0:80]
+    out.append(("checker", (yy + xx) % 2 == 0))
+    out.append(("dots", (yy % 2 == 0) & (xx % 2 == 0)))
+    out.append(("stripes", yy % 3 == 0))
+    return out
+
+
+def flood_numbering(mask, connectivity):
+    """literal restatement of the numbering rule: visit 2x2 blocks in raster order (pixels for 4-connectivity); an unlabelled
+    foreground pixel starts the next component, flood-filled at once"""
+    H, W = mask.shape
+    lab = np.zeros((H, W), np.int32)
+    nb = [(-1, 0), (1, 0), (0, -1), (0, 1)] + ([(-1, -1), (-1, 1), (1, -1), (1, 1)] if connectivity == 8 else [])
+    order = ([(y, x) for by in range(0, H, 2) for bx in range(0, W, 2) for y in (by, by + 1) for x in (bx, bx + 1) if y < H and x < W]
+             if connectivity == 8 else [(y, x) for y in range(H) for x in range(W)])
+    n = 0
+    for y, x in order:
+        if not mask[y, x] or lab[y, x]:
+            continue
+        n += 1
+        stack = [(y, x)]
+        lab[y, x] = n
+        while stack:
+            cy, cx = stack.pop()
+            for dy, dx in nb:
+                qy, qx = cy + dy, cx + dx
+                if 0 <= qy < H and 0 <= qx < W and mask[qy, qx] and not lab[qy, qx]:
+                    lab[qy, qx] = n
+                    stack.append((qy, qx))
+    return n, lab
+
+
+@pytest.mark.parametrize("connectivity", [4, 8])
+def test_component_numbering_rule(connectivity):
+    for name, m in masks():
+        num, lab, stats = O.cv_connected_components_with_stats(m, connectivity)
+        n, ref = flood_numbering(m, connectivity)
+        assert num == n + 1 and np.array_equal(lab, ref), name
+        for k in range(1, num):
+            ys, xs = np.nonzero(lab == k)
+            assert tuple(stats[k]) == (xs.min(), ys.min(), xs.max() - xs.min() + 1, ys.max() - ys.min() + 1, len(ys)), name
+        if (~m).any():
+            assert stats[0, 4] == (~m).sum()
+
+
+def test_extract_regions_and_buffer_zone():
+    rng = np.random.default_rng(11)
+    H, W = 60, 90
+    img = rng.integers(0, 256, (H, W, 3), dtype=np.uint8)
+    yy, xx = np.mgrid[0:H, 0:W]
+    region_map = (((yy - 30) ** 2 + (xx - 40) ** 2 < 400) | ((yy < 6) & (xx > 80))).astype(np.uint8)
+    ri, ni, rm, nm = O.extract_roi_nonroi(img, region_map, 3)
+    # L1 ball of radius 3, border value 0
+    def ball(core):
+        out = np.zeros_like(core)
+        for dy in range(-3, 4):
+            for dx in range(-(3 - abs(dy)), 3 - abs(dy) + 1):
+                sh = np.zeros_like(core)
+                ys, yd = slice(max(0, -dy), H - max(0, dy)), slice(max(0, dy), H - max(0, -dy))
+                xs, xd = slice(max(0, -dx), W - max(0, dx)), slice(max(0, dx), W - max(0, -dx))
+                sh[yd, xd] = core[ys, xs]
+                out |= sh
+        return out
+    buf = ball(region_map == 1) & ball(region_map == 0)
+    assert np.array_equal(rm, (region_map == 1) | buf) and np.array_equal(nm, (region_map == 0) | buf)
+    assert np.array_equal(ri, img * rm[..., None]) and np.array_equal(ni, img * nm[..., None])
+    roi, non = O.extract_regions(img, rm, nm)
+    mn = O.roi_min_region_size(img)
+    assert mn == 162 and all(r["area"] >= mn for r in roi)            # 16 200 values -> ceil(16200 / 10^(5-3)), roi.py:47-49
+    assert [r.get("type") for r in non].count("nonroi") == 1 and non[-1]["area"] < mn      # the small corner component moved over
+    for r in roi + non:
+        y0, x0, y1, x1 = r["bbox"]
+        assert r["bbox_mask"].shape == (y1 - y0, x1 - x0) and r["bbox_mask"].sum() == r["area"] == len(r["coords"])
+        assert np.array_equal(r["full_image"], img * r["mask"][..., None])
