@@ -277,21 +277,19 @@ int rhccq_slic_connectivity_host(const int32_t* labels_host, int32_t H, int32_t 
  * clean-up step of the encoder/ROI modules).  PARITY UNPINNED for the label NUMBERING: OpenCV is absent from the build container; its
  * published block-based algorithms (Grana's BBDT / Bolelli's Spaghetti, 8-connectivity) number components by their first
  * 2x2 block in block-raster order, the pixel-based 4-connectivity one by their first pixel; the partition itself is unambiguous.
- * rhccq_ccl_roots: mask (device u8[H][W], nonzero = foreground), connectivity 4 or 8; numbering 0 = OpenCV's (above), 1 = by first
- *   pixel in raster order (scipy.ndimage.label / skimage.measure.label, roi.py:262 extract_connected_regions); work: rhccq_ccl_work_bytes(H, W) bytes;
- *   parent (device int32[H*W]): root pixel (= first pixel of the component in raster order) of every foreground pixel, -1 elsewhere;
- *   cid (device int32[H*W]): at root positions the compact component id (arbitrary order), other entries untouched;
- *   stats (device int32[cap + 1][6]): per compact id {area, min x, max x, min y, max y, order key}; row `cap` = the background;
- *   count (device int32): number of components (when it exceeds cap, call again with a larger cap).
- * rhccq_ccl_relabel: labels[p] = rank[cid[parent[p]]] for foreground pixels, 0 elsewhere (rank: device int32[count]).
+ * rhccq_ccl: mask (device u8[H][W], nonzero = foreground), connectivity 4 or 8; numbering 0 = OpenCV's (above), 1 = by first
+ *   pixel in raster order (scipy.ndimage.label / skimage.measure.label, roi.py:262 extract_connected_regions);
+ *   work: rhccq_ccl_work_bytes(H, W, cap) bytes of device scratch; labels (device int32[H][W]): 0 = background, 1..count;
+ *   stats (device int32[cap + 1][5]): row l = {CC_STAT_LEFT, TOP, WIDTH, HEIGHT, AREA} of label l, row 0 = the background;
+ *   count (device int32): number of components.  When count > cap the labels are all 0 and the statistics meaningless:
+ *   call again with cap >= count.  No host synchronisation inside.
  * rhccq_ccl_select: out[p] = lut[labels[p]] (u8 look-up per label: keep / drop whole components).
  * rhccq_roi_buffer = extract_roi_nonroi (roi.py:685-718): region_map (device u8, 1 = ROI core, 0 = non-ROI core), both cores
  * dilated buffer_size times with scipy's default cross (= L1 ball, border value 0), buffer zone = both dilations; outputs the
  * two masks (u8 0/1) and the two masked copies of rgb.  This one is pinned: the reference calls scipy.ndimage.binary_dilation. */
-int64_t rhccq_ccl_work_bytes(int32_t H, int32_t W);
-int rhccq_ccl_roots(rhccq_ctx* ctx, const uint8_t* mask, int32_t H, int32_t W, int32_t connectivity, int32_t numbering, void* work, int64_t work_bytes,
-                    int32_t* parent, int32_t* cid, int32_t cap, int32_t* stats, int32_t* count);
-int rhccq_ccl_relabel(rhccq_ctx* ctx, const int32_t* parent, const int32_t* cid, const int32_t* rank, int64_t n_pixels, int32_t* labels);
+int64_t rhccq_ccl_work_bytes(int32_t H, int32_t W, int32_t cap);
+int rhccq_ccl(rhccq_ctx* ctx, const uint8_t* mask, int32_t H, int32_t W, int32_t connectivity, int32_t numbering, void* work, int64_t work_bytes,
+              int32_t cap, int32_t* labels, int32_t* stats, int32_t* count);
 int rhccq_ccl_select(rhccq_ctx* ctx, const int32_t* labels, const uint8_t* lut, int64_t n_pixels, uint8_t* out);
 int rhccq_roi_buffer(rhccq_ctx* ctx, const uint8_t* region_map, const uint8_t* rgb, int32_t H, int32_t W, int32_t buffer_size,
                      uint8_t* roi_mask, uint8_t* nonroi_mask, uint8_t* roi_image, uint8_t* nonroi_image);

@@ -63,9 +63,8 @@ PROTOTYPES = {
     "rhccq_split_stats": (c_int32, [c_void_p, c_void_p, c_int32, c_int32, c_void_p, c_void_p, c_int64, c_void_p]),
     "rhccq_slic_assign": (c_int32, [c_void_p, c_void_p, c_void_p, c_void_p, c_int32, c_int32, c_int32, c_double, c_int32, c_void_p]),
     "rhccq_slic_connectivity_host": (c_int32, [c_void_p, c_int32, c_int32, c_int32, c_int32, c_void_p]),
-    "rhccq_ccl_work_bytes": (c_int64, [c_int32, c_int32]),
-    "rhccq_ccl_roots": (c_int32, [c_void_p, c_void_p, c_int32, c_int32, c_int32, c_int32, c_void_p, c_int64, c_void_p, c_void_p, c_int32, c_void_p, c_void_p]),
-    "rhccq_ccl_relabel": (c_int32, [c_void_p, c_void_p, c_void_p, c_void_p, c_int64, c_void_p]),
+    "rhccq_ccl_work_bytes": (c_int64, [c_int32, c_int32, c_int32]),
+    "rhccq_ccl": (c_int32, [c_void_p, c_void_p, c_int32, c_int32, c_int32, c_int32, c_void_p, c_int64, c_int32, c_void_p, c_void_p, c_void_p]),
     "rhccq_ccl_select": (c_int32, [c_void_p, c_void_p, c_void_p, c_int64, c_void_p]),
     "rhccq_roi_buffer": (c_int32, [c_void_p, c_void_p, c_void_p, c_int32, c_int32, c_int32, c_void_p, c_void_p, c_void_p, c_void_p]),
     "rhccq_mt_uniforms": (c_int32, [c_void_p, c_void_p, c_int64, c_int64, c_void_p]),

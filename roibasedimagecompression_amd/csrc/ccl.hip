@@ -8,17 +8,19 @@
 //                lanes: the run start is the position above the highest 0 bit below the lane).
 //   ccl_merge:   lock-free union-find; a pixel links to the row above / the previous segment only where its left neighbour
 //                cannot have done so already (run starts and diagonal-only contacts), so a solid area issues no union at all.
-//   ccl_flatten: parent[p] = root; roots take a compact id and initialise their statistics row.
+//   ccl_flatten: parent[p] = root (one tree walk per run, shared through the wave); roots take a compact id.
 //   ccl_stats:   area / bounding box / first 2x2 block per root; every value comes from the ballot of the lanes that share
-//                a root (popcount, ctz, clz), one lane per (wave, root) issues the atomics.
-//   ccl_relabel: labels[p] = rank[id[root]] (the host ranks the roots in OpenCV's numbering order, see api/roi.py).
-// HBM bytes per pixel (algorithmic): 1 B mask read + 4 B parent written (init), 4 B read (merge, + the rare union walks),
-// 4 + 4 (flatten), 4 (stats), 4 + 4 (relabel): 29 B/px for the whole labelling.
+//                a root (popcount, ctz, clz), gathered per workgroup in an LDS table, then a handful of global atomics.
+//   ccl_mark / scan / rank: the numbering.  Ordering keys are unique small integers, so label = 1 + number of smaller keys
+//                = a prefix count over the key bit plane; the statistics land in label order, in cv2's column order.
+//   ccl_relabel: labels[p] = rank[id[root]].
+// One C call, no host round trip inside.  HBM bytes per pixel (algorithmic): 1 B mask read + 4 B parent written (init),
+// 4 + 4 (flatten), 4 (stats), 4 + 4 (relabel) = 25 B/px; merge reads the 1-bit plane only.
 #include "rhccq_common.h"
 
 namespace rhccq {
 
-constexpr int kCclStat = 6;   // area, min x, max x, min y, max y, first block key
+constexpr int kCclStat = 6;   // area, min x, max x, min y, max y, ordering key
 
 __device__ __forceinline__ int ccl_find(const int32_t* parent, int x) {
   int p = __hip_atomic_load(parent + x, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
@@ -107,64 +109,199 @@ __global__ __launch_bounds__(256) void ccl_merge_kernel(const uint64_t* __restri
   }
 }
 
-// key_is_root (4-connectivity, or raster numbering asked for): the ordering key of a component is its first pixel in raster order = the root itself
-__global__ __launch_bounds__(256) void ccl_flatten_kernel(int32_t* parent, long long n, int32_t* __restrict__ cid, int cap, int32_t* __restrict__ stats,
-                                                          int32_t* count, int key_is_root) {
-  const long long p = (long long)blockIdx.x * 256 + threadIdx.x;
-  if (p >= n) return;
-  if (p == 0) {                                             // statistics row `cap` = background (label 0 of cv2's stats)
-    int32_t* s = stats + (long long)cap * kCclStat;
-    s[0] = 0; s[1] = 0x7fffffff; s[2] = -1; s[3] = 0x7fffffff; s[4] = -1; s[5] = -1;
-  }
-  if (parent[p] < 0) return;
-  const int r = ccl_find(parent, (int)p);
-  parent[p] = r;
-  if (r == (int)p) {
-    const int id = atomicAdd(count, 1);
-    cid[p] = id;
-    if (id < cap) {
-      int32_t* s = stats + (long long)id * kCclStat;
-      s[0] = 0; s[1] = 0x7fffffff; s[2] = -1; s[3] = 0x7fffffff; s[4] = -1; s[5] = key_is_root ? r : 0x7fffffff;
-    }
-  }
+constexpr int kCclEmpty = -3;     // LDS slot marker (roots are >= 0, the background aggregates under -1)
+constexpr int kCclSlots = 128;
+
+__device__ __forceinline__ void ccl_stat_reset(int32_t* s, int key) {
+  s[0] = 0; s[1] = 0x7fffffff; s[2] = -1; s[3] = 0x7fffffff; s[4] = -1; s[5] = key;
 }
 
-__global__ __launch_bounds__(256) void ccl_stats_kernel(const int32_t* __restrict__ parent, const int32_t* __restrict__ cid, int H, int W, int segs,
-                                                        int cap, int32_t* stats, int key_is_root) {
+// parent[p] = root.  Only the first pixel of each horizontal run walks the tree (the other pixels of a run still point at it:
+// they are never roots, so no union ever touched them); roots take a compact id and reset their statistics row.
+// key_is_root (4-connectivity, or raster numbering asked for): the ordering key of a component is its first pixel = the root
+__global__ __launch_bounds__(256) void ccl_flatten_kernel(int32_t* parent, int H, int W, int segs, int32_t* __restrict__ cid, int cap,
+                                                          int32_t* __restrict__ stats, int32_t* count, int key_is_root) {
   int y, seg, lane;
   if (!ccl_wave_pos(H, segs, y, seg, lane)) return;
   const int x = seg * 64 + lane;
-  const int r = x < W ? parent[(long long)y * W + x] : -2;  // -1 background, -2 outside
-  uint64_t todo = __ballot(r != -2);
-  const int w2 = (W + 1) >> 1;
-  while (todo) {
-    const int first = __builtin_ctzll(todo);
-    const int lead = __shfl(r, first);
-    const uint64_t same = __ballot(r == lead);
-    todo &= ~same;
-    if (lane == first) {
-      const int id = lead < 0 ? cap : cid[lead];
-      if (lead < 0 || id < cap) {
-        int32_t* s = stats + (long long)id * kCclStat;
-        const int x0 = seg * 64 + __builtin_ctzll(same), x1 = seg * 64 + 63 - __clzll((long long)same);
-        atomicAdd(&s[0], __popcll(same));
-        atomicMin(&s[1], x0);
-        atomicMax(&s[2], x1);
-        atomicMin(&s[3], y);
-        atomicMax(&s[4], y);
-        // first 2x2 block in block-raster order: only pixels of the root's row pair can hold it
-        if (!key_is_root && lead >= 0 && (y >> 1) == ((lead / W) >> 1)) atomicMin(&s[5], (y >> 1) * w2 + (x0 >> 1));
-      }
-    }
+  const int p = y * W + x;
+  if (p == 0) ccl_stat_reset(stats + (long long)cap * kCclStat, -1);     // row `cap` = background (label 0 of cv2's stats)
+  const bool fg = x < W && parent[p] >= 0;
+  const uint64_t b = __ballot(fg);
+  const bool is_start = fg && (lane == 0 || !((b >> (lane - 1)) & 1ull));
+  int r = -1;
+  if (is_start) r = ccl_find(parent, p);
+  const uint64_t zeros_below = ~b & ((1ull << lane) - 1ull);
+  const int start = zeros_below ? 64 - __clzll((long long)zeros_below) : 0;
+  const int rs = __shfl(r, start);
+  if (fg && !is_start) r = rs;
+  if (fg) parent[p] = r;
+  const bool root = fg && r == p;
+  const uint64_t roots = __ballot(root);                     // one counter update per wave
+  if (!roots) return;
+  int base = 0;
+  const int leader = __builtin_ctzll(roots);
+  if (lane == leader) base = atomicAdd(count, __popcll(roots));
+  base = __shfl(base, leader);
+  if (root) {
+    const int id = base + __popcll(roots & ((1ull << lane) - 1ull));
+    cid[p] = id;
+    if (id < cap) ccl_stat_reset(stats + (long long)id * kCclStat, key_is_root ? r : 0x7fffffff);
   }
 }
 
+__device__ __forceinline__ void ccl_stat_add(int32_t* s, int area, int x0, int x1, int y0, int y1, int key) {
+  atomicAdd(&s[0], area);
+  atomicMin(&s[1], x0);
+  atomicMax(&s[2], x1);
+  atomicMin(&s[3], y0);
+  atomicMax(&s[4], y1);
+  if (key != 0x7fffffff) atomicMin(&s[5], key);
+}
+
+// area / bounding box / first 2x2 block per root.  A workgroup walks `units` consecutive (row, segment) units; per wave every
+// value comes from the ballot of the lanes that share a root (popcount, ctz, clz); they are gathered in an LDS table keyed by
+// root and only its occupied slots reach the global statistics rows (a solid 4K area: 6 atomics per workgroup, not per wave).
+__global__ __launch_bounds__(1024) void ccl_stats_kernel(const int32_t* __restrict__ parent, const int32_t* __restrict__ cid, int H, int W, int segs,
+                                                         int cap, int32_t* stats, int key_is_root, int units) {
+  __shared__ int s_key[kCclSlots];
+  __shared__ int32_t s_val[kCclSlots][kCclStat];
+  for (int i = threadIdx.x; i < kCclSlots; i += 1024) {
+    s_key[i] = kCclEmpty;
+    ccl_stat_reset(s_val[i], 0x7fffffff);
+  }
+  __syncthreads();
+  const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
+  const long long total = (long long)H * segs;
+  const int w2 = (W + 1) >> 1;
+  for (int it = wave; it < units; it += 16) {
+    const long long u = (long long)blockIdx.x * units + it;
+    if (u >= total) break;
+    const int y = (int)(u / segs), seg = (int)(u % segs);
+    const int x = seg * 64 + lane;
+    const int r = x < W ? parent[(long long)y * W + x] : -2;  // -1 background, -2 outside
+    uint64_t todo = __ballot(r != -2);
+    while (todo) {
+      const int first = __builtin_ctzll(todo);
+      const int lead = __shfl(r, first);
+      const uint64_t same = __ballot(r == lead);
+      todo &= ~same;
+      if (lane == first) {
+        const int x0 = seg * 64 + __builtin_ctzll(same), x1 = seg * 64 + 63 - __clzll((long long)same);
+        // first 2x2 block in block-raster order: only pixels of the root's row pair can hold it
+        const int key = (!key_is_root && lead >= 0 && (y >> 1) == ((lead / W) >> 1)) ? (y >> 1) * w2 + (x0 >> 1) : 0x7fffffff;
+        int slot = (int)(((unsigned)lead * 2654435761u) >> 25);           // 7 bits
+        bool done = false;
+        for (int probe = 0; probe < 8 && !done; ++probe, slot = (slot + 1) & (kCclSlots - 1)) {
+          const int old = atomicCAS(&s_key[slot], kCclEmpty, lead);
+          if (old == kCclEmpty || old == lead) {
+            ccl_stat_add(s_val[slot], __popcll(same), x0, x1, y, y, key);
+            done = true;
+          }
+        }
+        if (!done) {                                                       // table crowded: straight to the global row
+          const int id = lead < 0 ? cap : cid[lead];
+          if (lead < 0 || id < cap) ccl_stat_add(stats + (long long)id * kCclStat, __popcll(same), x0, x1, y, y, key);
+        }
+      }
+    }
+  }
+  __syncthreads();
+  for (int i = threadIdx.x; i < kCclSlots; i += 1024) {
+    const int lead = s_key[i];
+    if (lead == kCclEmpty) continue;
+    const int id = lead < 0 ? cap : cid[lead];
+    if (lead < 0 || id < cap) ccl_stat_add(stats + (long long)id * kCclStat, s_val[i][0], s_val[i][1], s_val[i][2], s_val[i][3], s_val[i][4], s_val[i][5]);
+  }
+}
+
+// ---- numbering on the device: the ordering keys are unique integers below n_keys, so a component's label is 1 + the number
+// of smaller keys = a prefix count over the key bit plane (mark -> per-word popcounts scanned in two levels -> rank)
+__global__ __launch_bounds__(256) void ccl_mark_kernel(const int32_t* __restrict__ stats, const int32_t* __restrict__ count, int cap,
+                                                       unsigned long long* keybits) {
+  const int id = blockIdx.x * 256 + threadIdx.x;
+  const int n = min(*count, cap);
+  if (id >= n) return;
+  const int key = stats[(long long)id * kCclStat + 5];
+  atomicOr(&keybits[key >> 6], 1ull << (key & 63));
+}
+
+__device__ __forceinline__ int ccl_block_exclusive_scan(int v, int* s_wave /* [17] */, int& block_total) {
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+  int inc = v;
+  for (int d = 1; d < 64; d <<= 1) {
+    const int t = __shfl_up(inc, d);
+    if (lane >= d) inc += t;
+  }
+  if (lane == 63) s_wave[wave] = inc;
+  __syncthreads();
+  if (threadIdx.x == 0) {
+    int acc = 0;
+    for (int w = 0; w < 16; ++w) { const int t = s_wave[w]; s_wave[w] = acc; acc += t; }
+    s_wave[16] = acc;
+  }
+  __syncthreads();
+  block_total = s_wave[16];
+  return s_wave[wave] + inc - v;
+}
+
+__global__ __launch_bounds__(1024) void ccl_scan_words_kernel(const unsigned long long* __restrict__ keybits, long long n_words, int32_t* __restrict__ wordrank,
+                                                              int32_t* __restrict__ blocksum) {
+  __shared__ int s_wave[17];
+  const long long w = (long long)blockIdx.x * 1024 + threadIdx.x;
+  const int v = w < n_words ? __popcll(keybits[w]) : 0;
+  int total;
+  const int ex = ccl_block_exclusive_scan(v, s_wave, total);
+  if (w < n_words) wordrank[w] = ex;
+  if (threadIdx.x == 0) blocksum[blockIdx.x] = total;
+}
+
+__global__ __launch_bounds__(1024) void ccl_scan_blocks_kernel(int32_t* blocksum, int n_blocks) {
+  __shared__ int s_wave[17];
+  int carry = 0;
+  for (int base = 0; base < n_blocks; base += 1024) {
+    const int i = base + threadIdx.x;
+    const int v = i < n_blocks ? blocksum[i] : 0;
+    int total;
+    const int ex = ccl_block_exclusive_scan(v, s_wave, total);
+    if (i < n_blocks) blocksum[i] = carry + ex;
+    carry += total;
+    __syncthreads();
+  }
+}
+
+// rank[id] = label; the component's row of the cv2-ordered statistics (LEFT, TOP, WIDTH, HEIGHT, AREA); row 0 = background
+__global__ __launch_bounds__(256) void ccl_rank_kernel(const int32_t* __restrict__ stats, const int32_t* __restrict__ count, int cap,
+                                                       const unsigned long long* __restrict__ keybits, const int32_t* __restrict__ wordrank,
+                                                       const int32_t* __restrict__ blocksum, int32_t* __restrict__ rank, int32_t* __restrict__ out) {
+  const int id = blockIdx.x * 256 + threadIdx.x;
+  const int n = min(*count, cap);
+  if (id > n) return;
+  const int32_t* s = stats + (long long)(id == n ? cap : id) * kCclStat;
+  int label = 0;
+  if (id < n) {
+    const int key = s[5], w = key >> 6;
+    label = 1 + blocksum[w >> 10] + wordrank[w] + __popcll(keybits[w] & ((1ull << (key & 63)) - 1ull));
+    rank[id] = label;
+  }
+  int32_t* o = out + (long long)label * 5;
+  const bool any = s[0] > 0;
+  o[0] = any ? s[1] : 0;
+  o[1] = any ? s[3] : 0;
+  o[2] = any ? s[2] - s[1] + 1 : 0;
+  o[3] = any ? s[4] - s[3] + 1 : 0;
+  o[4] = s[0];
+}
+
 __global__ __launch_bounds__(256) void ccl_relabel_kernel(const int32_t* __restrict__ parent, const int32_t* __restrict__ cid,
-                                                          const int32_t* __restrict__ rank, long long n, int32_t* __restrict__ labels) {
+                                                          const int32_t* __restrict__ rank, const int32_t* __restrict__ count, int cap, long long n,
+                                                          int32_t* __restrict__ labels) {
   const long long p = (long long)blockIdx.x * 256 + threadIdx.x;
   if (p >= n) return;
   const int r = parent[p];
-  labels[p] = r < 0 ? 0 : rank[cid[r]];
+  int v = 0;
+  if (r >= 0 && *count <= cap) v = rank[cid[r]];              // more components than `cap`: the caller repeats the call; labels stay 0
+  labels[p] = v;
 }
 
 // out[p] = lut[labels[p]] (u8): keeps / drops whole components (every "remove regions whose statistic ..." step of encoder/ROI/*)
@@ -229,40 +366,76 @@ using namespace rhccq;
 
 extern "C" {
 
-int64_t rhccq_ccl_work_bytes(int32_t H, int32_t W) {
-  if (H <= 0 || W <= 0) return 0;
-  const long long segs = (W + 63) / 64;
-  return (long long)H * segs * 8 + 256;                     // the bit plane
+namespace {
+struct CclWork {
+  size_t bits, parent, cid, stats, keybits, wordrank, blocksum, rank, total;
+  long long n_keys, n_words;
+  int n_blocks;
+};
+CclWork ccl_layout(int H, int W, int cap, bool key_is_root) {
+  CclWork w{};
+  auto up = [](size_t v) { return (v + 255) & ~(size_t)255; };
+  const long long segs = (W + 63) / 64, n = (long long)H * W;
+  w.n_keys = key_is_root ? n : (long long)((H + 1) / 2) * ((W + 1) / 2);
+  w.n_words = (w.n_keys + 63) / 64;
+  w.n_blocks = (int)((w.n_words + 1023) / 1024);
+  size_t o = 0;
+  w.bits = o;     o = up(o + (size_t)H * segs * 8);
+  w.parent = o;   o = up(o + (size_t)n * 4);
+  w.cid = o;      o = up(o + (size_t)n * 4);
+  w.stats = o;    o = up(o + ((size_t)cap + 1) * kCclStat * 4);
+  w.keybits = o;  o = up(o + (size_t)w.n_words * 8);
+  w.wordrank = o; o = up(o + (size_t)w.n_words * 4);
+  w.blocksum = o; o = up(o + (size_t)w.n_blocks * 4);
+  w.rank = o;     o = up(o + (size_t)(cap > 0 ? cap : 1) * 4);
+  w.total = o;
+  return w;
+}
+}  // namespace
+
+int64_t rhccq_ccl_work_bytes(int32_t H, int32_t W, int32_t cap) {
+  if (H <= 0 || W <= 0 || cap < 0) return 0;
+  return (int64_t)ccl_layout(H, W, cap, true).total;            // raster keys need the larger planes
 }
 
-int rhccq_ccl_roots(rhccq_ctx* ctx, const uint8_t* mask, int32_t H, int32_t W, int32_t connectivity, int32_t numbering, void* work, int64_t work_bytes,
-                    int32_t* parent, int32_t* cid, int32_t cap, int32_t* stats, int32_t* count) {
-  if (!ctx || !mask || !work || !parent || !cid || !stats || !count || H <= 0 || W <= 0 || cap < 0)
-    return rhccq_fail(ctx, RHCCQ_E_ARG, "ccl_roots: bad argument");
-  if (connectivity != 4 && connectivity != 8) return rhccq_fail(ctx, RHCCQ_E_ARG, "ccl_roots: connectivity must be 4 or 8");
-  if ((long long)H * W >= 0x7fffffffLL) return rhccq_fail(ctx, RHCCQ_E_LIMIT, "ccl_roots: more than 2^31 pixels");
-  if (work_bytes < rhccq_ccl_work_bytes(H, W)) return rhccq_fail(ctx, RHCCQ_E_ARG, "ccl_roots: work buffer too small");
-  if (numbering != 0 && numbering != 1) return rhccq_fail(ctx, RHCCQ_E_ARG, "ccl_roots: numbering must be 0 (OpenCV) or 1 (raster)");
+int rhccq_ccl(rhccq_ctx* ctx, const uint8_t* mask, int32_t H, int32_t W, int32_t connectivity, int32_t numbering, void* work, int64_t work_bytes,
+              int32_t cap, int32_t* labels, int32_t* stats, int32_t* count) {
+  if (!ctx || !mask || !work || !labels || !stats || !count || H <= 0 || W <= 0 || cap < 0) return rhccq_fail(ctx, RHCCQ_E_ARG, "ccl: bad argument");
+  if (connectivity != 4 && connectivity != 8) return rhccq_fail(ctx, RHCCQ_E_ARG, "ccl: connectivity must be 4 or 8");
+  if (numbering != 0 && numbering != 1) return rhccq_fail(ctx, RHCCQ_E_ARG, "ccl: numbering must be 0 (OpenCV) or 1 (raster)");
+  if ((long long)H * W >= 0x7fffffffLL) return rhccq_fail(ctx, RHCCQ_E_LIMIT, "ccl: more than 2^31 pixels");
+  if (work_bytes < rhccq_ccl_work_bytes(H, W, cap)) return rhccq_fail(ctx, RHCCQ_E_ARG, "ccl: work buffer too small");
   const int key_is_root = (connectivity == 4 || numbering == 1) ? 1 : 0;
+  const CclWork L = ccl_layout(H, W, cap, key_is_root != 0);
+  char* base = (char*)work;
+  uint64_t* bits = (uint64_t*)(base + L.bits);
+  int32_t* parent = (int32_t*)(base + L.parent);
+  int32_t* cid = (int32_t*)(base + L.cid);
+  int32_t* raw = (int32_t*)(base + L.stats);
+  unsigned long long* keybits = (unsigned long long*)(base + L.keybits);
+  int32_t* wordrank = (int32_t*)(base + L.wordrank);
+  int32_t* blocksum = (int32_t*)(base + L.blocksum);
+  int32_t* rank = (int32_t*)(base + L.rank);
   const int segs = (W + 63) / 64;
-  const long long n = (long long)H * W;
-  const unsigned wgrid = (unsigned)(((long long)H * segs + 3) / 4), pgrid = (unsigned)((n + 255) / 256);
-  uint64_t* bits = (uint64_t*)work;
+  const long long n = (long long)H * W, units_total = (long long)H * segs;
+  const unsigned wgrid = (unsigned)((units_total + 3) / 4), pgrid = (unsigned)((n + 255) / 256);
+  const int units = 128;
   RHCCQ_HIP(ctx, hipMemsetAsync(count, 0, sizeof(int32_t), ctx->stream));
+  RHCCQ_HIP(ctx, hipMemsetAsync(keybits, 0, (size_t)L.n_words * 8, ctx->stream));
   hipLaunchKernelGGL(ccl_init_kernel, dim3(wgrid), dim3(256), 0, ctx->stream, mask, H, W, segs, bits, parent);
   if (connectivity == 4)
     hipLaunchKernelGGL(ccl_merge_kernel<4>, dim3(wgrid), dim3(256), 0, ctx->stream, bits, H, W, segs, parent);
   else
     hipLaunchKernelGGL(ccl_merge_kernel<8>, dim3(wgrid), dim3(256), 0, ctx->stream, bits, H, W, segs, parent);
-  hipLaunchKernelGGL(ccl_flatten_kernel, dim3(pgrid), dim3(256), 0, ctx->stream, parent, n, cid, cap, stats, count, key_is_root);
-  hipLaunchKernelGGL(ccl_stats_kernel, dim3(wgrid), dim3(256), 0, ctx->stream, parent, cid, H, W, segs, cap, stats, key_is_root);
-  RHCCQ_LAUNCH_CHECK(ctx);
-  return 0;
-}
-
-int rhccq_ccl_relabel(rhccq_ctx* ctx, const int32_t* parent, const int32_t* cid, const int32_t* rank, int64_t n_pixels, int32_t* labels) {
-  if (!ctx || !parent || !cid || !rank || !labels || n_pixels <= 0) return rhccq_fail(ctx, RHCCQ_E_ARG, "ccl_relabel: bad argument");
-  hipLaunchKernelGGL(ccl_relabel_kernel, dim3((unsigned)((n_pixels + 255) / 256)), dim3(256), 0, ctx->stream, parent, cid, rank, (long long)n_pixels, labels);
+  hipLaunchKernelGGL(ccl_flatten_kernel, dim3(wgrid), dim3(256), 0, ctx->stream, parent, H, W, segs, cid, cap, raw, count, key_is_root);
+  hipLaunchKernelGGL(ccl_stats_kernel, dim3((unsigned)((units_total + units - 1) / units)), dim3(1024), 0, ctx->stream, parent, cid, H, W, segs, cap, raw,
+                     key_is_root, units);
+  const unsigned cgrid = (unsigned)((cap + 1 + 255) / 256);
+  hipLaunchKernelGGL(ccl_mark_kernel, dim3(cgrid), dim3(256), 0, ctx->stream, raw, count, cap, keybits);
+  hipLaunchKernelGGL(ccl_scan_words_kernel, dim3((unsigned)L.n_blocks), dim3(1024), 0, ctx->stream, keybits, L.n_words, wordrank, blocksum);
+  hipLaunchKernelGGL(ccl_scan_blocks_kernel, dim3(1), dim3(1024), 0, ctx->stream, blocksum, L.n_blocks);
+  hipLaunchKernelGGL(ccl_rank_kernel, dim3(cgrid), dim3(256), 0, ctx->stream, raw, count, cap, keybits, wordrank, blocksum, rank, stats);
+  hipLaunchKernelGGL(ccl_relabel_kernel, dim3(pgrid), dim3(256), 0, ctx->stream, parent, cid, rank, count, cap, n, labels);
   RHCCQ_LAUNCH_CHECK(ctx);
   return 0;
 }

@@ -691,35 +691,19 @@ class Rhccq:
             mask = mask.view(torch.uint8)
         assert mask.dtype == torch.uint8 and mask.dim() == 2 and mask.is_contiguous()
         H, W = int(mask.shape[0]), int(mask.shape[1])
-        wb = int(self.lib.rhccq_ccl_work_bytes(H, W))
-        work = self.empty((wb,), torch.uint8)
-        parent = self.empty((H * W,), torch.int32)
-        cid = self.empty((H * W,), torch.int32)
+        labels = self.empty((H, W), torch.int32)
         count = self.empty((1,), torch.int32)
         while True:
-            stats = self.empty((cap + 1, 6), torch.int32)
-            self._check(self.lib.rhccq_ccl_roots(self.ctx, self._p(mask), H, W, int(connectivity), 0 if numbering == "opencv" else 1, self._p(work), wb, self._p(parent),
-                                                 self._p(cid), cap, self._p(stats), self._p(count)), "ccl_roots")
+            wb = int(self.lib.rhccq_ccl_work_bytes(H, W, cap))
+            work = self.empty((wb,), torch.uint8)
+            stats = self.empty((cap + 1, 5), torch.int32)
+            self._check(self.lib.rhccq_ccl(self.ctx, self._p(mask), H, W, int(connectivity), 0 if numbering == "opencv" else 1, self._p(work), wb,
+                                           cap, self._p(labels), self._p(stats), self._p(count)), "ccl")
             n = int(count.cpu()[0])
             if n <= cap:
                 break
             cap = n
-        st = stats.cpu().numpy()
-        rows, bg = st[:n], st[cap]
-        order = np.argsort(rows[:, 5], kind="stable")                       # keys are unique: one component per 2x2 block / root
-        rank = np.empty(max(n, 1), np.int32)
-        rank[order] = np.arange(1, n + 1, dtype=np.int32)
-        labels = self.empty((H, W), torch.int32)
-        self._check(self.lib.rhccq_ccl_relabel(self.ctx, self._p(parent), self._p(cid), self._p(self.dev(rank)), H * W, self._p(labels)), "ccl_relabel")
-        out = np.zeros((n + 1, 5), np.int32)
-        srt = np.concatenate([bg[None], rows[order]]) if n else bg[None]
-        has = srt[:, 0] > 0
-        out[has, 0] = srt[has, 1]
-        out[has, 1] = srt[has, 3]
-        out[has, 2] = srt[has, 2] - srt[has, 1] + 1
-        out[has, 3] = srt[has, 4] - srt[has, 3] + 1
-        out[has, 4] = srt[has, 0]
-        return n, labels, out
+        return n, labels, stats[:n + 1].cpu().numpy()
 
     def ccl_select(self, labels, lut):
         """labels int32[H,W] device, lut uint8[n + 1] (numpy) -> uint8[H,W] device = lut[labels]"""
