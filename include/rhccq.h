@@ -94,7 +94,8 @@ int rhccq_job_set_black(rhccq_ctx* ctx, uint32_t* bitmaps, const int32_t* jobs, 
  * chunk_sums[n_jobs*512] */
 int rhccq_bitmap_count(rhccq_ctx* ctx, const uint32_t* bitmaps, int32_t n_jobs, uint32_t* chunk_sums,
                        int32_t* counts);
-/* per-word exclusive prefix (word_prefix[n_jobs*BITMAP_WORDS]) and the sorted palette keys of each
+/* word_prefix[n_jobs*BITMAP_WORDS][2] = (bitmap word, exclusive prefix of the set bits before it) pairs -- the table the
+ * per-pixel passes gather from, one 8-byte load per rank lookup -- and the sorted palette keys of each
  * job written at keys_out[pal_off[j] ...) (np.unique order, clustering.py:22) */
 int rhccq_bitmap_emit(rhccq_ctx* ctx, const uint32_t* bitmaps, int32_t n_jobs, const uint32_t* chunk_sums,
                       const int64_t* pal_off /* device int64[n_jobs] */, uint32_t* word_prefix,

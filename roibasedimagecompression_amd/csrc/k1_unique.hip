@@ -9,7 +9,7 @@
 // pass sets bits (test-before-atomicOr; the bitmaps of the jobs of a frame live in L2 / Infinity
 // Cache), a popcount scan turns the bitmap into ranks (== np.unique order because the key order is
 // the lexicographic R,G,B order), and every later pass recomputes a pixel's palette index as
-//   word_prefix[key >> 5] + popc(word & lower_mask)
+//   (word, prefix) = word_prefix[key >> 5];  prefix + popc(word & lower_mask)        (one 8-byte gather)
 // instead of storing a 4 B/pixel index map.  All per-pixel passes are HBM-streaming kernels:
 // 4 pixels per thread, 12 B of RGB as three dwords + one int4 of labels per class.
 #include "rhccq_common.h"
@@ -232,9 +232,10 @@ __global__ __launch_bounds__(256) void bitmap_emit_kernel(const uint32_t* __rest
   unsigned ex = block_exscan<unsigned>(c0 + c1 + c2 + c3, red, &tot);
   if (tot == 0) return;                                 // empty chunk: its prefixes are never read
   const unsigned base = chunk_base[job * kChunks + blockIdx.x] + ex;
-  uint4 pre;
-  pre.x = base; pre.y = base + c0; pre.z = base + c0 + c1; pre.w = base + c0 + c1 + c2;
-  reinterpret_cast<uint4*>(word_prefix + job * RHCCQ_BITMAP_WORDS)[w0 >> 2] = pre;
+  // (bitmap word, exclusive prefix) pairs: the per-pixel rank lookup of K1d / K6 is ONE 8-byte gather
+  uint4* wp = reinterpret_cast<uint4*>(word_prefix + 2 * (job * RHCCQ_BITMAP_WORDS + w0));
+  wp[0] = make_uint4(v.x, base, v.y, base + c0);
+  wp[1] = make_uint4(v.z, base + c0 + c1, v.w, base + c0 + c1 + c2);
   if (keys_out) {
     uint32_t* out = keys_out + pal_off[job];
     uint32_t words[4] = {v.x, v.y, v.z, v.w};
@@ -277,10 +278,9 @@ __global__ __launch_bounds__(256) void job_blackfix_kernel(const uint8_t* __rest
 }
 
 // ---- rank lookup shared by K1d and K6 ----------------------------------------------------------
-__device__ __forceinline__ uint32_t rank_of(const uint32_t* __restrict__ bitmaps, const uint32_t* __restrict__ word_prefix, int job, uint32_t key) {
-  const size_t w = (size_t)job * RHCCQ_BITMAP_WORDS + (key >> 5);
-  const uint32_t word = bitmaps[w];
-  return word_prefix[w] + __popc(word & ((1u << (key & 31u)) - 1u));
+__device__ __forceinline__ uint32_t rank_of(const uint32_t* __restrict__ word_prefix, int job, uint32_t key) {
+  const uint2 wp = reinterpret_cast<const uint2*>(word_prefix)[(size_t)job * RHCCQ_BITMAP_WORDS + (key >> 5)];
+  return wp.y + __popc(wp.x & ((1u << (key & 31u)) - 1u));
 }
 
 __global__ __launch_bounds__(256) void job_index_kernel(const uint8_t* __restrict__ rgb, int H, int W, ClassArgs ca,
@@ -305,7 +305,7 @@ __global__ __launch_bounds__(256) void job_index_kernel(const uint8_t* __restric
         const int job = ca.job_base[c] + lab[i] - 1;
         uint32_t k = key[i];
         if (k == 0u && fix_key) k = fix_key[job];      // recoloured in-mask black (0 = keep black)
-        const uint32_t rk = rank_of(bitmaps, word_prefix, job, k);
+        const uint32_t rk = rank_of(word_prefix, job, k);
         res[i] = (int32_t)rk;
         if (first_pos) {
           // fp_lut (optional) maps (job, rank) to an entry of a smaller table, e.g. the level-1 clustered
@@ -351,7 +351,7 @@ __global__ __launch_bounds__(256) void frame_remap_kernel(const uint8_t* __restr
         const int job = ca.job_base[c] + lab[i] - 1;
         uint32_t k = key[i];
         if (k == 0u && fix_key) k = fix_key[job];
-        int32_t v = lut[pal_off[job] + rank_of(bitmaps, word_prefix, job, k)];
+        int32_t v = lut[pal_off[job] + rank_of(word_prefix, job, k)];
         if (lut2) v = lut2[v];                          // level-1 index -> composed levels 2/3 (small, cache resident)
         res[i] = v;
       }

@@ -295,7 +295,7 @@ class Rhccq:
 
     def bitmap_emit(self, bitmaps, chunk, pal_off, total, want_keys=True):
         n_jobs = bitmaps.shape[0]
-        prefix = self.empty((n_jobs, BITMAP_WORDS), torch.int32)
+        prefix = self.empty((n_jobs, BITMAP_WORDS, 2), torch.int32)            # (bitmap word, exclusive prefix) pairs
         keys = self.empty((max(int(total), 1),), torch.int32) if want_keys else None
         self._check(self.lib.rhccq_bitmap_emit(self.ctx, self._p(bitmaps), n_jobs, self._p(chunk), self._p(pal_off),
                                                self._p(prefix), self._p(keys)), "bitmap_emit")
