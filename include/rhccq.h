@@ -48,10 +48,16 @@ const char* rhccq_last_error(const rhccq_ctx* ctx);
  *                              picks that exceed it evaluate each candidate by its own enumeration instead;
  *   RHCCQ_OPT_INIT_KERNEL      0 (default): the second-generation k-means++ chain whenever the block tables fit LDS;
  *                              1: the first-generation chain always (same picks; kept for problems beyond LDS and as
- *                              a cross-check). */
+ *                              a cross-check);
+ *   RHCCQ_OPT_INIT_SHARDS      workgroups (CUs) per problem of the second-generation chain: 1 (default) = one; 2 / 4 / 8 =
+ *                              up to that many, each owning a range of the draws, when every shard keeps >= 4096 init
+ *                              samples and at most 64 workgroups result (they wait for each other inside the launch, so
+ *                              all must be resident).  Same picks; measured SLOWER than one workgroup (two cross-CU
+ *                              exchanges per pick), kept as a checked alternative. */
 #define RHCCQ_OPT_INIT_LDS_BLOCKS 1
 #define RHCCQ_OPT_INIT_MAX_ITEMS 2
 #define RHCCQ_OPT_INIT_KERNEL 3
+#define RHCCQ_OPT_INIT_SHARDS 4
 int rhccq_ctx_set_int(rhccq_ctx* ctx, int32_t option, int64_t value);
 int rhccq_sync(rhccq_ctx* ctx);                 /* hipStreamSynchronize on the context stream */
 void* rhccq_stream(rhccq_ctx* ctx);             /* the hipStream_t in use */

@@ -688,7 +688,43 @@ struct JShared {
   uint32_t cna[kTMaxI];
   uint32_t ckp[kTMaxI][4];
   int n_items, overflow, n_touch2[2], n_hits;
+  // sharded chain only
+  unsigned long long tot[8];              // every shard's sum of closest (exact)
+  unsigned long long gd[8][kTMaxI];       // every shard's improvement per candidate of this pick
+  int owner[kTMaxI];
+  int abort;
 };
+
+// ---- sharded chain: C workgroups (one CU each) per problem; shard s owns the draws [s D, (s + 1) D) with its own Morton
+// index.  Per pick two exchanges through 8-byte data-tagged granules (tag = pick number, agent-scope relaxed = sc1 accesses):
+// the owner of a search target publishes the candidate's colour; every shard publishes its T partial improvements.
+constexpr int kJMaxShards = 8;
+constexpr unsigned kJTagInit = 0xffffffu;
+struct JExchange {                        // global memory, zeroed before every launch
+  unsigned long long cand[2][kTMaxI];
+  unsigned long long delta[2][kJMaxShards][kTMaxI];
+  unsigned long long tot[kJMaxShards];
+  unsigned long long abort;
+  unsigned long long pad;
+};
+__device__ __forceinline__ unsigned long long jx_load(const unsigned long long* p) {
+  return __hip_atomic_load(p, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+}
+__device__ __forceinline__ void jx_store(unsigned long long* p, unsigned tag, unsigned long long value) {
+  __hip_atomic_store(p, ((unsigned long long)tag << 40) | value, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+}
+// every lane with `on` re-reads its granule until the tags of all of them match; false = gave up (a partner aborted or
+// never arrived): the caller raises the abort words and every shard leaves the chain at its next barrier
+__device__ __forceinline__ bool jx_wait(const unsigned long long* p, bool on, unsigned tag, const unsigned long long* abort_word,
+                                        unsigned long long& value) {
+  for (unsigned spins = 0;; ++spins) {
+    unsigned long long x = 0;
+    if (on) x = jx_load(p);
+    const bool ok = !on || (unsigned)(x >> 40) == tag;
+    if (__all(ok)) { value = x & ((1ull << 40) - 1ull); return true; }
+    if ((spins & 255u) == 255u && (spins > (1u << 21) || jx_load(abort_word) != 0)) return false;
+  }
+}
 
 // sample pair, Morton order: x = key | (dpos & 255) << 24 ; y = (c' & 0x7ffff) | (dpos >> 8) << 19, c' = closest - |key|^2
 __device__ __forceinline__ uint2 jpack(uint32_t key, int cprime, uint32_t dpos) {
@@ -807,11 +843,13 @@ __device__ __forceinline__ void j_enumerate(const CandP& cp, int sb_first, int n
   }
 }
 
+template <bool kSh>
 __global__ __launch_bounds__(kJThreads) void mbk_init2_kernel(const uint32_t* __restrict__ keys, const MbkP* __restrict__ probs,
                                                                const int32_t* __restrict__ init_idx, const int32_t* __restrict__ perm,
                                                                const double* __restrict__ rand, double* __restrict__ centres,
                                                                int32_t* __restrict__ chosen, uint32_t* scratch,
-                                                               const long long* __restrict__ scratch_off, int max_items) {
+                                                               const long long* __restrict__ scratch_off, int max_items, int nshard,
+                                                               JExchange* xch_all) {
   __shared__ JShared sh;
   __shared__ uint4 blk[kInitLdsBlocks];                  // per Morton block: box (3 pairs), max closest
   __shared__ uint4 sup[kInitLdsSuper];                   // per Morton super-block: box, max of the blocks' max (may lag high)
@@ -820,17 +858,24 @@ __global__ __launch_bounds__(kJThreads) void mbk_init2_kernel(const uint32_t* __
   __shared__ uint32_t items[kJMaxItems];
   __shared__ uint32_t hits[kTMaxI * kInitLdsSuper];      // (candidate, super-block) pairs whose box test passed
   __shared__ int s_touch[2 * kJTouch];
-  const MbkP P = probs[blockIdx.x];
+  const int prob = kSh ? (int)blockIdx.x / nshard : (int)blockIdx.x;
+  const int me = kSh ? (int)blockIdx.x % nshard : 0;
+  const MbkP P = probs[prob];
   const int tid = threadIdx.x, lane = tid & 63;
   const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);     // wave-uniform BY CONSTRUCTION: loops and branches on it stay scalar
-  const int n = (int)P.init_n, k = (int)P.k, T = P.T;
+  const int n_all = (int)P.init_n, k = (int)P.k, T = P.T;
+  // shard `me` owns the draws [lo, lo + n): whole draw super-blocks, so that its sums are the global ones restricted to it
+  const int shard_d = kSh ? ((((n_all + nshard - 1) / nshard) + 1023) & ~1023) : n_all;
+  const int lo = kSh ? me * shard_d : 0;
+  const int n = kSh ? min(shard_d, n_all - lo) : n_all;          // (the launcher makes sure every shard is non-empty)
   const int nb = (n + 63) >> 6, np = nb << 6, nsb = (nb + 15) >> 4;
   uint2* samp = reinterpret_cast<uint2*>(scratch + scratch_off[blockIdx.x]);
   uint2* dsamp = samp + np;
   int32_t* cho = chosen + P.koff;
+  JExchange* xch = kSh ? xch_all + prob : nullptr;
   // ---- gather the sample (both orders), first centre, tables ---------------------------------------------
   const uint32_t kf = keys[P.off + init_idx[P.init_off + P.first]];
-  {
+  if (!kSh) {
     const int last_d = perm[P.init_off + n - 1];
     for (int i = tid; i < np; i += kJThreads) {
       const int d = i < n ? perm[P.init_off + i] : i;     // padding: the last Morton sample again, closest = 0, unused draw slots
@@ -838,6 +883,40 @@ __global__ __launch_bounds__(kJThreads) void mbk_init2_kernel(const uint32_t* __
       const unsigned cl = i < n ? (unsigned)dist2_keys(kk, kf) : 0u;
       samp[i] = jpack(kk, (int)cl - (int)norm2_key(kk), (uint32_t)d);
       dsamp[d] = make_uint2(kk, cl);
+    }
+  } else {
+    // the problem's Morton order, filtered to this shard's draws (a stable compaction keeps the order)
+    __shared__ int s_cnt[kJWaves + 1];
+    int base = 0;
+    uint32_t last_key = 0;
+    for (int i0 = 0; i0 < n_all; i0 += kJThreads) {
+      const int i = i0 + tid;
+      const int d = i < n_all ? perm[P.init_off + i] : -1;
+      const bool in = d >= lo && d < lo + n;
+      const unsigned long long mb = __ballot(in);
+      if (lane == 0) s_cnt[wave] = __popcll(mb);
+      __syncthreads();
+      int before = 0, total = 0;
+      for (int w = 0; w < kJWaves; ++w) {
+        const int cw = s_cnt[w];
+        before += w < wave ? cw : 0;
+        total += cw;
+      }
+      if (in) {
+        const uint32_t kk = keys[P.off + init_idx[P.init_off + d]];
+        const unsigned cl = (unsigned)dist2_keys(kk, kf);
+        const int m = base + before + __popcll(mb & ((1ull << lane) - 1ull));
+        samp[m] = jpack(kk, (int)cl - (int)norm2_key(kk), (uint32_t)(d - lo));
+        dsamp[d - lo] = make_uint2(kk, cl);
+        if (m == n - 1) s_cnt[kJWaves] = (int)kk;
+      }
+      base += total;
+      __syncthreads();
+    }
+    last_key = (uint32_t)s_cnt[kJWaves];
+    for (int i = n + tid; i < np; i += kJThreads) {       // padding as above
+      samp[i] = jpack(last_key, -(int)norm2_key(last_key), (uint32_t)i);
+      dsamp[i] = make_uint2(last_key, 0u);
     }
   }
   __syncthreads();
@@ -875,7 +954,24 @@ __global__ __launch_bounds__(kJThreads) void mbk_init2_kernel(const uint32_t* __
     psum += sum;
   }
   psum = block_sum<unsigned long long>(psum, sh.red64);
-  if (tid == 0) { cho[0] = P.first; sh.n_touch2[0] = 0; sh.n_touch2[1] = 0; sh.pot = psum; sh.n_items = 0; sh.n_hits = 0; sh.overflow = 0; }
+  if (kSh) {
+    if (tid == 0) { sh.abort = 0; jx_store(&xch->tot[me], kJTagInit, psum); }
+    if (wave == 0) {
+      unsigned long long v = 0;
+      const bool ok = jx_wait(&xch->tot[lane < nshard ? lane : 0], lane < nshard, kJTagInit, &xch->abort, v);
+      if (!ok && lane == 0) { sh.abort = 1; __hip_atomic_store(&xch->abort, 1ull, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); }
+      if (lane < nshard) sh.tot[lane] = v;
+    }
+    __syncthreads();
+    psum = 0;
+    for (int s2 = 0; s2 < nshard; ++s2) psum += sh.tot[s2];
+    if (tid == 0 && me == 0) {
+      const double c0 = (double)key_r(kf), c1 = (double)key_g(kf), c2 = (double)key_b(kf);
+      double* C = centres + P.koff * 4;
+      C[0] = c0; C[1] = c1; C[2] = c2; C[3] = km64_csq(c0, c1, c2);
+    }
+  }
+  if (tid == 0) { if (me == 0) cho[0] = P.first; sh.n_touch2[0] = 0; sh.n_touch2[1] = 0; sh.pot = psum; sh.n_items = 0; sh.n_hits = 0; sh.overflow = 0; }
   if (tid < kTMaxI) sh.delta[tid] = 0;
   if (tid < T && k > 1) sh.R[tid] = (unsigned long long)ceil(rand[P.rand_off + tid] * (double)psum);
   __syncthreads();
@@ -893,6 +989,7 @@ __global__ __launch_bounds__(kJThreads) void mbk_init2_kernel(const uint32_t* __
 #define WEND(ph) do {} while (0)
 #endif
   for (int c = 1; c < k; ++c) {
+    if (kSh && sh.abort) break;                           // (uniform: read behind the barrier that closed the previous pick)
     WBEGIN();
     // the next pick's uniforms are a cold line in HBM: fetch them now, use them at the end of the pick
     double u_next = 0.0;
@@ -911,7 +1008,25 @@ __global__ __launch_bounds__(kJThreads) void mbk_init2_kernel(const uint32_t* __
       int cand = R == 0 ? 0 : n - 1;                      // R = 0: position 0; a target beyond the total (cannot happen): the last
       uint32_t ck = 0;
       bool found = false;
-      if (R != 0) {
+      // sharded: the shard whose range of the global cumulative sum holds the target searches; the others wait for its answer
+      bool searcher = true;
+      unsigned long long Rl = R;
+      if (kSh) {
+        int own = R == 0 ? 0 : nshard - 1;
+        unsigned long long cum = 0, before = 0;
+        bool hit = R == 0;
+        for (int s2 = 0; s2 < nshard; ++s2) {
+          const unsigned long long v = sh.tot[s2];
+          if (!hit && v > 0 && cum < R && R <= cum + v) { own = s2; before = cum; hit = true; }
+          if (!hit && s2 == nshard - 1) before = cum;
+          cum += v;
+        }
+        searcher = own == me;
+        Rl = R - before;
+        if (lane == 0) sh.owner[t] = own;
+      }
+      if (searcher && R != 0) {
+        const unsigned long long R = Rl;                  // (the local target; shadows the global one inside the search)
         unsigned long long carry = 0;
         for (int ch = 0; ch < nch && !found; ++ch) {
           const int sb = ch * 64 + lane;
@@ -947,7 +1062,19 @@ __global__ __launch_bounds__(kJThreads) void mbk_init2_kernel(const uint32_t* __
           carry = readlane64(inc, 63);
         }
       }
-      if (!found) ck = dsamp[cand].x;
+      if (kSh) {
+        if (searcher) {
+          if (!found) ck = dsamp[cand].x;
+          if (lane == 0) jx_store(&xch->cand[c & 1][t], (unsigned)c, (unsigned long long)ck);
+        } else {
+          unsigned long long v = 0;
+          if (!jx_wait(&xch->cand[c & 1][t], true, (unsigned)c, &xch->abort, v) && lane == 0) {
+            sh.abort = 1;
+            __hip_atomic_store(&xch->abort, 1ull, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+          }
+          ck = (uint32_t)v & 0xffffffu;
+        }
+      } else if (!found) ck = dsamp[cand].x;
       const CandP cp = cand_pairs(ck);
       if (lane == 0) {
         sh.cand[t] = cand;
@@ -1103,9 +1230,29 @@ __global__ __launch_bounds__(kJThreads) void mbk_init2_kernel(const uint32_t* __
     __syncthreads();
     STAMP(5);
     WBEGIN();
+    if (kSh) {
+      // every shard's partial improvements: publish mine, collect the others' (wave w collects shard w)
+      if (wave == 0 && lane < T) jx_store(&xch->delta[c & 1][me][lane], (unsigned)c, sh.delta[lane]);
+      if (wave < nshard) {
+        unsigned long long v = lane < T ? sh.delta[lane] : 0ull;
+        if (wave != me) {
+          if (!jx_wait(&xch->delta[c & 1][wave][lane < T ? lane : 0], lane < T, (unsigned)c, &xch->abort, v) && lane == 0) {
+            sh.abort = 1;
+            __hip_atomic_store(&xch->abort, 1ull, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+          }
+        }
+        if (lane < T) sh.gd[wave][lane] = v;
+      }
+      __syncthreads();
+    }
     // ================= phase 4: greedy choice + commit =======================================================
     // largest reduction == smallest potential; the first candidate wins ties
-    const unsigned long long dv = lane < T ? sh.delta[lane] : 0ull;
+    unsigned long long dv = lane < T ? sh.delta[lane] : 0ull;
+    if (kSh) {
+      dv = 0;
+      if (lane < T)
+        for (int s2 = 0; s2 < nshard; ++s2) dv += sh.gd[s2][lane];
+    }
     const unsigned dhi = (unsigned)(dv >> 32), dlo = (unsigned)dv;
     const unsigned mhi = wave_max_u32(dhi);
     const unsigned mlo = wave_max_u32(dhi == mhi ? dlo : 0u);
@@ -1152,7 +1299,16 @@ __global__ __launch_bounds__(kJThreads) void mbk_init2_kernel(const uint32_t* __
         });
       }
     }
-    if (tid == 0) { cho[c] = sh.cand[best]; sh.pot = pot - bd; sh.n_items = 0; sh.n_hits = 0; sh.overflow = 0; sh.n_touch2[(c + 1) & 1] = 0; }
+    if (kSh) {
+      if (tid == 0 && sh.owner[best] == me) {             // the searcher of the winner knows its draw position
+        cho[c] = lo + sh.cand[best];
+        const double c0 = (double)key_r(kbest), c1 = (double)key_g(kbest), c2 = (double)key_b(kbest);
+        double* C = centres + (P.koff + c) * 4;
+        C[0] = c0; C[1] = c1; C[2] = c2; C[3] = km64_csq(c0, c1, c2);
+      }
+      if (tid >= 64 && tid < 64 + nshard) sh.tot[tid - 64] -= sh.gd[tid - 64][best];
+      if (tid == 0) { sh.pot = pot - bd; sh.n_items = 0; sh.n_hits = 0; sh.overflow = 0; sh.n_touch2[(c + 1) & 1] = 0; }
+    } else if (tid == 0) { cho[c] = sh.cand[best]; sh.pot = pot - bd; sh.n_items = 0; sh.n_hits = 0; sh.overflow = 0; sh.n_touch2[(c + 1) & 1] = 0; }
     if (tid < T) sh.R[tid] = (unsigned long long)ceil(u_next * (double)(pot - bd));
     WEND(3);
     STAMP(6);
@@ -1176,6 +1332,11 @@ __global__ __launch_bounds__(kJThreads) void mbk_init2_kernel(const uint32_t* __
   if (lane == 0 && blockIdx.x == gridDim.x - 1)
     for (int i = 0; i < 4; ++i) atomicAdd(&g_wave_stamps[i][wave], _wacc[i]);
 #endif
+  if (kSh) {                                               // (every centre was written by the shard that found it)
+    // a hand-off that never arrived: poison the first centre's norm; rhccq_mbk_steps turns that into state code 4
+    if (tid == 0 && (sh.abort || jx_load(&xch->abort) != 0)) centres[P.koff * 4 + 3] = __longlong_as_double(0x7ff8000000000000ll);
+    return;
+  }
   for (int j = tid; j < k; j += kJThreads) {
     const uint32_t kk = dsamp[cho[j]].x;
     const double c0 = (double)key_r(kk), c1 = (double)key_g(kk), c2 = (double)key_b(kk);
@@ -1208,7 +1369,7 @@ __device__ __forceinline__ int st_slot(int even_slot, long long step) {
 __device__ __forceinline__ bool mbk_stopped(const double* st, long long step, long long n) {
   const double stop_at = st[11];
   const long long bs = n < 1000 ? n : 1000;
-  return (stop_at != 0.0 && (double)step >= stop_at) || st[4] == 3.0 || step >= (100 * n) / bs;
+  return (stop_at != 0.0 && (double)step >= stop_at) || st[4] >= 3.0 || step >= (100 * n) / bs;
 }
 // Batch inertia of step `step` + sklearn _mini_batch_convergence (EWA early stopping), one wave.  The 1 000 terms (fold
 // kernel, against the centres before the update) are added ONE AFTER THE OTHER in batch order, as sklearn's
@@ -1579,7 +1740,7 @@ __device__ __forceinline__ long long draw_batch(const uint32_t* __restrict__ key
 // first batch of every problem (state[10] == 0: not drawn yet)
 __global__ __launch_bounds__(kUpdThreads) void mbk_draw0_kernel(const uint32_t* __restrict__ keys, const MbkP* __restrict__ probs,
                                                                  double* __restrict__ state, const uint32_t* __restrict__ words,
-                                                                 long long n_words, uint32_t* __restrict__ bkeys) {
+                                                                 long long n_words, uint32_t* __restrict__ bkeys, const double* __restrict__ centres) {
   __shared__ int s_out[kBatch];
   __shared__ int s_red[kUpdWaves + 1];
   __shared__ long long s_cursor;
@@ -1587,6 +1748,10 @@ __global__ __launch_bounds__(kUpdThreads) void mbk_draw0_kernel(const uint32_t* 
   double* st = state + p * kStateStride;
   if (st[10] != 0.0 || st[4] != 0.0) return;
   const MbkP P = probs[p];
+  if (centres[P.koff * 4 + 3] != centres[P.koff * 4 + 3]) {   // NaN: the sharded k-means++ chain gave up on a hand-off (code 4)
+    if (threadIdx.x == 0) st[4] = 4.0;
+    return;
+  }
   const long long c = draw_batch(keys, P, words, n_words, (long long)st[kStCursor], bkeys + (size_t)p * kBatch, s_out, s_red, &s_cursor);
   if (threadIdx.x == 0) {
     if (c < 0) st[4] = 3.0;                              // word table exhausted (the host sizes it so that this cannot happen)
@@ -2351,24 +2516,60 @@ int rhccq_mbk_init(rhccq_ctx* ctx, const uint32_t* keys, const rhccq_mbk_problem
     words += 5 * nb * 64 + 5 * nb + 5 * ((nb + 15) / 16) + 8;       // samp, dsamp (uint2 each), mperm, tables
     words = (words + 63) & ~(size_t)63;
   }
-  const size_t head = align256(sizeof(MbkP) * n_prob) + align256(8 * (size_t)n_prob);
-  if (int e = ensure_scratch(ctx, head + words * 4)) return e;
-  char* base = (char*)ctx->scratch;
-  MbkP* dp = (MbkP*)base;
-  long long* dof = (long long*)(base + align256(sizeof(MbkP) * n_prob));
-  uint32_t* dscr = (uint32_t*)(base + head);
-  if (int e = put(ctx, dp, hp, sizeof(MbkP) * n_prob)) return e;
-  if (int e = put(ctx, dof, ho, 8 * (size_t)n_prob)) return e;
-  RHCCQ_HIP(ctx, hipStreamSynchronize(ctx->stream));
   const int lds_blocks = ctx->opt_init_lds_blocks < 0 ? kInitLdsBlocks : ctx->opt_init_lds_blocks;
   const int max_items = ctx->opt_init_max_items < 0 ? kMaxItems : ctx->opt_init_max_items;
   // second-generation chain (8 waves, tables in LDS) whenever every problem's block tables fit; the first generation keeps
   // the tables of larger problems (more than 262 144 init samples) in global memory
   bool lean = ctx->opt_init_kernel != 1;
   for (int i = 0; i < n_prob && lean; ++i) lean = (probs[i].init_n + 63) / 64 <= lds_blocks;
-  if (lean)
-    hipLaunchKernelGGL(mbk_init2_kernel, dim3(n_prob), dim3(kJThreads), 0, ctx->stream, keys, dp, init_idx, perm, rand, centres, chosen, dscr,
-                       dof, max_items < kJMaxItems ? max_items : kJMaxItems);
+  // sharded chain: C workgroups per problem, all resident at once (they wait for each other), so only for a handful of
+  // problems; every shard must own at least one draw super-block and the pick number must fit the 24-bit granule tag
+  // MEASURED (MI355X, k = 30 000, 90 000 init samples): 4.84 us per pick on one workgroup, 7.7-8.0 us on 2, 4 or 8 -- each of
+  // the two exchanges costs ~3 us with a dozen waves of the receiving CU polling (the price of a hand-off sits in the consumer
+  // CU's memory queue), more than the sharded phases save.  Hence opt-in only (RHCCQ_OPT_INIT_SHARDS = 2 / 4 / 8).
+  int nshard = 1;
+  if (lean && ctx->opt_init_shards > 1) {
+    for (int c2 = ctx->opt_init_shards; c2 >= 2 && nshard == 1; c2 >>= 1) {
+      bool ok = (long long)n_prob * c2 <= 64;
+      for (int i = 0; i < n_prob && ok; ++i) {
+        const long long d = ((probs[i].init_n + c2 - 1) / c2 + 1023) & ~1023ll;
+        ok = d * (c2 - 1) < probs[i].init_n && probs[i].k < (1 << 24) - 2 && probs[i].init_n >= 4096ll * c2;
+      }
+      if (ok) nshard = c2;
+    }
+  }
+  const int n_wg = n_prob * nshard;
+  if (nshard > 1) {                                        // one sample area per (problem, shard)
+    stage.resize(sizeof(MbkP) * (size_t)n_prob + 8 * (size_t)n_wg);
+    hp = (MbkP*)stage.data();
+    ho = (long long*)(stage.data() + sizeof(MbkP) * n_prob);
+    words = 0;
+    for (int i = 0; i < n_prob; ++i) {
+      const long long d = ((probs[i].init_n + nshard - 1) / nshard + 1023) & ~1023ll;
+      for (int s2 = 0; s2 < nshard; ++s2) {
+        ho[i * nshard + s2] = (long long)words;
+        words += 4 * (size_t)d + 64;                        // samp, dsamp (uint2 each)
+      }
+    }
+  }
+  const size_t xbytes = nshard > 1 ? align256(sizeof(JExchange) * (size_t)n_prob) : 0;
+  const size_t head = align256(sizeof(MbkP) * n_prob) + align256(8 * (size_t)n_wg) + xbytes;
+  if (int e = ensure_scratch(ctx, head + words * 4)) return e;
+  char* base = (char*)ctx->scratch;
+  MbkP* dp = (MbkP*)base;
+  long long* dof = (long long*)(base + align256(sizeof(MbkP) * n_prob));
+  JExchange* xch = (JExchange*)(base + align256(sizeof(MbkP) * n_prob) + align256(8 * (size_t)n_wg));
+  uint32_t* dscr = (uint32_t*)(base + head);
+  if (int e = put(ctx, dp, hp, sizeof(MbkP) * n_prob)) return e;
+  if (int e = put(ctx, dof, ho, 8 * (size_t)n_wg)) return e;
+  if (nshard > 1) RHCCQ_HIP(ctx, hipMemsetAsync(xch, 0, xbytes, ctx->stream));
+  RHCCQ_HIP(ctx, hipStreamSynchronize(ctx->stream));
+  if (nshard > 1)
+    hipLaunchKernelGGL(mbk_init2_kernel<true>, dim3(n_wg), dim3(kJThreads), 0, ctx->stream, keys, dp, init_idx, perm, rand, centres, chosen, dscr,
+                       dof, max_items < kJMaxItems ? max_items : kJMaxItems, nshard, xch);
+  else if (lean)
+    hipLaunchKernelGGL(mbk_init2_kernel<false>, dim3(n_prob), dim3(kJThreads), 0, ctx->stream, keys, dp, init_idx, perm, rand, centres, chosen, dscr,
+                       dof, max_items < kJMaxItems ? max_items : kJMaxItems, 1, (JExchange*)nullptr);
   else
     hipLaunchKernelGGL(mbk_init_kernel, dim3(n_prob), dim3(kInitThreads), 0, ctx->stream, keys, dp, init_idx, perm, rand, centres, chosen, dscr, dof,
                        lds_blocks, max_items);
@@ -2397,7 +2598,7 @@ int rhccq_mbk_steps(rhccq_ctx* ctx, const uint32_t* keys, const rhccq_mbk_proble
   // problems whose first batch has not been drawn yet (state[10] == 0) draw it now; the others return at once
   if (step0 == 0)
     hipLaunchKernelGGL(mbk_draw0_kernel, dim3(n_prob), dim3(kUpdThreads), 0, ctx->stream, keys, v.probs, state, words, (long long)n_words,
-                       v.bkeys[0]);
+                       v.bkeys[0], centres);
   for (int s = 0; s < n_steps; ++s) {
     const long long step = step0 + s;
     const uint32_t* bk = v.bkeys[step & 1];

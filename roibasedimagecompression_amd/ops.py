@@ -178,7 +178,7 @@ class Rhccq:
         self.mtw = MtWords()
         self._mtw_dev = None
 
-    OPT_INIT_LDS_BLOCKS, OPT_INIT_MAX_ITEMS, OPT_INIT_KERNEL = 1, 2, 3
+    OPT_INIT_LDS_BLOCKS, OPT_INIT_MAX_ITEMS, OPT_INIT_KERNEL, OPT_INIT_SHARDS = 1, 2, 3, 4
 
     def _bind_stream(self):
         """kernels follow torch's current stream (see _StreamBoundLib)"""
@@ -599,6 +599,8 @@ class Rhccq:
             cur_max = int(max(st[:, 9].max(), st[:, 14].max()))
             if (st[:, 4] == 3).any():
                 raise RhccqError("mini-batch steps ran past the end of the MT19937 word table (internal sizing error)")
+            if (st[:, 4] == 4).any():
+                raise RhccqError("the sharded k-means++ chain gave up waiting for a partner workgroup (RHCCQ_OPT_INIT_SHARDS = 1 avoids the hand-offs)")
             running = (st[:, 11] == 0) & (st[:, 5] < limit)
         labels = self.empty((int(offs[-1]),), torch.int32)
         self._check(self.lib.rhccq_mbk_assign(self.ctx, self._p(keys), probs, n_prob, self._p(centres), self._p(work), wbytes,

@@ -238,6 +238,32 @@ def test_minibatch_init_chain_many_cases(rh, O, path):
         rh.set_option(rh.OPT_INIT_KERNEL, 0)
 
 
+@pytest.mark.parametrize("shards", [2, 8])
+def test_minibatch_init_chain_sharded(rh, O, shards):
+    """The sharded k-means++ chain (mbk_init2_kernel<true>): C workgroups per problem, each with its own draw range and Morton
+    index, candidate colours and partial improvements exchanged through tagged 8-byte granules.  Exact integers everywhere, so
+    every pick must equal the one-workgroup chain's = sklearn's.  Opt-in (measured slower than one workgroup); one launch
+    with two problems (the second one too small for 8 shards: the launcher falls back to 2 for both) and the pipelined
+    per-problem launches."""
+    rng = np.random.default_rng(321)
+    cases = []
+    for n, hi, k in ((140000, 256, 11000), (90000, 200, 3000)):
+        P = np.unique(rng.integers(0, hi, (n, 3)).astype(np.uint8), axis=0)
+        cases.append((P, k))
+    rh.set_option(rh.OPT_INIT_SHARDS, shards)
+    try:
+        for lanes in (1, None):
+            labs, info = rh.minibatch_kmeans([O.pack_rgb(P) for P, _ in cases], [k for _, k in cases], return_info=True, lanes=lanes)
+            for i, (P, k) in enumerate(cases):
+                want, _ = O.kmeanspp_picks_native(P, k)
+                got = info["chosen"][info["koff"][i]:info["koff"][i + 1]]
+                assert np.array_equal(got, want), (shards, lanes, i, int(np.argmax(got != want)))
+                cen = info["init_centres"][info["koff"][i]:info["koff"][i + 1]] if "init_centres" in info else None
+                assert cen is None or np.array_equal(cen[:, :3], P[info["init_idx"][i]][want].astype(np.float64))
+    finally:
+        rh.set_option(rh.OPT_INIT_SHARDS, 1)
+
+
 def _init_chain_cases(rh, O):
     import math
     rng = np.random.default_rng(123)
