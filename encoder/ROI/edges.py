@@ -1,11 +1,7 @@
-"""Placeholder for a stage UPSTREAM/DOWNSTREAM of the MI355X hot path (SURVEY.md 8f "next" rows).  When the reference
-checkout sits behind this repository on sys.path its own module of this name is executed instead (roibasedimagecompression_amd/_shim.py);
-otherwise the names exist so that the reference's import lines resolve and raise when called."""
-from roibasedimagecompression_amd._shim import defer_to_downstream, upstream
-
-if defer_to_downstream(__name__, __file__) is None:
-    compute_local_density = upstream("compute_local_density")
-    suggest_automatic_threshold = upstream("suggest_automatic_threshold")
-    get_edge_map = upstream("get_edge_map")
-    get_edge_map_fast = upstream("get_edge_map_fast")
-    find_best_edges_by_quality = upstream("find_best_edges_by_quality")
+"""Drop-in for the reference's encoder/ROI/edges.py: the whole module -- get_edge_map (20 adaptive threshold pairs scored on their
+Canny edge maps + the final Canny on the colour image), compute_local_density, suggest_automatic_threshold and the helpers -- runs
+on the MI355X (roibasedimagecompression_amd.api.edges, csrc/edges.hip + csrc/ccl.hip).  PARITY UNPINNED: OpenCV's cvtColor / Sobel /
+Otsu / Canny are restated from their published integer implementations (no OpenCV in the build container)."""
+from roibasedimagecompression_amd.api.edges import (compute_adaptive_canny_thresholds, compute_fast_canny_thresholds,  # noqa: F401
+                                                    compute_local_density, evaluate_edge_quality, find_best_edges_by_quality,
+                                                    get_edge_map, get_edge_map_fast, suggest_automatic_threshold)

@@ -1,7 +1,4 @@
-"""Placeholder for a stage UPSTREAM/DOWNSTREAM of the MI355X hot path (SURVEY.md 8f "next" rows).  When the reference
-checkout sits behind this repository on sys.path its own module of this name is executed instead (roibasedimagecompression_amd/_shim.py);
-otherwise the names exist so that the reference's import lines resolve and raise when called."""
-from roibasedimagecompression_amd._shim import defer_to_downstream, upstream
-
-if defer_to_downstream(__name__, __file__) is None:
-    remove_thin_structures_optimized = upstream("remove_thin_structures_optimized")
+"""Drop-in for the reference's encoder/ROI/thin_regions2.py: the whole module runs on the MI355X
+(roibasedimagecompression_amd.api.roi_chain: connected components, chamfer distance transform, box densities; parity unpinned)."""
+from roibasedimagecompression_amd.api.roi_chain import (identify_thin_regions_fast, identify_thin_regions_ultrafast,  # noqa: F401
+                                                        remove_thin_structures_optimized)

@@ -301,6 +301,52 @@ int rhccq_ccl_select(rhccq_ctx* ctx, const int32_t* labels, const uint8_t* lut, 
 int rhccq_roi_buffer(rhccq_ctx* ctx, const uint8_t* region_map, const uint8_t* rgb, int32_t H, int32_t W, int32_t buffer_size,
                      uint8_t* roi_mask, uint8_t* nonroi_mask, uint8_t* roi_image, uint8_t* nonroi_image);
 
+/* ---- ROI stage, edge front end (encoder/ROI/edges.py:35-71,173-195: get_edge_map = 20 adaptive threshold pairs scored on a
+ * Canny edge map each + the final Canny; compute_local_density).  PARITY UNPINNED (OpenCV absent from the build container):
+ * integer restatements of cvtColor(RGB2GRAY), Sobel 3x3, Canny (L1 gradient, aperture 3) -- csrc/edges.hip.
+ * rhccq_edges_gray: gray (device u8[n]) + its 256-bin histogram (device int32[256]: Otsu's threshold on the host).
+ * rhccq_edges_grad_hist: histogram (device int32[rhccq_edges_m2_bins()]) of gx^2 + gy^2, Sobel 3x3 with BORDER_REFLECT_101.
+ * rhccq_canny_nms: img (device u8[H][W][channels], 1 or 3) -> nm (device u16[H][W]): Canny's L1 gradient magnitude where the
+ *   pixel is a local maximum along its gradient direction, 0 elsewhere (threshold independent); mag_tmp u16[H*W], dxy_tmp int32[H*W].
+ * rhccq_edges_above: mask[p] = nm[p] > low.
+ * rhccq_label_reduce: red (device u64[n_labels + 1][3]) = per label {max of val16, sum of val8, sum of val8^2} (either plane may be NULL: zeros).
+ *   With rhccq_ccl on the mask this is Canny's hysteresis: a component is an edge iff its max exceeds `high`.
+ * rhccq_box_count: out (device u16[H][W]) = number of non-zero pixels in the kernel_size x kernel_size window (odd, <= 31),
+ *   BORDER_REFLECT_101: the integer content of compute_local_density's normalised box filter. */
+int64_t rhccq_edges_m2_bins(void);
+int rhccq_edges_gray(rhccq_ctx* ctx, const uint8_t* rgb, int64_t n_pixels, uint8_t* gray, int32_t* hist256);
+int rhccq_edges_grad_hist(rhccq_ctx* ctx, const uint8_t* gray, int32_t H, int32_t W, int32_t* hist_m2);
+int rhccq_canny_nms(rhccq_ctx* ctx, const uint8_t* img, int32_t H, int32_t W, int32_t channels, uint16_t* mag_tmp, int32_t* dxy_tmp,
+                    uint16_t* nm);
+int rhccq_edges_above(rhccq_ctx* ctx, const uint16_t* nm, int64_t n_pixels, int32_t low, uint8_t* mask);
+int rhccq_label_reduce(rhccq_ctx* ctx, const int32_t* labels, const uint16_t* val16, const uint8_t* val8, int64_t n_pixels,
+                       int32_t n_labels, uint64_t* red);
+int rhccq_box_count(rhccq_ctx* ctx, const uint8_t* mask, int32_t H, int32_t W, int32_t kernel_size, uint16_t* out);
+
+/* ---- ROI stage, clean-up chain (encoder/ROI/{roi,small_regions,small_gaps,thin_regions2}.py): binary-mask operators.  PARITY
+ * UNPINNED (OpenCV absent from the build container); masks are device u8 planes, set = non-zero, outputs 0 / 255.
+ * rhccq_morph_dilate: dilation by a structuring element given as one half-width per row dy = -radius .. radius (-1 = empty row;
+ *   radius <= 15), nothing set outside the image (cv2.dilate's default border); invert_in / invert_out = the erosion by the same
+ *   symmetric element with cv2.erode's border rule (outside = set).  cv2.morphologyEx(MORPH_CLOSE) = dilate, then erode.
+ * rhccq_mask_op: out = a | b (op 0), a & b (1), a & ~b (2), ~a (3).
+ * rhccq_gap_bridge = bridge_small_gaps_fast (small_gaps.py:221-271): an unset pixel whose window count (rhccq_box_count) is at
+ *   least min_count is set when both opposite rays of one of the four direction pairs meet a set pixel within `reach` steps.
+ * rhccq_dist_chamfer = cv2.distanceTransform(mask, DIST_L2, 3) in OpenCV's fixed point (16 fractional bits; hz_tmp: u16[H*W]).
+ * rhccq_binary_sobel: m2 (device u8[H*W]) = gx^2 + gy^2 of the 3x3 Sobel of the 0/1 image (BORDER_REFLECT_101), max_out = its
+ *   maximum (device int32); rhccq_lut_u8: out[p] = lut256[in[p]].
+ * rhccq_label_sum: sums (device u64[n_labels + 1]) = per label (background 0 included) the sum of a u16 (value_bytes 2) or a
+ *   non-negative int32 (value_bytes 4) plane. */
+int rhccq_morph_dilate(rhccq_ctx* ctx, const uint8_t* in, int32_t H, int32_t W, int32_t radius, const int32_t* half_widths /* host */,
+                       int32_t invert_in, int32_t invert_out, uint8_t* out);
+int rhccq_mask_op(rhccq_ctx* ctx, const uint8_t* a, const uint8_t* b, int64_t n, int32_t op, uint8_t* out);
+int rhccq_gap_bridge(rhccq_ctx* ctx, const uint8_t* in, const uint16_t* counts, int32_t H, int32_t W, int32_t min_count, int32_t reach,
+                     uint8_t* out);
+int rhccq_dist_chamfer(rhccq_ctx* ctx, const uint8_t* mask, int32_t H, int32_t W, uint16_t* hz_tmp, int32_t* dist);
+int rhccq_binary_sobel(rhccq_ctx* ctx, const uint8_t* mask, int32_t H, int32_t W, uint8_t* m2, int32_t* max_out);
+int rhccq_lut_u8(rhccq_ctx* ctx, const uint8_t* in, const uint8_t* lut256, int64_t n, uint8_t* out);
+int rhccq_label_sum(rhccq_ctx* ctx, const int32_t* labels, const void* values, int32_t value_bytes, int64_t n_pixels, int32_t n_labels,
+                    uint64_t* sums);
+
 /* ---- EXTENSION (no reference counterpart; named by BASELINE.json's north_star only): pixel-space DBSCAN ----
  * Features (x, y, L, a, b); q is a neighbour of p when dx^2 + dy^2 <= radius^2 (radius 0..4) and
  * dL^2 + da^2 + db^2 + spatial_weight^2 (dx^2 + dy^2) <= eps^2 (float32, operation order fixed in

@@ -1331,6 +1331,449 @@ def extract_roi_nonroi(original_image, region_map, buffer_size=3):
 
 
 # --------------------------------------------------------------------------------------
+# SURVEY 8f-1, edge front end of the ROI stage (encoder/ROI/edges.py).  PARITY UNPINNED: OpenCV is absent from the build
+# container; cvtColor / Sobel / threshold(OTSU) / Canny / filter2D are restated from OpenCV's published implementation (all
+# integer arithmetic but the box filter); everything the reference does in numpy is done in numpy here too.
+# --------------------------------------------------------------------------------------
+def cv_rgb2gray(rgb_u8):
+    """cvtColor(RGB2GRAY) on 8-bit data: fixed point, 14 fractional bits"""
+    r, g, b = (rgb_u8[..., i].astype(np.int64) for i in range(3))
+    return ((4899 * r + 9617 * g + 1868 * b + 8192) >> 14).astype(np.uint8)
+
+
+def cv_sobel3(plane, border):
+    """3x3 Sobel (dx, dy) of an integer plane as int64; border 'reflect' = BORDER_REFLECT_101 (cv2.Sobel's default),
+    'edge' = BORDER_REPLICATE (what cv2.Canny uses)"""
+    p = np.pad(plane.astype(np.int64), 1, mode=border)
+    a, b, c = p[:-2, :-2], p[:-2, 1:-1], p[:-2, 2:]
+    d, f = p[1:-1, :-2], p[1:-1, 2:]
+    g, h, i = p[2:, :-2], p[2:, 1:-1], p[2:, 2:]
+    return (c + 2 * f + i) - (a + 2 * d + g), (g + 2 * h + i) - (a + 2 * b + c)
+
+
+def cv_otsu(gray_u8):
+    """threshold(THRESH_OTSU)'s threshold value (getThreshVal_Otsu_8u)"""
+    h = np.bincount(gray_u8.ravel(), minlength=256).astype(np.float64)
+    scale = 1.0 / gray_u8.size
+    mu = float((np.arange(256) * h).sum()) * scale
+    mu1 = q1 = 0.0
+    max_sigma = max_val = 0.0
+    eps = float(np.finfo(np.float32).eps)
+    for i in range(256):
+        p_i = h[i] * scale
+        mu1 *= q1
+        q1 += p_i
+        q2 = 1.0 - q1
+        if min(q1, q2) < eps or max(q1, q2) > 1.0 - eps:
+            continue
+        mu1 = (mu1 + i * p_i) / q1
+        mu2 = (mu - q1 * mu1) / q2
+        sigma = q1 * q2 * (mu1 - mu2) * (mu1 - mu2)
+        if sigma > max_sigma:
+            max_sigma, max_val = sigma, float(i)
+    return max_val
+
+
+def cv_canny_nms(img_u8):
+    """the threshold-independent half of cv2.Canny(img, low, high) (aperture 3, L1 gradient): magnitude |dx| + |dy| of the
+    channel with the largest one (first on ties) where the pixel is a local maximum along its gradient direction, else 0"""
+    planes = [img_u8] if img_u8.ndim == 2 else [img_u8[..., c] for c in range(img_u8.shape[2])]
+    grads = [cv_sobel3(pl, "edge") for pl in planes]
+    mags = np.stack([np.abs(gx) + np.abs(gy) for gx, gy in grads])
+    best = np.argmax(mags, axis=0)                                   # first maximum
+    mag = np.take_along_axis(mags, best[None], 0)[0]
+    dx = np.take_along_axis(np.stack([g[0] for g in grads]), best[None], 0)[0]
+    dy = np.take_along_axis(np.stack([g[1] for g in grads]), best[None], 0)[0]
+    m = np.pad(mag, 1)                                               # magnitudes outside the image: 0
+    H, W = mag.shape
+    c = m[1:-1, 1:-1]
+    ax, ay = np.abs(dx), np.abs(dy) << 15
+    tg22x = ax * 13573
+    tg67x = tg22x + (ax << 16)
+    horiz = ay < tg22x
+    vert = ~horiz & (ay > tg67x)
+    s = np.where((dx ^ dy) < 0, -1, 1)
+    yy, xx = np.mgrid[1:H + 1, 1:W + 1]
+    is_max = np.where(horiz, (c > m[1:-1, :-2]) & (c >= m[1:-1, 2:]),
+                      np.where(vert, (c > m[:-2, 1:-1]) & (c >= m[2:, 1:-1]), (c > m[yy - 1, xx - s]) & (c > m[yy + 1, xx + s])))
+    return np.where(is_max & (mag > 0), mag, 0).astype(np.uint16)
+
+
+def cv_canny(img_u8, low, high, nm=None):
+    """cv2.Canny(img, low, high): hysteresis = the 8-connected components of {nm > low} that hold a pixel with nm > high"""
+    from scipy import ndimage
+    if nm is None:
+        nm = cv_canny_nms(img_u8)
+    low, high = math.floor(low), math.floor(high)
+    if low > high:
+        low, high = high, low
+    lab, n = ndimage.label(nm > low, structure=np.ones((3, 3)))
+    strong = np.zeros(n + 1, bool)
+    strong[np.unique(lab[nm > high])] = True
+    strong[0] = False
+    return np.where(strong[lab], 255, 0).astype(np.uint8)
+
+
+def adaptive_canny_thresholds(gray, method="otsu", sensitivity=1.0):
+    """edges.py:88-169"""
+    def grad_mag():
+        gx, gy = cv_sobel3(gray, "reflect")
+        return np.sqrt(gx.astype(np.float64) ** 2 + gy.astype(np.float64) ** 2)
+    if method == "otsu":
+        o = cv_otsu(gray)
+        lo, hi = max(10, int(o * 0.5 * sensitivity)), min(255, int(o * 1.5 * sensitivity))
+    elif method == "percentile":
+        g = grad_mag()
+        nz = g[g > 0]
+        if len(nz) > 0:
+            lp, hp = np.percentile(nz, 70) * sensitivity, np.percentile(nz, 90) * sensitivity
+        else:
+            lp, hp = 50 * sensitivity, 150 * sensitivity
+        lo, hi = max(10, int(lp)), min(255, int(hp))
+    elif method == "gradient":
+        g = grad_mag()
+        mean, std = np.mean(g), np.std(g)
+        lo, hi = max(10, int((mean - 0.5 * std) * sensitivity)), min(255, int((mean + 0.5 * std) * sensitivity))
+    elif method == "hybrid":
+        o = cv_otsu(gray)
+        mean = np.mean(grad_mag())
+        lo = max(10, int((o * 0.5 + mean * 0.5) * sensitivity))
+        hi = min(255, int((o * 1.5 + mean * 1.0) * sensitivity))
+    else:
+        lo, hi = 50, 150
+    lo = max(10, min(200, lo))
+    hi = max(lo + 10, min(255, hi))
+    return lo, hi
+
+
+def edge_quality(edges, gray):
+    """edges.py:73-86: mean size of the 8-connected edge components x standard deviation of the gray values on the edges"""
+    from scipy import ndimage
+    lab, n = ndimage.label(edges > 0, structure=np.ones((3, 3)))
+    sizes = np.bincount(lab.ravel())
+    with np.errstate(all="ignore"):
+        avg = np.mean(sizes[1:]) if n else float("nan")
+    vals = gray[edges > 0]
+    contrast = np.std(vals) if len(vals) > 0 else 0
+    return avg * contrast
+
+
+def find_best_edges_by_quality(image_rgb):
+    """edges.py:40-71 -> (best_edges, best_low, best_high, best_method)"""
+    gray = cv_rgb2gray(image_rgb)
+    nm = cv_canny_nms(gray)
+    best = (-1, None, None, None, None)
+    for method in ("otsu", "percentile", "gradient", "hybrid"):
+        for sens in (0.5, 0.7, 1.0, 1.3, 1.5):
+            lo, hi = adaptive_canny_thresholds(gray, method, sens)
+            edges = cv_canny(gray, lo, hi, nm)
+            score = edge_quality(edges, gray)
+            if score > best[0]:
+                best = (score, edges, lo, hi, method)
+    if best[1] is None:
+        raise UnboundLocalError("no threshold pair produced an edge (the reference fails on its unset best_low too)")
+    return best[1], best[2], best[3], best[4]
+
+
+def get_edge_map(image_rgb):
+    """edges.py:35-38: the winning thresholds applied to the COLOUR image"""
+    _, lo, hi, _ = find_best_edges_by_quality(image_rgb)
+    return cv_canny(image_rgb, lo, hi)
+
+
+def box_counts(binary_map, kernel_size):
+    """number of non-zero pixels in the k x k window around every pixel, BORDER_REFLECT_101"""
+    nz = np.pad(np.asarray(binary_map) != 0, kernel_size // 2, mode="reflect").astype(np.int64)
+    H, W = np.shape(binary_map)
+    cnt = np.zeros((H, W), np.int64)
+    for dy in range(kernel_size):
+        for dx in range(kernel_size):
+            cnt += nz[dy:dy + H, dx:dx + W]
+    return cnt
+
+
+def local_density(binary_map, kernel_size=15):
+    """edges.py:173-195: filter2D(float32 map, normalised box kernel), BORDER_REFLECT_101.  Kernels up to 11 x 11 run through
+    OpenCV's direct filter: a float32 accumulator over the taps in row-major order (restated literally); larger kernels go through
+    its DFT path, whose rounding noise (~1e-7) has no closed form: float32(count) * float32(1 / k^2) here."""
+    bm = np.asarray(binary_map)
+    if bm.max() > 1:
+        bm = bm / 255.0
+    kernel = np.ones((kernel_size, kernel_size), np.float32)
+    kernel /= kernel.sum()
+    H, W = bm.shape
+    if kernel_size * kernel_size < 130:
+        src = np.pad(bm.astype(np.float32), kernel_size // 2, mode="reflect")
+        acc = np.zeros((H, W), np.float32)
+        for dy in range(kernel_size):
+            for dx in range(kernel_size):
+                acc = (acc + kernel[dy, dx] * src[dy:dy + H, dx:dx + W]).astype(np.float32)
+        return acc
+    return box_counts(bm, kernel_size).astype(np.float32) * kernel[0, 0]
+
+
+def region_mean_density(labels, num, binary_map, kernel_size):
+    """per label the mean box density over its pixels, DFT-path kernel sizes: (exact sum of the window counts) * float32(1 / k^2) / area
+    (the reference averages the float32 map in float64: the same number up to the last bits)"""
+    assert kernel_size * kernel_size >= 130
+    term = float((np.ones((kernel_size, kernel_size), np.float32) / np.float32(kernel_size * kernel_size))[0, 0])
+    counts = np.bincount(labels.ravel(), minlength=num)
+    sums = np.bincount(labels.ravel(), weights=box_counts(binary_map, kernel_size).ravel(), minlength=num)
+    out = np.zeros(num)
+    out[counts > 0] = sums[counts > 0] * term / counts[counts > 0]
+    return out
+
+
+def suggest_automatic_threshold(edge_density_map, edge_map, method="mean"):
+    """edges.py:4-32"""
+    vals = edge_density_map[edge_map > 0]
+    if len(vals) == 0:
+        return 0.1
+    if method == "median":
+        return np.median(vals)
+    if method == "percentile":
+        return np.percentile(vals, 70)
+    return np.mean(vals)
+
+
+# --------------------------------------------------------------------------------------
+# SURVEY 8f-1, clean-up chain of the ROI stage (encoder/ROI/{roi,small_regions,small_gaps,thin_regions2}.py).  PARITY UNPINNED:
+# cv2.morphologyEx / dilate / getStructuringElement / distanceTransform / connectedComponentsWithStats / filter2D restated
+# (scipy.ndimage for the morphology, literal raster passes for the chamfer distance); the numpy logic follows the reference.
+# --------------------------------------------------------------------------------------
+def cv_ellipse_half_widths(ksize):
+    """getStructuringElement(MORPH_ELLIPSE, (ksize, ksize)): per row the half-width of the set run around the centre column"""
+    r = c = ksize // 2
+    inv_r2 = 1.0 / (r * r) if r else 0.0
+    out = []
+    for i in range(ksize):
+        dy = i - r
+        dx = int(np.rint(c * math.sqrt((r * r - dy * dy) * inv_r2)))          # saturate_cast<int>: round half to even
+        out.append(min(dx, c))
+    return out
+
+
+def _footprint(half_widths):
+    k = len(half_widths)
+    fp = np.zeros((k, k), bool)
+    for i, hw in enumerate(half_widths):
+        if hw >= 0:
+            fp[i, k // 2 - hw:k // 2 + hw + 1] = True
+    return fp
+
+
+def cv_dilate(mask, half_widths):
+    from scipy import ndimage
+    return ndimage.binary_dilation(np.asarray(mask) != 0, structure=_footprint(half_widths), border_value=0)
+
+
+def cv_erode(mask, half_widths):
+    from scipy import ndimage
+    return ndimage.binary_erosion(np.asarray(mask) != 0, structure=_footprint(half_widths), border_value=1)
+
+
+def cv_close(mask, half_widths):
+    return cv_erode(cv_dilate(mask, half_widths), half_widths)
+
+
+def cv_dist_chamfer3(mask):
+    """distanceTransform(mask, DIST_L2, 3) in OpenCV's fixed point (a = round(0.955 * 2^16), b = round(1.3693 * 2^16)): the
+    two raster passes of distanceTransform_3x3, literally (int64; the float32 result is value / 65536)"""
+    m = np.asarray(mask) != 0
+    H, W = m.shape
+    a, b, big = 62587, 89738, (2 ** 31 - 1) >> 2
+    t = np.full((H + 2, W + 2), big, np.int64)
+    for y in range(1, H + 1):
+        for x in range(1, W + 1):
+            if not m[y - 1, x - 1]:
+                t[y, x] = 0
+            else:
+                t[y, x] = min(t[y - 1, x - 1] + b, t[y - 1, x] + a, t[y - 1, x + 1] + b, t[y, x - 1] + a, big * 2)
+    for y in range(H, 0, -1):
+        for x in range(W, 0, -1):
+            v = t[y, x]
+            if v > a:
+                v = min(v, t[y + 1, x + 1] + b, t[y + 1, x] + a, t[y + 1, x - 1] + b, t[y, x + 1] + a)
+            t[y, x] = v
+    return np.minimum(t[1:-1, 1:-1], big)
+
+
+def _density_count_threshold(kernel_size, threshold, dtype):
+    """smallest window count whose density (local_density's value for that count) exceeds `threshold` compared in `dtype`"""
+    k2 = kernel_size * kernel_size
+    term = (np.ones((kernel_size, kernel_size), np.float32) / np.float32(k2))[0, 0]
+    if k2 < 130:
+        table = np.zeros(k2 + 1, np.float32)
+        for m in range(1, k2 + 1):
+            table[m] = np.float32(table[m - 1] + term)
+    else:
+        table = (np.arange(k2 + 1, dtype=np.float32) * term).astype(np.float32)
+    thr = dtype(threshold)
+    above = np.flatnonzero(table.astype(dtype) > thr)
+    return int(above[0]) if len(above) else k2 + 1, table
+
+
+def identify_thin_regions(binary_image, min_region_size=10, thinness_threshold=0.3):
+    """thin_regions2.py:158-242"""
+    num, labels, stats = cv_connected_components_with_stats(binary_image, 8)
+    if num <= 1:
+        return np.zeros(np.shape(binary_image), bool)
+    dist = cv_dist_chamfer3(binary_image)
+    sums = np.bincount(labels.ravel(), weights=dist.ravel() / 65536.0, minlength=num)
+    counts = np.bincount(labels.ravel(), minlength=num)
+    avg = np.zeros(num)
+    avg[counts > 0] = sums[counts > 0] / counts[counts > 0]
+    max_dims = np.maximum(stats[1:, 2], stats[1:, 3])
+    norm = np.zeros(num - 1)
+    ok = max_dims > 0
+    norm[ok] = avg[1:][ok] * 2 / max_dims[ok]
+    is_thin = ((1.0 - norm) > thinness_threshold) & (stats[1:, 4] >= min_region_size)
+    return np.isin(labels, np.flatnonzero(is_thin) + 1)
+
+
+def remove_thin_structures(binary_image, density_threshold=0.2, thinness_threshold=0.3, window_size=25, min_region_size=10, connectivity=8):
+    """thin_regions2.py:14-99 (the thin-region test runs with ITS OWN defaults there: min_region_size 10, thinness 0.3)"""
+    binary_image = np.asarray(binary_image)
+    if np.sum(binary_image > 0) == 0:
+        return binary_image
+    num, labels, _ = cv_connected_components_with_stats(binary_image, connectivity)
+    thin = identify_thin_regions(binary_image)
+    thin_ids = np.unique(labels[thin])
+    dens = region_mean_density(labels, num, binary_image, window_size).astype(np.float32)
+    remove = thin_ids[dens[thin_ids] < density_threshold]
+    out = binary_image.copy()
+    out[np.isin(labels, remove)] = 0
+    return out
+
+
+def _remove_small_density_aware(binary_image, min_size, density_source, window_size, density_threshold):
+    """roi.py:1025-1093 with the return the reference's function forgets (it falls off its end after building cleaned_image)"""
+    num, labels, stats = cv_connected_components_with_stats(binary_image == 255, 8)
+    if num <= 1:
+        return binary_image.copy()
+    dens = region_mean_density(labels, num, density_source, window_size)
+    ids = np.arange(1, num)[(stats[1:, 4] < min_size) & (dens[1:] < density_threshold)]
+    out = binary_image.copy()
+    out[np.isin(labels, ids)] = 0
+    return out
+
+
+def remove_small_noise_regions(binary_image, min_size=5, density_threshold=0.2, window_size=15):
+    """roi.py:925-968"""
+    binary_image = np.asarray(binary_image)
+    white = _remove_small_density_aware(binary_image, min_size, binary_image, window_size, density_threshold)
+    black = _remove_small_density_aware(255 - white, min_size, binary_image, window_size, density_threshold)   # (the ORIGINAL image's density)
+    return 255 - black
+
+
+def connect_by_closing(binary_image, connection_distance, min_region_size=None):
+    """small_regions.py:175-194"""
+    return np.where(cv_close(binary_image, cv_ellipse_half_widths(connection_distance * 2 + 1)), 255, 0).astype(np.uint8)
+
+
+def bridge_small_gaps(binary_image, max_gap=3, density_threshold=0.3, local_window=5, regional_window=25):
+    """small_gaps.py:221-319: the one-directional kernels reach min(max_gap, local_window) pixels; their filter2D response is
+    positive exactly when a set pixel lies on the ray (BORDER_REFLECT_101); the DFT path's rounding noise around 0 is not restated"""
+    b = np.asarray(binary_image)
+    out = b.copy()
+    cand = (b == 0) & (local_density(b, regional_window) > density_threshold)
+    if not cand.any():
+        return out
+    reach = min(max_gap, local_window)
+    H, W = b.shape
+    src = np.pad(b != 0, reach, mode="reflect")
+
+    def ray(dx, dy):
+        acc = np.zeros((H, W), bool)
+        for t in range(1, reach + 1):
+            acc |= src[reach + dy * t:reach + dy * t + H, reach + dx * t:reach + dx * t + W]
+        return acc
+    gaps = np.zeros((H, W), bool)
+    for (ax, ay), (bx, by) in (((-1, 0), (1, 0)), ((0, -1), (0, 1)), ((-1, -1), (1, 1)), ((-1, 1), (1, -1))):
+        gaps |= cand & ray(ax, ay) & ray(bx, by)
+    out[gaps] = 255
+    return out
+
+
+def detect_meaningful_borders(binary_image, sensitivity=0.7):
+    """roi.py:784-822"""
+    img = np.asarray(binary_image).astype(np.float32) / 255.0
+    gx, gy = cv_sobel3((img != 0).astype(np.int64), "reflect") if set(np.unique(img)) <= {0.0, 1.0} else (None, None)
+    if gx is None:
+        raise ValueError("a 0 / 255 image is expected")
+    mag = np.sqrt(gx.astype(np.float32) ** 2 + gy.astype(np.float32) ** 2)
+    if mag.max() > 0:
+        mag = mag / mag.max()
+    strong = mag > sensitivity * 0.5
+    rect3 = [1, 1, 1]
+    enhanced = cv_close(strong, rect3)
+    return cv_dilate(enhanced, [2] * 5)                             # two 3x3 dilations = one 5x5
+
+
+def protect_border_regions(binary_image, border_mask, kernel_size=18):
+    """roi.py:824-857 (odd kernel sizes; the pipeline passes 15)"""
+    b = np.asarray(binary_image)
+    closed = cv_close(b > 0, [kernel_size // 2] * kernel_size)
+    out = b.copy()
+    out[(b == 0) & closed & ~np.asarray(border_mask, bool)] = 255
+    return out
+
+
+def fill_closed_regions(binary_image, min_hole_size=10, max_hole_size=1000, connectivity=4):
+    """roi.py:881-918"""
+    b = np.asarray(binary_image)
+    if b.max() <= 1:
+        b = (b * 255).astype(np.uint8)
+    num, labels, stats = cv_connected_components_with_stats(255 - b, connectivity)
+    fill = np.zeros(num, bool)
+    fill[1:] = (stats[1:, 4] >= min_hole_size) & (stats[1:, 4] <= max_hole_size)
+    return np.where(fill[labels], 255, b).astype(np.uint8) | b
+
+
+def remove_small_regions(binary_image, min_size=10, remove_thin_lines=False, kernel_size=3):
+    """small_regions.py:4-21 (a 3x3 closing whatever kernel_size says, then the components of at least min_size pixels)"""
+    closed = cv_close(binary_image, [1, 1, 1])
+    num, labels, stats = cv_connected_components_with_stats(closed, 8)
+    keep = np.zeros(num, bool)
+    keep[1:] = stats[1:, 4] >= min_size
+    return np.where(keep[labels], 255, 0).astype(np.uint8)
+
+
+def directional_region_unification(binary_image, border_sensitivity=0.3, min_region_size=30, max_gap_to_bridge=50):
+    """roi.py:720-782 (its own parameters are ignored there in favour of fixed ones)"""
+    b = np.asarray(binary_image)
+    if b.max() <= 1:
+        b = (b * 255).astype(np.uint8)
+    border = detect_meaningful_borders(b, 0.5)
+    protected = protect_border_regions(b, border, 15)
+    bridged = bridge_small_gaps(protected, 25, 0.2, 15, 25)
+    closed = fill_closed_regions(bridged, 10, 10000, 4)
+    cleaned = remove_small_regions(closed, 5, True, 30)
+    return cleaned, (cleaned > 0).astype(np.uint8)
+
+
+def process_and_unify_borders(edge_map, edge_density, original_image, density_threshold=0.3, min_region_size=30):
+    """roi.py:527-607"""
+    borders = edge_map.copy()
+    borders[~(edge_density > density_threshold)] = 0
+    binary = (borders > 0).astype(np.uint8) * 255
+    thinless = remove_thin_structures(binary, 0.10, 0.3, 25, 25)
+    noiseless = remove_small_noise_regions(thinless, 75)
+    pre = connect_by_closing(noiseless, 5, 25)
+    connected = bridge_small_gaps(pre, 100, 0.2, 15, 25)
+    unified, region_map = directional_region_unification(connected)
+    return (unified, region_map) + extract_roi_nonroi(original_image, region_map)
+
+
+def get_regions(image_rgb):
+    """roi.py:14-40"""
+    edge_map = get_edge_map(image_rgb)
+    density = local_density(edge_map, 3)
+    threshold = suggest_automatic_threshold(density, edge_map, "mean") / 100
+    return process_and_unify_borders(edge_map, density, image_rgb, density_threshold=threshold, min_region_size=roi_min_region_size(image_rgb))
+
+
+# --------------------------------------------------------------------------------------
 # EXTENSION (no reference counterpart, SURVEY 8a-13): block DCT-II + per-region quantisation
 # --------------------------------------------------------------------------------------
 def dct_quant_blocks(plane, block, qstep_map):

@@ -67,6 +67,20 @@ PROTOTYPES = {
     "rhccq_ccl": (c_int32, [c_void_p, c_void_p, c_int32, c_int32, c_int32, c_int32, c_void_p, c_int64, c_int32, c_void_p, c_void_p, c_void_p]),
     "rhccq_ccl_select": (c_int32, [c_void_p, c_void_p, c_void_p, c_int64, c_void_p]),
     "rhccq_roi_buffer": (c_int32, [c_void_p, c_void_p, c_void_p, c_int32, c_int32, c_int32, c_void_p, c_void_p, c_void_p, c_void_p]),
+    "rhccq_edges_m2_bins": (c_int64, []),
+    "rhccq_edges_gray": (c_int32, [c_void_p, c_void_p, c_int64, c_void_p, c_void_p]),
+    "rhccq_edges_grad_hist": (c_int32, [c_void_p, c_void_p, c_int32, c_int32, c_void_p]),
+    "rhccq_canny_nms": (c_int32, [c_void_p, c_void_p, c_int32, c_int32, c_int32, c_void_p, c_void_p, c_void_p]),
+    "rhccq_edges_above": (c_int32, [c_void_p, c_void_p, c_int64, c_int32, c_void_p]),
+    "rhccq_label_reduce": (c_int32, [c_void_p, c_void_p, c_void_p, c_void_p, c_int64, c_int32, c_void_p]),
+    "rhccq_box_count": (c_int32, [c_void_p, c_void_p, c_int32, c_int32, c_int32, c_void_p]),
+    "rhccq_morph_dilate": (c_int32, [c_void_p, c_void_p, c_int32, c_int32, c_int32, C.POINTER(c_int32), c_int32, c_int32, c_void_p]),
+    "rhccq_mask_op": (c_int32, [c_void_p, c_void_p, c_void_p, c_int64, c_int32, c_void_p]),
+    "rhccq_gap_bridge": (c_int32, [c_void_p, c_void_p, c_void_p, c_int32, c_int32, c_int32, c_int32, c_void_p]),
+    "rhccq_dist_chamfer": (c_int32, [c_void_p, c_void_p, c_int32, c_int32, c_void_p, c_void_p]),
+    "rhccq_binary_sobel": (c_int32, [c_void_p, c_void_p, c_int32, c_int32, c_void_p, c_void_p]),
+    "rhccq_lut_u8": (c_int32, [c_void_p, c_void_p, c_void_p, c_int64, c_void_p]),
+    "rhccq_label_sum": (c_int32, [c_void_p, c_void_p, c_void_p, c_int32, c_int64, c_int32, c_void_p]),
     "rhccq_mt_uniforms": (c_int32, [c_void_p, c_void_p, c_int64, c_int64, c_void_p]),
     "rhccq_mbk_order_bytes": (c_int64, [c_int64]),
     "rhccq_mbk_order": (c_int32, [c_void_p, c_void_p, C.POINTER(MbkProblem), c_int32, c_void_p, c_void_p, c_void_p, c_int64]),

@@ -1,0 +1,254 @@
+// Edge front end of the ROI stage (reference encoder/ROI/edges.py:35-71,173-195): what `get_edge_map` takes from
+// OpenCV -- cvtColor(RGB2GRAY), Sobel, threshold(OTSU), 21 x Canny -- as integer kernels.  PARITY UNPINNED (OpenCV is absent from
+// the build container); every operation below is integer arithmetic restated from OpenCV's published implementation:
+//   gray   = (4899 R + 9617 G + 1868 B + 8192) >> 14                                   (cvtColor, 8-bit RGB2GRAY, fixed point)
+//   Sobel  = the 3x3 kernels [-1 0 1; -2 0 2; -1 0 1] and its transpose; BORDER_REFLECT_101 for cv2.Sobel's default,
+//            BORDER_REPLICATE inside cv2.Canny
+//   Canny  = L1 magnitude |dx| + |dy| (per pixel the channel with the largest one, first on ties), non-maximum suppression with
+//            the fixed-point tangents TG22 = round(0.41421356 * 2^15) and tg67 = tg22 + 2 |dx| 2^15 (comparisons: "> left and >= right",
+//            "> up and >= down", both ">" on the diagonals), hysteresis = 8-connected growth of the pixels above `high` through the
+//            pixels above `low`.
+// Non-maximum suppression does not depend on the thresholds, so it runs ONCE per image (nm[p] = magnitude of a local maximum,
+// else 0); each of the 21 threshold pairs then costs one mask + one connected-component labelling (csrc/ccl.hip) + one per-label
+// reduction (largest magnitude, sum and sum of squares of the gray values): a component belongs to the edge map iff its largest
+// magnitude exceeds `high`, and the quality score of edges.py:73-86 needs nothing but those per-label numbers.
+#include "rhccq_common.h"
+
+namespace rhccq {
+
+constexpr int kM2Bins = 2 * 1020 * 1020 + 1;   // gx^2 + gy^2 of a 3x3 Sobel on 8-bit data
+constexpr int kM2Lds = 8192;
+
+__device__ __forceinline__ int reflect101(int i, int n) {
+  if (n == 1) return 0;
+  if (i < 0) i = -i;
+  if (i >= n) i = 2 * n - 2 - i;
+  return i;
+}
+__device__ __forceinline__ int clampi(int i, int n) { return i < 0 ? 0 : (i >= n ? n - 1 : i); }
+
+__global__ __launch_bounds__(256) void edges_gray_kernel(const uint8_t* __restrict__ rgb, long long n, uint8_t* __restrict__ gray, int32_t* hist) {
+  __shared__ int s_h[256];
+  s_h[threadIdx.x] = 0;
+  __syncthreads();
+  for (long long p = (long long)blockIdx.x * 256 + threadIdx.x; p < n; p += (long long)gridDim.x * 256) {
+    const int g = (4899 * rgb[3 * p] + 9617 * rgb[3 * p + 1] + 1868 * rgb[3 * p + 2] + 8192) >> 14;
+    gray[p] = (uint8_t)g;
+    atomicAdd(&s_h[g], 1);
+  }
+  __syncthreads();
+  if (s_h[threadIdx.x]) atomicAdd(&hist[threadIdx.x], s_h[threadIdx.x]);
+}
+
+// 3x3 Sobel of one channel at (y, x); kReplicate: BORDER_REPLICATE (Canny), else BORDER_REFLECT_101 (cv2.Sobel's default)
+template <int kCn, bool kReplicate>
+__device__ __forceinline__ void sobel3(const uint8_t* __restrict__ img, int H, int W, int y, int x, int c, int& gx, int& gy) {
+  const int ym = kReplicate ? clampi(y - 1, H) : reflect101(y - 1, H), yp = kReplicate ? clampi(y + 1, H) : reflect101(y + 1, H);
+  const int xm = kReplicate ? clampi(x - 1, W) : reflect101(x - 1, W), xp = kReplicate ? clampi(x + 1, W) : reflect101(x + 1, W);
+  auto at = [&](int yy, int xx) { return (int)img[((long long)yy * W + xx) * kCn + c]; };
+  const int a = at(ym, xm), b = at(ym, x), cc = at(ym, xp), d = at(y, xm), f = at(y, xp), g = at(yp, xm), h = at(yp, x), i = at(yp, xp);
+  gx = (cc + 2 * f + i) - (a + 2 * d + g);
+  gy = (g + 2 * h + i) - (a + 2 * b + cc);
+}
+
+// histogram of gx^2 + gy^2 (BORDER_REFLECT_101): everything edges.py:88-160 derives from the float64 gradient magnitude
+// (mean, standard deviation, percentiles of the non-zero values) follows from it on the host
+__global__ __launch_bounds__(256) void edges_gradhist_kernel(const uint8_t* __restrict__ gray, int H, int W, int32_t* hist) {
+  __shared__ int s_h[kM2Lds];
+  for (int i = threadIdx.x; i < kM2Lds; i += 256) s_h[i] = 0;
+  __syncthreads();
+  const long long n = (long long)H * W;
+  for (long long p = (long long)blockIdx.x * 256 + threadIdx.x; p < n; p += (long long)gridDim.x * 256) {
+    int gx, gy;
+    sobel3<1, false>(gray, H, W, (int)(p / W), (int)(p % W), 0, gx, gy);
+    const int m2 = gx * gx + gy * gy;
+    if (m2 < kM2Lds) atomicAdd(&s_h[m2], 1);
+    else atomicAdd(&hist[m2], 1);
+  }
+  __syncthreads();
+  for (int i = threadIdx.x; i < kM2Lds; i += 256)
+    if (s_h[i]) atomicAdd(&hist[i], s_h[i]);
+}
+
+// Canny's gradient: per pixel the channel with the largest |dx| + |dy| (first on ties); mag u16, (dx, dy) as two int16
+template <int kCn>
+__global__ __launch_bounds__(256) void canny_grad_kernel(const uint8_t* __restrict__ img, int H, int W, uint16_t* __restrict__ mag, int32_t* __restrict__ dxy) {
+  const long long p = (long long)blockIdx.x * 256 + threadIdx.x;
+  if (p >= (long long)H * W) return;
+  const int y = (int)(p / W), x = (int)(p % W);
+  int bx = 0, by = 0, bm = -1;
+#pragma unroll
+  for (int c = 0; c < kCn; ++c) {
+    int gx, gy;
+    sobel3<kCn, true>(img, H, W, y, x, c, gx, gy);
+    const int m = abs(gx) + abs(gy);
+    if (m > bm) { bm = m; bx = gx; by = gy; }
+  }
+  mag[p] = (uint16_t)bm;
+  dxy[p] = (int32_t)(((uint32_t)(uint16_t)(int16_t)bx) | ((uint32_t)(uint16_t)(int16_t)by << 16));
+}
+
+// nm[p] = mag[p] when p is a local maximum along its gradient direction, else 0 (magnitudes outside the image count as 0)
+__global__ __launch_bounds__(256) void canny_nms_kernel(const uint16_t* __restrict__ mag, const int32_t* __restrict__ dxy, int H, int W,
+                                                        uint16_t* __restrict__ nm) {
+  const long long p = (long long)blockIdx.x * 256 + threadIdx.x;
+  if (p >= (long long)H * W) return;
+  const int y = (int)(p / W), x = (int)(p % W);
+  const int m = mag[p];
+  uint16_t out = 0;
+  if (m > 0) {
+    auto at = [&](int yy, int xx) { return (yy < 0 || yy >= H || xx < 0 || xx >= W) ? 0 : (int)mag[(long long)yy * W + xx]; };
+    const int32_t d = dxy[p];
+    const int xs = (int)(int16_t)(d & 0xffff), ys = (int)(int16_t)((uint32_t)d >> 16);
+    const int ax = abs(xs), ay = abs(ys) << 15;
+    const int tg22x = ax * 13573;                           // TG22 = (int)(0.4142135623730950488 * 2^15 + 0.5)
+    bool is_max;
+    if (ay < tg22x) is_max = m > at(y, x - 1) && m >= at(y, x + 1);
+    else {
+      const int tg67x = tg22x + (ax << 16);
+      if (ay > tg67x) is_max = m > at(y - 1, x) && m >= at(y + 1, x);
+      else {
+        const int s = (xs ^ ys) < 0 ? -1 : 1;
+        is_max = m > at(y - 1, x - s) && m > at(y + 1, x + s);
+      }
+    }
+    if (is_max) out = (uint16_t)m;
+  }
+  nm[p] = out;
+}
+
+__global__ __launch_bounds__(256) void edges_above_kernel(const uint16_t* __restrict__ nm, long long n, int low, uint8_t* __restrict__ mask) {
+  const long long p = (long long)blockIdx.x * 256 + threadIdx.x;
+  if (p < n) mask[p] = nm[p] > low;
+}
+
+// per label: red[l] = {largest value of `val16`, sum of `val8`, sum of val8^2} over the label's pixels (int64 each); one wave
+// covers 64 consecutive pixels: when all its foreground lanes share one label (the common case on edge maps: short runs) the
+// wave reduces first and issues three atomics
+__global__ __launch_bounds__(256) void label_reduce_kernel(const int32_t* __restrict__ labels, const uint16_t* __restrict__ val16,
+                                                           const uint8_t* __restrict__ val8, long long n, unsigned long long* red) {
+  const long long p = (long long)blockIdx.x * 256 + threadIdx.x;
+  const int lane = threadIdx.x & 63;
+  const int l = p < n ? labels[p] : 0;
+  const unsigned long long fg = __ballot(l != 0);
+  if (!fg) return;
+  unsigned long long v16 = l && val16 ? val16[p] : 0ull, v8 = l && val8 ? val8[p] : 0ull;
+  const int first = __builtin_ctzll(fg);
+  const int lead = __shfl(l, first);
+  if (__ballot(l != 0 && l != lead) == 0) {
+    unsigned long long mx = v16, s1 = v8, s2 = v8 * v8;
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) {
+      mx = max(mx, (unsigned long long)__shfl_down(mx, o, 64));
+      s1 += __shfl_down(s1, o, 64);
+      s2 += __shfl_down(s2, o, 64);
+    }
+    if (lane == 0) {
+      atomicMax(&red[3ll * lead], mx);
+      if (s1) { atomicAdd(&red[3ll * lead + 1], s1); atomicAdd(&red[3ll * lead + 2], s2); }
+    }
+  } else if (l) {
+    atomicMax(&red[3ll * l], v16);
+    if (v8) { atomicAdd(&red[3ll * l + 1], v8); atomicAdd(&red[3ll * l + 2], v8 * v8); }
+  }
+}
+
+// number of non-zero pixels in the k x k window centred on each pixel, BORDER_REFLECT_101 (cv2.filter2D's default border), k odd <= 31
+constexpr int kBoxTW = 64, kBoxTH = 16, kBoxMaxR = 15;
+__global__ __launch_bounds__(256) void box_count_kernel(const uint8_t* __restrict__ mask, int H, int W, int r, uint16_t* __restrict__ out) {
+  __shared__ uint8_t t[kBoxTH + 2 * kBoxMaxR][kBoxTW + 2 * kBoxMaxR + 2];
+  __shared__ uint16_t hsum[kBoxTH + 2 * kBoxMaxR][kBoxTW];
+  const int tiles_x = (W + kBoxTW - 1) / kBoxTW;
+  const int y0 = (blockIdx.x / tiles_x) * kBoxTH, x0 = (blockIdx.x % tiles_x) * kBoxTW;
+  const int th = kBoxTH + 2 * r, tw = kBoxTW + 2 * r;
+  for (int i = threadIdx.x; i < th * tw; i += 256) {
+    const int ly = i / tw, lx = i % tw;
+    const int y = reflect101(y0 + ly - r, H), x = reflect101(x0 + lx - r, W);
+    // (tiles that stick out of the image reflect far coordinates back inside: those outputs are never stored)
+    t[ly][lx] = mask[(long long)clampi(y, H) * W + clampi(x, W)] != 0;
+  }
+  __syncthreads();
+  for (int i = threadIdx.x; i < th * kBoxTW; i += 256) {
+    const int ly = i / kBoxTW, lx = i % kBoxTW;
+    int s = 0;
+    for (int d = 0; d <= 2 * r; ++d) s += t[ly][lx + d];
+    hsum[ly][lx] = (uint16_t)s;
+  }
+  __syncthreads();
+  for (int i = threadIdx.x; i < kBoxTH * kBoxTW; i += 256) {
+    const int ly = i / kBoxTW, lx = i % kBoxTW;
+    const int y = y0 + ly, x = x0 + lx;
+    if (y >= H || x >= W) continue;
+    int s = 0;
+    for (int d = 0; d <= 2 * r; ++d) s += hsum[ly + d][lx];
+    out[(long long)y * W + x] = (uint16_t)s;
+  }
+}
+
+}  // namespace rhccq
+
+using namespace rhccq;
+
+extern "C" {
+
+int64_t rhccq_edges_m2_bins(void) { return kM2Bins; }
+
+int rhccq_edges_gray(rhccq_ctx* ctx, const uint8_t* rgb, int64_t n_pixels, uint8_t* gray, int32_t* hist256) {
+  if (!ctx || !rgb || !gray || !hist256 || n_pixels <= 0) return rhccq_fail(ctx, RHCCQ_E_ARG, "edges_gray: bad argument");
+  RHCCQ_HIP(ctx, hipMemsetAsync(hist256, 0, 256 * sizeof(int32_t), ctx->stream));
+  const unsigned grid = (unsigned)((n_pixels + 255) / 256 < 2048 ? (n_pixels + 255) / 256 : 2048);
+  hipLaunchKernelGGL(edges_gray_kernel, dim3(grid), dim3(256), 0, ctx->stream, rgb, (long long)n_pixels, gray, hist256);
+  RHCCQ_LAUNCH_CHECK(ctx);
+  return 0;
+}
+
+int rhccq_edges_grad_hist(rhccq_ctx* ctx, const uint8_t* gray, int32_t H, int32_t W, int32_t* hist_m2) {
+  if (!ctx || !gray || !hist_m2 || H <= 0 || W <= 0) return rhccq_fail(ctx, RHCCQ_E_ARG, "edges_grad_hist: bad argument");
+  RHCCQ_HIP(ctx, hipMemsetAsync(hist_m2, 0, (size_t)kM2Bins * sizeof(int32_t), ctx->stream));
+  const long long n = (long long)H * W;
+  const unsigned grid = (unsigned)((n + 255) / 256 < 1024 ? (n + 255) / 256 : 1024);
+  hipLaunchKernelGGL(edges_gradhist_kernel, dim3(grid), dim3(256), 0, ctx->stream, gray, H, W, hist_m2);
+  RHCCQ_LAUNCH_CHECK(ctx);
+  return 0;
+}
+
+int rhccq_canny_nms(rhccq_ctx* ctx, const uint8_t* img, int32_t H, int32_t W, int32_t channels, uint16_t* mag_tmp, int32_t* dxy_tmp, uint16_t* nm) {
+  if (!ctx || !img || !mag_tmp || !dxy_tmp || !nm || H <= 0 || W <= 0) return rhccq_fail(ctx, RHCCQ_E_ARG, "canny_nms: bad argument");
+  if (channels != 1 && channels != 3) return rhccq_fail(ctx, RHCCQ_E_ARG, "canny_nms: 1 or 3 channels");
+  const unsigned grid = (unsigned)(((long long)H * W + 255) / 256);
+  if (channels == 1) hipLaunchKernelGGL(canny_grad_kernel<1>, dim3(grid), dim3(256), 0, ctx->stream, img, H, W, mag_tmp, dxy_tmp);
+  else hipLaunchKernelGGL(canny_grad_kernel<3>, dim3(grid), dim3(256), 0, ctx->stream, img, H, W, mag_tmp, dxy_tmp);
+  hipLaunchKernelGGL(canny_nms_kernel, dim3(grid), dim3(256), 0, ctx->stream, mag_tmp, dxy_tmp, H, W, nm);
+  RHCCQ_LAUNCH_CHECK(ctx);
+  return 0;
+}
+
+int rhccq_edges_above(rhccq_ctx* ctx, const uint16_t* nm, int64_t n_pixels, int32_t low, uint8_t* mask) {
+  if (!ctx || !nm || !mask || n_pixels <= 0) return rhccq_fail(ctx, RHCCQ_E_ARG, "edges_above: bad argument");
+  hipLaunchKernelGGL(edges_above_kernel, dim3((unsigned)((n_pixels + 255) / 256)), dim3(256), 0, ctx->stream, nm, (long long)n_pixels, low, mask);
+  RHCCQ_LAUNCH_CHECK(ctx);
+  return 0;
+}
+
+int rhccq_label_reduce(rhccq_ctx* ctx, const int32_t* labels, const uint16_t* val16, const uint8_t* val8, int64_t n_pixels, int32_t n_labels,
+                       uint64_t* red) {
+  if (!ctx || !labels || !red || n_pixels <= 0 || n_labels < 0) return rhccq_fail(ctx, RHCCQ_E_ARG, "label_reduce: bad argument");
+  RHCCQ_HIP(ctx, hipMemsetAsync(red, 0, 3 * sizeof(uint64_t) * ((size_t)n_labels + 1), ctx->stream));
+  hipLaunchKernelGGL(label_reduce_kernel, dim3((unsigned)((n_pixels + 255) / 256)), dim3(256), 0, ctx->stream, labels, val16, val8, (long long)n_pixels,
+                     (unsigned long long*)red);
+  RHCCQ_LAUNCH_CHECK(ctx);
+  return 0;
+}
+
+int rhccq_box_count(rhccq_ctx* ctx, const uint8_t* mask, int32_t H, int32_t W, int32_t kernel_size, uint16_t* out) {
+  if (!ctx || !mask || !out || H <= 0 || W <= 0) return rhccq_fail(ctx, RHCCQ_E_ARG, "box_count: bad argument");
+  if (kernel_size < 1 || kernel_size > 2 * kBoxMaxR + 1 || !(kernel_size & 1)) return rhccq_fail(ctx, RHCCQ_E_LIMIT, "box_count: odd kernel sizes 1..31");
+  const int r = kernel_size / 2;
+  if (r >= H || r >= W) return rhccq_fail(ctx, RHCCQ_E_LIMIT, "box_count: window radius must be smaller than the image");
+  const unsigned grid = (unsigned)(((W + kBoxTW - 1) / kBoxTW) * (long long)((H + kBoxTH - 1) / kBoxTH));
+  hipLaunchKernelGGL(box_count_kernel, dim3(grid), dim3(256), 0, ctx->stream, mask, H, W, r, out);
+  RHCCQ_LAUNCH_CHECK(ctx);
+  return 0;
+}
+
+}  // extern "C"

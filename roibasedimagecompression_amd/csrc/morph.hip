@@ -1,0 +1,253 @@
+// Binary-mask operators of the ROI clean-up chain (reference encoder/ROI/{roi,small_regions,small_gaps,thin_regions2}.py):
+// what the reference takes from cv2.morphologyEx / dilate (rectangular and elliptical structuring elements), cv2.filter2D with
+// one-directional kernels (small_gaps.py:221-319), cv2.distanceTransform(DIST_L2, 3) and cv2.Sobel on a 0/1 image.  PARITY UNPINNED
+// (OpenCV is absent from the build container); restated from the published definitions, integer arithmetic throughout.
+// Masks are u8 planes, "set" = non-zero; outputs are 0 / 255.
+#include "rhccq_common.h"
+
+namespace rhccq {
+
+__device__ __forceinline__ int m_reflect101(int i, int n) {
+  if (n == 1) return 0;
+  if (i < 0) i = -i;
+  if (i >= n) i = 2 * n - 2 - i;
+  return i < 0 ? 0 : (i >= n ? n - 1 : i);
+}
+
+// ---- dilation by a structuring element given as one half-width per row (-1: the row is empty), rows dy = -r .. r; pixels outside
+// the image are not set (cv2's default border value for dilate).  invert_in / invert_out turn it into the erosion by the same
+// (symmetric) element with cv2's border rule for erode (outside = set): erode(A) = not dilate(not A).
+constexpr int kMorTW = 64, kMorTH = 16, kMorMaxR = 15;
+struct MorphSpans { int r; signed char half[2 * kMorMaxR + 1]; };
+
+__global__ __launch_bounds__(256) void morph_dilate_kernel(const uint8_t* __restrict__ in, int H, int W, MorphSpans se, int invert_in, int invert_out,
+                                                           uint8_t* __restrict__ out) {
+  __shared__ uint16_t pre[kMorTH + 2 * kMorMaxR][kMorTW + 2 * kMorMaxR + 2];   // per row: prefix count of set pixels
+  const int r = se.r;
+  const int tiles_x = (W + kMorTW - 1) / kMorTW;
+  const int y0 = (blockIdx.x / tiles_x) * kMorTH, x0 = (blockIdx.x % tiles_x) * kMorTW;
+  const int th = kMorTH + 2 * r, tw = kMorTW + 2 * r;
+  for (int ly = threadIdx.x; ly < th; ly += 256) {          // one thread per staged row: a sequential prefix count
+    const int y = y0 + ly - r;
+    int acc = 0;
+    pre[ly][0] = 0;
+    for (int lx = 0; lx < tw; ++lx) {
+      const int x = x0 + lx - r;
+      bool v = false;
+      if (y >= 0 && y < H && x >= 0 && x < W) v = (in[(long long)y * W + x] != 0) != (invert_in != 0);
+      acc += v;
+      pre[ly][lx + 1] = (uint16_t)acc;
+    }
+  }
+  __syncthreads();
+  for (int i = threadIdx.x; i < kMorTH * kMorTW; i += 256) {
+    const int ly = i / kMorTW, lx = i % kMorTW;
+    const int y = y0 + ly, x = x0 + lx;
+    if (y >= H || x >= W) continue;
+    bool any = false;
+    for (int dy = -r; dy <= r && !any; ++dy) {
+      const int hw = se.half[dy + r];
+      if (hw < 0) continue;
+      const uint16_t* row = pre[ly + r + dy];
+      any = row[lx + r + hw + 1] != row[lx + r - hw];
+    }
+    out[(long long)y * W + x] = (any != (invert_out != 0)) ? 255 : 0;
+  }
+}
+
+// ---- element-wise combinations of masks: op 0: a | b, 1: a & b, 2: a & ~b, 3: ~a
+__global__ __launch_bounds__(256) void mask_op_kernel(const uint8_t* __restrict__ a, const uint8_t* __restrict__ b, long long n, int op, uint8_t* __restrict__ out) {
+  const long long p = (long long)blockIdx.x * 256 + threadIdx.x;
+  if (p >= n) return;
+  const bool x = a[p] != 0, y = b ? b[p] != 0 : false;
+  const bool v = op == 0 ? (x || y) : op == 1 ? (x && y) : op == 2 ? (x && !y) : !x;
+  out[p] = v ? 255 : 0;
+}
+
+// ---- bridge_small_gaps_fast (small_gaps.py:221-271): an unset pixel whose window count reaches `min_count` (its regional density
+// exceeds the threshold) is set when, for one of the four direction pairs, BOTH opposite rays hold a set pixel within `reach` steps
+// (the reference's one-directional filter2D kernels; coordinates beyond the image reflect, BORDER_REFLECT_101)
+__global__ __launch_bounds__(256) void gap_bridge_kernel(const uint8_t* __restrict__ in, const uint16_t* __restrict__ counts, int H, int W, int min_count,
+                                                         int reach, uint8_t* __restrict__ out) {
+  const long long p = (long long)blockIdx.x * 256 + threadIdx.x;
+  if (p >= (long long)H * W) return;
+  if (in[p] != 0) { out[p] = 255; return; }
+  uint8_t v = 0;
+  if ((int)counts[p] >= min_count) {
+    const int y = (int)(p / W), x = (int)(p % W);
+    auto ray = [&](int dx, int dy) {
+      for (int t = 1; t <= reach; ++t)
+        if (in[(long long)m_reflect101(y + dy * t, H) * W + m_reflect101(x + dx * t, W)] != 0) return true;
+      return false;
+    };
+    if ((ray(-1, 0) && ray(1, 0)) || (ray(0, -1) && ray(0, 1)) || (ray(-1, -1) && ray(1, 1)) || (ray(-1, 1) && ray(1, -1))) v = 255;
+  }
+  out[p] = v;
+}
+
+// ---- cv2.distanceTransform(mask, DIST_L2, 3): the 3x3 chamfer metric with OpenCV's fixed-point weights a = round(0.955 * 2^16),
+// b = round(1.3693 * 2^16): distance to the nearest unset pixel = min over rows y' of chamfer(hz[y'][x], |y - y'|), where hz is
+// the horizontal distance to the nearest unset pixel of row y' (the metric grows with |dx| for fixed |dy|, so the row's nearest
+// unset pixel is its best); the row loop stops once a |dy| alone exceeds the best distance found.  The two-pass raster algorithm
+// of OpenCV computes exactly this metric (paths never need to leave the image).  Output: fixed point, 16 fractional bits.
+constexpr int kChamA = 62587, kChamB = 89738, kChamMax = 0x7fffffff >> 2;
+constexpr int kHzNone = 0xffff;
+
+__global__ __launch_bounds__(64) void dist_hz_kernel(const uint8_t* __restrict__ mask, int H, int W, uint16_t* __restrict__ hz) {
+  const int y = blockIdx.x * 64 + threadIdx.x;
+  if (y >= H) return;
+  const uint8_t* row = mask + (long long)y * W;
+  uint16_t* o = hz + (long long)y * W;
+  int d = kHzNone;
+  for (int x = 0; x < W; ++x) {
+    d = row[x] == 0 ? 0 : (d >= kHzNone - 1 ? kHzNone : d + 1);
+    o[x] = (uint16_t)d;
+  }
+  d = kHzNone;
+  for (int x = W - 1; x >= 0; --x) {
+    d = row[x] == 0 ? 0 : (d >= kHzNone - 1 ? kHzNone : d + 1);
+    if (d < o[x]) o[x] = (uint16_t)d;
+  }
+}
+
+__global__ __launch_bounds__(256) void dist_chamfer_kernel(const uint16_t* __restrict__ hz, int H, int W, int32_t* __restrict__ dist) {
+  const long long p = (long long)blockIdx.x * 256 + threadIdx.x;
+  if (p >= (long long)H * W) return;
+  const int y = (int)(p / W), x = (int)(p % W);
+  const int h0 = hz[p];
+  if (h0 == 0) { dist[p] = 0; return; }
+  long long best = h0 == kHzNone ? (long long)kChamMax : (long long)h0 * kChamA;
+  for (int dy = 1; (long long)dy * kChamA < best; ++dy) {
+    bool any_row = false;
+#pragma unroll
+    for (int sgn = -1; sgn <= 1; sgn += 2) {
+      const int yy = y + sgn * dy;
+      if (yy < 0 || yy >= H) continue;
+      any_row = true;
+      const int dx = hz[(long long)yy * W + x];
+      if (dx == kHzNone) continue;
+      const int mn = dx < dy ? dx : dy, mx = dx < dy ? dy : dx;
+      const long long c = (long long)mn * kChamB + (long long)(mx - mn) * kChamA;
+      if (c < best) best = c;
+    }
+    if (!any_row) break;
+  }
+  dist[p] = (int32_t)(best > kChamMax ? kChamMax : best);
+}
+
+// ---- detect_meaningful_borders (roi.py:784-822), first half: squared 3x3 Sobel magnitude of the 0/1 image (BORDER_REFLECT_101),
+// a value in 0..32, and its maximum over the image
+__global__ __launch_bounds__(256) void binary_sobel_kernel(const uint8_t* __restrict__ mask, int H, int W, uint8_t* __restrict__ m2, int32_t* max_out) {
+  const long long p = (long long)blockIdx.x * 256 + threadIdx.x;
+  int v = 0;
+  if (p < (long long)H * W) {
+    const int y = (int)(p / W), x = (int)(p % W);
+    const int ym = m_reflect101(y - 1, H), yp = m_reflect101(y + 1, H), xm = m_reflect101(x - 1, W), xp = m_reflect101(x + 1, W);
+    auto at = [&](int yy, int xx) { return mask[(long long)yy * W + xx] != 0 ? 1 : 0; };
+    const int a = at(ym, xm), b = at(ym, x), c = at(ym, xp), d = at(y, xm), f = at(y, xp), g = at(yp, xm), h = at(yp, x), i = at(yp, xp);
+    const int gx = (c + 2 * f + i) - (a + 2 * d + g), gy = (g + 2 * h + i) - (a + 2 * b + c);
+    v = gx * gx + gy * gy;
+    m2[p] = (uint8_t)v;
+  }
+  for (int o = 32; o > 0; o >>= 1) v = max(v, __shfl_down(v, o, 64));
+  if ((threadIdx.x & 63) == 0 && v > 0) atomicMax(max_out, v);
+}
+
+__global__ __launch_bounds__(256) void lut_u8_kernel(const uint8_t* __restrict__ in, const uint8_t* __restrict__ lut, long long n, uint8_t* __restrict__ out) {
+  const long long p = (long long)blockIdx.x * 256 + threadIdx.x;
+  if (p < n) out[p] = lut[in[p]];
+}
+
+// ---- per label: sum of a u16 plane (box counts) or of an int32 plane (fixed-point distances), int64 accumulators
+template <typename T>
+__global__ __launch_bounds__(256) void label_sum_kernel(const int32_t* __restrict__ labels, const T* __restrict__ val, long long n, unsigned long long* sums) {
+  const long long p = (long long)blockIdx.x * 256 + threadIdx.x;
+  const int lane = threadIdx.x & 63;
+  const int l = p < n ? labels[p] : -1;
+  const unsigned long long in = __ballot(l >= 0);
+  if (!in) return;
+  unsigned long long v = l >= 0 ? (unsigned long long)val[p] : 0ull;
+  const int lead = __shfl(l, __builtin_ctzll(in));
+  if (__ballot(l >= 0 && l != lead) == 0) {
+    for (int o = 32; o > 0; o >>= 1) v += __shfl_down(v, o, 64);
+    if (lane == 0 && v) atomicAdd(&sums[lead], v);
+  } else if (l >= 0 && v) {
+    atomicAdd(&sums[l], v);
+  }
+}
+
+}  // namespace rhccq
+
+using namespace rhccq;
+
+extern "C" {
+
+int rhccq_morph_dilate(rhccq_ctx* ctx, const uint8_t* in, int32_t H, int32_t W, int32_t radius, const int32_t* half_widths, int32_t invert_in,
+                       int32_t invert_out, uint8_t* out) {
+  if (!ctx || !in || !out || !half_widths || H <= 0 || W <= 0 || in == out) return rhccq_fail(ctx, RHCCQ_E_ARG, "morph_dilate: bad argument");
+  if (radius < 0 || radius > kMorMaxR) return rhccq_fail(ctx, RHCCQ_E_LIMIT, "morph_dilate: structuring elements up to 31 x 31");
+  MorphSpans se;
+  se.r = radius;
+  for (int i = 0; i <= 2 * radius; ++i) {
+    if (half_widths[i] > radius) return rhccq_fail(ctx, RHCCQ_E_ARG, "morph_dilate: a half-width exceeds the radius");
+    se.half[i] = (signed char)(half_widths[i] < 0 ? -1 : half_widths[i]);
+  }
+  const unsigned grid = (unsigned)(((W + kMorTW - 1) / kMorTW) * (long long)((H + kMorTH - 1) / kMorTH));
+  hipLaunchKernelGGL(morph_dilate_kernel, dim3(grid), dim3(256), 0, ctx->stream, in, H, W, se, invert_in, invert_out, out);
+  RHCCQ_LAUNCH_CHECK(ctx);
+  return 0;
+}
+
+int rhccq_mask_op(rhccq_ctx* ctx, const uint8_t* a, const uint8_t* b, int64_t n, int32_t op, uint8_t* out) {
+  if (!ctx || !a || !out || n <= 0 || op < 0 || op > 3 || (op != 3 && !b)) return rhccq_fail(ctx, RHCCQ_E_ARG, "mask_op: bad argument");
+  hipLaunchKernelGGL(mask_op_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, ctx->stream, a, b, (long long)n, op, out);
+  RHCCQ_LAUNCH_CHECK(ctx);
+  return 0;
+}
+
+int rhccq_gap_bridge(rhccq_ctx* ctx, const uint8_t* in, const uint16_t* counts, int32_t H, int32_t W, int32_t min_count, int32_t reach, uint8_t* out) {
+  if (!ctx || !in || !counts || !out || H <= 0 || W <= 0 || reach < 0 || in == out) return rhccq_fail(ctx, RHCCQ_E_ARG, "gap_bridge: bad argument");
+  if (reach >= H || reach >= W) return rhccq_fail(ctx, RHCCQ_E_LIMIT, "gap_bridge: reach must be smaller than the image");
+  hipLaunchKernelGGL(gap_bridge_kernel, dim3((unsigned)(((long long)H * W + 255) / 256)), dim3(256), 0, ctx->stream, in, counts, H, W, min_count, reach, out);
+  RHCCQ_LAUNCH_CHECK(ctx);
+  return 0;
+}
+
+int rhccq_dist_chamfer(rhccq_ctx* ctx, const uint8_t* mask, int32_t H, int32_t W, uint16_t* hz_tmp, int32_t* dist) {
+  if (!ctx || !mask || !hz_tmp || !dist || H <= 0 || W <= 0) return rhccq_fail(ctx, RHCCQ_E_ARG, "dist_chamfer: bad argument");
+  if (W >= kHzNone) return rhccq_fail(ctx, RHCCQ_E_LIMIT, "dist_chamfer: rows up to 65534 pixels");
+  hipLaunchKernelGGL(dist_hz_kernel, dim3((unsigned)((H + 63) / 64)), dim3(64), 0, ctx->stream, mask, H, W, hz_tmp);
+  hipLaunchKernelGGL(dist_chamfer_kernel, dim3((unsigned)(((long long)H * W + 255) / 256)), dim3(256), 0, ctx->stream, hz_tmp, H, W, dist);
+  RHCCQ_LAUNCH_CHECK(ctx);
+  return 0;
+}
+
+int rhccq_binary_sobel(rhccq_ctx* ctx, const uint8_t* mask, int32_t H, int32_t W, uint8_t* m2, int32_t* max_out) {
+  if (!ctx || !mask || !m2 || !max_out || H <= 0 || W <= 0) return rhccq_fail(ctx, RHCCQ_E_ARG, "binary_sobel: bad argument");
+  RHCCQ_HIP(ctx, hipMemsetAsync(max_out, 0, sizeof(int32_t), ctx->stream));
+  hipLaunchKernelGGL(binary_sobel_kernel, dim3((unsigned)(((long long)H * W + 255) / 256)), dim3(256), 0, ctx->stream, mask, H, W, m2, max_out);
+  RHCCQ_LAUNCH_CHECK(ctx);
+  return 0;
+}
+
+int rhccq_lut_u8(rhccq_ctx* ctx, const uint8_t* in, const uint8_t* lut256, int64_t n, uint8_t* out) {
+  if (!ctx || !in || !lut256 || !out || n <= 0) return rhccq_fail(ctx, RHCCQ_E_ARG, "lut_u8: bad argument");
+  hipLaunchKernelGGL(lut_u8_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, ctx->stream, in, lut256, (long long)n, out);
+  RHCCQ_LAUNCH_CHECK(ctx);
+  return 0;
+}
+
+int rhccq_label_sum(rhccq_ctx* ctx, const int32_t* labels, const void* values, int32_t value_bytes, int64_t n_pixels, int32_t n_labels, uint64_t* sums) {
+  if (!ctx || !labels || !values || !sums || n_pixels <= 0 || n_labels < 0 || (value_bytes != 2 && value_bytes != 4))
+    return rhccq_fail(ctx, RHCCQ_E_ARG, "label_sum: bad argument");
+  RHCCQ_HIP(ctx, hipMemsetAsync(sums, 0, sizeof(uint64_t) * ((size_t)n_labels + 1), ctx->stream));
+  const unsigned grid = (unsigned)((n_pixels + 255) / 256);
+  if (value_bytes == 2)
+    hipLaunchKernelGGL(label_sum_kernel<uint16_t>, dim3(grid), dim3(256), 0, ctx->stream, labels, (const uint16_t*)values, (long long)n_pixels, (unsigned long long*)sums);
+  else
+    hipLaunchKernelGGL(label_sum_kernel<int32_t>, dim3(grid), dim3(256), 0, ctx->stream, labels, (const int32_t*)values, (long long)n_pixels, (unsigned long long*)sums);
+  RHCCQ_LAUNCH_CHECK(ctx);
+  return 0;
+}
+
+}  // extern "C"

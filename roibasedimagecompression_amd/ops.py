@@ -724,6 +724,110 @@ class Rhccq:
                                               self._p(ri), self._p(ni)), "roi_buffer")
         return ri, ni, rm.view(torch.bool), nm.view(torch.bool)
 
+    # -- ROI stage: edge front end (csrc/edges.hip) -------------------------------------------------------
+    def edges_gray(self, rgb):
+        """rgb uint8[H,W,3] device -> (gray uint8[H,W] device, histogram np.int64[256])"""
+        assert rgb.dtype == torch.uint8 and rgb.is_contiguous() and rgb.shape[-1] == 3
+        gray = self.empty(tuple(rgb.shape[:2]), torch.uint8)
+        hist = self.empty((256,), torch.int32)
+        self._check(self.lib.rhccq_edges_gray(self.ctx, self._p(rgb), gray.numel(), self._p(gray), self._p(hist)), "edges_gray")
+        return gray, hist.cpu().numpy().astype(np.int64)
+
+    def edges_grad_hist(self, gray):
+        """gray uint8[H,W] device -> (values, counts): the distinct gx^2 + gy^2 of the 3x3 Sobel (BORDER_REFLECT_101), ascending"""
+        H, W = int(gray.shape[0]), int(gray.shape[1])
+        hist = self.empty((int(self.lib.rhccq_edges_m2_bins()),), torch.int32)
+        self._check(self.lib.rhccq_edges_grad_hist(self.ctx, self._p(gray), H, W, self._p(hist)), "edges_grad_hist")
+        h = hist.cpu().numpy()
+        v = np.flatnonzero(h)
+        return v.astype(np.int64), h[v].astype(np.int64)
+
+    def canny_nms(self, img):
+        """img uint8[H,W] or [H,W,3] device -> uint16[H,W] device (stored as int16): Canny's magnitude at the local maxima, 0 elsewhere"""
+        assert img.dtype == torch.uint8 and img.is_contiguous()
+        H, W = int(img.shape[0]), int(img.shape[1])
+        cn = 1 if img.dim() == 2 else int(img.shape[2])
+        mag, nm = self.empty((H, W), torch.int16), self.empty((H, W), torch.int16)
+        dxy = self.empty((H, W), torch.int32)
+        self._check(self.lib.rhccq_canny_nms(self.ctx, self._p(img), H, W, cn, self._p(mag), self._p(dxy), self._p(nm)), "canny_nms")
+        return nm
+
+    def canny_components(self, nm, low, gray=None):
+        """components of {nm > low}: -> (n, labels int32[H,W] device, areas np.int64[n + 1], red np.uint64[n + 1, 3] = per label
+        max nm, sum gray, sum gray^2); an edge component of cv2.Canny(img, low, high) is one whose max exceeds `high`"""
+        H, W = int(nm.shape[0]), int(nm.shape[1])
+        mask = self.empty((H, W), torch.uint8)
+        self._check(self.lib.rhccq_edges_above(self.ctx, self._p(nm), H * W, int(low), self._p(mask)), "edges_above")
+        n, labels, stats = self.ccl(mask, 8, cap=1 << 16)
+        red = self.label_reduce(labels, n, nm, gray)
+        return n, labels, stats[:, 4].astype(np.int64), red
+
+    def label_reduce(self, labels, n, val16=None, val8=None):
+        """-> np.uint64[n + 1, 3]: per label {max of val16, sum of val8, sum of val8^2}"""
+        red = self.empty((n + 1, 3), torch.int64)
+        self._check(self.lib.rhccq_label_reduce(self.ctx, self._p(labels), self._p(val16), self._p(val8), labels.numel(), n, self._p(red)), "label_reduce")
+        return red.cpu().numpy().view(np.uint64)
+
+    def box_count(self, mask, kernel_size):
+        """mask uint8 / bool [H,W] device -> uint16[H,W] device (int16 storage): non-zero pixels per k x k window, BORDER_REFLECT_101"""
+        if mask.dtype == torch.bool:
+            mask = mask.view(torch.uint8)
+        H, W = int(mask.shape[0]), int(mask.shape[1])
+        out = self.empty((H, W), torch.int16)
+        self._check(self.lib.rhccq_box_count(self.ctx, self._p(mask), H, W, int(kernel_size), self._p(out)), "box_count")
+        return out
+
+    # -- ROI stage: clean-up chain (csrc/morph.hip); masks are uint8[H,W] device planes, set = non-zero, results 0 / 255 ----
+    def morph(self, mask, half_widths, erode=False):
+        """cv2.dilate / cv2.erode by the symmetric structuring element given as one half-width per row (-1 = empty row)"""
+        H, W = int(mask.shape[0]), int(mask.shape[1])
+        hw = (C.c_int32 * len(half_widths))(*[int(v) for v in half_widths])
+        out = self.empty((H, W), torch.uint8)
+        self._check(self.lib.rhccq_morph_dilate(self.ctx, self._p(mask), H, W, len(half_widths) // 2, hw, int(erode), int(erode), self._p(out)), "morph_dilate")
+        return out
+
+    def morph_close(self, mask, half_widths):
+        return self.morph(self.morph(mask, half_widths), half_widths, erode=True)
+
+    def mask_op(self, a, b, op):
+        """op: 'or', 'and', 'andnot' (a & ~b), 'not' (~a)"""
+        out = torch.empty_like(a)
+        self._check(self.lib.rhccq_mask_op(self.ctx, self._p(a), self._p(b), a.numel(), ("or", "and", "andnot", "not").index(op), self._p(out)), "mask_op")
+        return out
+
+    def gap_bridge(self, mask, counts, min_count, reach):
+        out = torch.empty_like(mask)
+        self._check(self.lib.rhccq_gap_bridge(self.ctx, self._p(mask), self._p(counts), int(mask.shape[0]), int(mask.shape[1]), int(min_count), int(reach),
+                                              self._p(out)), "gap_bridge")
+        return out
+
+    def dist_chamfer(self, mask):
+        """cv2.distanceTransform(mask, DIST_L2, 3) in fixed point (int32[H,W] device, 16 fractional bits)"""
+        H, W = int(mask.shape[0]), int(mask.shape[1])
+        hz = self.empty((H, W), torch.int16)
+        dist = self.empty((H, W), torch.int32)
+        self._check(self.lib.rhccq_dist_chamfer(self.ctx, self._p(mask), H, W, self._p(hz), self._p(dist)), "dist_chamfer")
+        return dist
+
+    def binary_sobel(self, mask):
+        """-> (uint8[H,W] device: gx^2 + gy^2 of the 0/1 image's 3x3 Sobel, its maximum)"""
+        H, W = int(mask.shape[0]), int(mask.shape[1])
+        m2 = self.empty((H, W), torch.uint8)
+        mx = self.empty((1,), torch.int32)
+        self._check(self.lib.rhccq_binary_sobel(self.ctx, self._p(mask), H, W, self._p(m2), self._p(mx)), "binary_sobel")
+        return m2, int(mx.cpu()[0])
+
+    def lut_u8(self, plane, lut256):
+        out = torch.empty_like(plane)
+        self._check(self.lib.rhccq_lut_u8(self.ctx, self._p(plane), self._p(self.dev(np.asarray(lut256, np.uint8))), plane.numel(), self._p(out)), "lut_u8")
+        return out
+
+    def label_sum(self, labels, n, values):
+        """-> np.uint64[n + 1]: per label (0 = background included) the sum of a uint16 (int16 storage) or non-negative int32 plane"""
+        sums = self.empty((n + 1,), torch.int64)
+        self._check(self.lib.rhccq_label_sum(self.ctx, self._p(labels), self._p(values), values.element_size(), labels.numel(), n, self._p(sums)), "label_sum")
+        return sums.cpu().numpy().view(np.uint64)
+
     # -- K6 / decode ------------------------------------------------------------------------------
     def remap(self, idx, lut):
         out = torch.empty_like(idx)

@@ -88,12 +88,17 @@ def test_reference_import_surface():
     assert compute_clustering_params(2274, 20, color_space="lab") == (102.4, 1, 91)
     assert get_all_unique_colors(np.zeros((0, 0, 3), np.uint8), (0, 0)) is None
     assert merge_region_components_simple([], (0, 0, 4, 4)) == []
-    from encoder.ROI.roi import get_regions, process_and_unify_borders
+    from encoder.ROI.roi import get_regions, process_and_unify_borders, visualize_roi_nonroi_comparison
+    from encoder.ROI.small_regions import remove_small_regions, connect_by_closing_fast, connect_nearby_pixels
+    from encoder.ROI.small_gaps import bridge_small_gaps_fast, bridge_small_gaps
+    from encoder.ROI.thin_regions2 import remove_thin_structures_optimized
     assert extract_regions.__module__ == "roibasedimagecompression_amd.api.roi" and extract_roi_nonroi.__module__ == extract_regions.__module__
-    with pytest.raises(NotImplementedError):
-        get_regions(None)                                   # the edge / morphology heuristics: the reference's own
-    with pytest.raises(NotImplementedError):
-        process_and_unify_borders(None, None, None)
+    assert get_edge_map.__module__ == "roibasedimagecompression_amd.api.edges" and compute_local_density.__module__ == get_edge_map.__module__
+    for fn in (get_regions, process_and_unify_borders, remove_small_regions, connect_by_closing_fast, bridge_small_gaps_fast, remove_thin_structures_optimized):
+        assert fn.__module__ == "roibasedimagecompression_amd.api.roi_chain"
+    for helper in (visualize_roi_nonroi_comparison, connect_nearby_pixels, bridge_small_gaps):   # matplotlib / unused variants: the reference's own
+        with pytest.raises(NotImplementedError):
+            helper(None)
     assert calculate_split_score.__module__ == "roibasedimagecompression_amd.api.split_score"
     assert enhanced_slic_with_texture.__module__ == "roibasedimagecompression_amd.api.slic"
     with pytest.raises(NotImplementedError):

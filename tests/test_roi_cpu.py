@@ -93,3 +93,27 @@ def test_extract_regions_and_buffer_zone():
         y0, x0, y1, x1 = r["bbox"]
         assert r["bbox_mask"].shape == (y1 - y0, x1 - x0) and r["bbox_mask"].sum() == r["area"] == len(r["coords"])
         assert np.array_equal(r["full_image"], img * r["mask"][..., None])
+
+
+def test_edge_front_end_restatements():
+    """known answers of the OpenCV restatements that need no OpenCV to verify"""
+    px = np.array([[[255, 255, 255], [255, 0, 0], [0, 255, 0], [0, 0, 255], [0, 0, 0], [12, 200, 77]]], np.uint8)
+    assert O.cv_rgb2gray(px).tolist() == [[255, 76, 150, 29, 0, 130]]                    # cvtColor's documented 8-bit results
+    step = np.zeros((12, 16), np.uint8)
+    step[:, 8:] = 200
+    gx, gy = O.cv_sobel3(step, "reflect")
+    assert (gy == 0).all() and (gx[:, 7] == 800).all() and (gx[:, 8] == 800).all() and (gx[:, :7] == 0).all()
+    nm = O.cv_canny_nms(step)
+    assert (nm[:, 7] == 800).all() and (nm[:, 8] == 0).all() and nm.sum() == 800 * 12     # "> left and >= right": the left pixel of the pair wins
+    assert np.array_equal(O.cv_canny(step, 100, 200) > 0, nm > 0) and not O.cv_canny(step, 100, 900).any()
+    # hysteresis: a weak run touching a strong pixel survives as a whole, an isolated weak run does not
+    nm2 = np.zeros((5, 12), np.uint16)
+    nm2[1, 1:6] = 60
+    nm2[1, 6] = 300
+    nm2[3, 8:11] = 60
+    out = O.cv_canny(np.zeros((5, 12), np.uint8), 50, 200, nm2)
+    assert out[1, 1:7].all() and not out[3].any()
+    bim = np.r_[np.full(500, 40), np.full(300, 200)].astype(np.uint8).reshape(20, 40)
+    assert 40 <= O.cv_otsu(bim) < 200
+    d = O.local_density(np.pad(np.full((1, 1), 255, np.uint8), 3), 3)
+    assert d.dtype == np.float32 and d[3, 3] == np.float32(1) / np.float32(9) and d[0, 0] == 0 and (d > 0).sum() == 9
