@@ -1481,6 +1481,26 @@ def get_edge_map(image_rgb):
     return cv_canny(image_rgb, lo, hi)
 
 
+def get_edge_map_fast(image_rgb):
+    """edges.py:200-233 with compute_fast_canny_thresholds('percentile_fast') (edges.py:235-255,292-298)"""
+    gray = cv_rgb2gray(image_rgb)
+    low = max(10, min(100, int(np.percentile(gray, 25) * 0.7)))
+    high = max(50, min(200, int(np.percentile(gray, 75) * 1.3)))
+    if high < low * 2:
+        high = low * 2
+    if high > 255:
+        high = 255
+    low = max(10, min(100, low))
+    high = max(low * 2, min(200, high))
+    gx, gy = cv_sobel3(gray, "reflect")
+    mag = np.sqrt(gx.astype(np.float64) ** 2 + gy.astype(np.float64) ** 2)
+    nz = mag[mag > 0]
+    if len(nz) > 0:
+        low = int((low + np.percentile(nz, 10)) / 2)
+        high = int((high + np.percentile(nz, 90)) / 2)
+    return cv_canny(gray, low, high)
+
+
 def box_counts(binary_map, kernel_size):
     """number of non-zero pixels in the k x k window around every pixel, BORDER_REFLECT_101"""
     nz = np.pad(np.asarray(binary_map) != 0, kernel_size // 2, mode="reflect").astype(np.int64)

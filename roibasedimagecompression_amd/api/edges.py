@@ -92,7 +92,7 @@ class EdgeAnalysis:
         self.rh = rh or default_context()
         image = np.ascontiguousarray(image, dtype=np.uint8)
         self.image = image
-        dev = torch.from_numpy(image).to(self.rh.device)
+        dev = torch.from_numpy(np.array(image, dtype=np.uint8, order="C")).to(self.rh.device)
         if image.ndim == 3:
             self.rgb = dev
             self.gray, self.hist = self.rh.edges_gray(dev)

@@ -173,5 +173,5 @@ def extract_roi_nonroi(original_image, region_map, buffer_size=3, rh=None):
         non_image[~non_mask] = 0
         return roi_image, non_image, roi_mask, non_mask
     rm = np.where(region_map == 1, 1, np.where(region_map == 0, 0, 2)).astype(np.uint8)
-    ri, ni, m1, m0 = rh.roi_buffer(torch.from_numpy(rm).to(rh.device), torch.from_numpy(original_image).to(rh.device), buffer_size)
+    ri, ni, m1, m0 = rh.roi_buffer(torch.from_numpy(rm).to(rh.device), torch.from_numpy(np.array(original_image, dtype=np.uint8, order="C")).to(rh.device), buffer_size)
     return ri.cpu().numpy(), ni.cpu().numpy(), m1.cpu().numpy(), m0.cpu().numpy()

@@ -61,7 +61,7 @@ def calculate_split_score(region_image, mask=None):
         if m.sum() < 100:
             return 0.0, 0.0, 0.0
         d_mask = torch.from_numpy(m.view(np.uint8)).to(rh.device)
-    sums, lbp_hist, gray_hist = rh.split_stats(torch.from_numpy(img).to(rh.device), d_mask)
+    sums, lbp_hist, gray_hist = rh.split_stats(torch.from_numpy(np.array(img, dtype=np.uint8, order="C")).to(rh.device), d_mask)
     if sums[0] < 100:
         return 0.0, 0.0, 0.0
     return scores_from_stats(sums, lbp_hist, gray_hist)

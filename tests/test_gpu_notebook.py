@@ -1,0 +1,38 @@
+"""The reference's end-to-end flow (encoder/compression/test.py:77-151, the script twin of rhccq.ipynb: the flow that wrote the
+images/rhccq_20_10/*.rhccq artefacts) driven through the mirrored modules ONLY -- ROI detection, region extraction, split score +
+masked SLIC, the three clustering levels, the container -- from the PNG to the .rhccq file and back.  GPU only.
+
+What can be compared with the reference here is Tier B: the stages upstream of the hot path are parity-unpinned restatements of
+OpenCV / scikit-image (neither library exists in the build container), so the artefacts the reference ships for the same image and
+settings (tests/golden/*.rhccq, data) are the yardstick: PSNR against the original, palette size, file size."""
+import os
+import sys
+
+import numpy as np
+import pytest
+
+pytestmark = pytest.mark.gpu
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+G = os.path.join(ROOT, "tests", "golden")
+
+
+@pytest.mark.parametrize("png,artefact,ref_colours,ref_psnr", [("Lenna.png", "Lenna_compressed_20_10.rhccq", 146, 33.26),
+                                                              ("kodak_23.png", "compressed_23.rhccq", 106, 28.32)])
+def test_script_flow_vs_the_reference_artefact(png, artefact, ref_colours, ref_psnr, tmp_path):
+    sys.path.insert(0, os.path.join(ROOT, "tools"))
+    try:
+        import notebook_flow
+    finally:
+        sys.path.pop(0)
+    out = str(tmp_path / "out.rhccq")
+    rep = notebook_flow.report(os.path.join(G, png), os.path.join(G, artefact), out)
+    ref, mine = rep["reference_artefact"], rep["this_build"]
+    assert ref["colours"] == ref_colours and abs(ref["psnr"] - ref_psnr) < 0.005          # the artefact decodes to what it always did
+    assert rep["roi_regions"] >= 1 and 0.05 < rep["region_map_roi_fraction"] < 0.9
+    # observed: Lenna 139 colours / 33.23 dB / 118 807 B (artefact 146 / 33.26 / 122 736); kodak 23 145 / 28.47 / 72 635 (106 / 28.32 / 73 921)
+    assert abs(mine["psnr"] - ref["psnr"]) <= 0.3, rep
+    assert abs(mine["bytes"] - ref["bytes"]) <= 0.06 * ref["bytes"], rep
+    assert 0.6 * ref["colours"] <= mine["colours"] <= 1.5 * ref["colours"], rep
+    # deterministic: the same file again
+    rep2 = notebook_flow.report(os.path.join(G, png), os.path.join(G, artefact), str(tmp_path / "again.rhccq"))
+    assert open(out, "rb").read() == open(str(tmp_path / "again.rhccq"), "rb").read() and rep2["this_build"] == mine

@@ -1,0 +1,68 @@
+"""diagnostic: the reference's end-to-end flow (encoder/compression/test.py = rhccq.ipynb cells 6-16) driven through the mirrored modules only, image file -> .rhccq,
+compared with the artefact the reference ships for the same image and settings:  python tools/notebook_flow.py [png] [artefact]"""
+import os, sys, time
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+import numpy as np
+from PIL import Image
+
+
+def notebook_flow(image_rgb, roi_quality=20, nonroi_quality=10, out_path=None):
+    """encoder/compression/test.py:77-151 (the script twin of the notebook: the flow that wrote images/rhccq_20_10/*.rhccq) with the
+    reference's import lines.  (The notebook's own cell 6 inlines the ROI chain and, through a uint8 overflow in
+    `(connected * 255).astype(np.uint8)`, feeds 0 / 1 / 255 images to the later steps; the script calls get_regions.)"""
+    from encoder.ROI.roi import get_regions, extract_regions
+    from encoder.compression.subregions import subregion_quantization
+    from encoder.compression.regions import region_quantization
+    from encoder.compression.image import quantize_image
+    from encoder.compression.compression import lossless_compress_optimized, save_compressed
+    t = {}
+    t0 = time.perf_counter()
+    unified, region_map, roi_image, nonroi_image, roi_mask, nonroi_mask = get_regions(image_rgb)
+    roi_regions, nonroi_regions = extract_regions(image_rgb, roi_mask, nonroi_mask)
+    t["roi_stage"] = time.perf_counter() - t0
+    t0 = time.perf_counter()
+    roi_components = subregion_quantization(image_rgb, roi_regions, quality=roi_quality, subregion_type="ROI", debug=False)
+    nonroi_components = subregion_quantization(image_rgb, nonroi_regions, quality=nonroi_quality, subregion_type="nonROI", debug=False)
+    t["level1"] = time.perf_counter() - t0
+    t0 = time.perf_counter()
+    H, W = image_rgb.shape[:2]
+    q2r, q2n = min(roi_quality * 2, 100), min(nonroi_quality * 2, 100)
+    try:
+        roi2 = region_quantization(roi_components, quality=q2r, original_image_height=H, original_image_width=W)
+    except Exception:                                       # the notebook's bare `except: roi_components = []`
+        roi2 = []
+    try:
+        non2 = region_quantization(nonroi_components, quality=q2n, original_image_height=H, original_image_width=W)
+    except Exception:
+        non2 = []
+    final = quantize_image(roi2 + non2, quality=min(q2r + q2n, 100), original_image_height=H, original_image_width=W)
+    t["levels23"] = time.perf_counter() - t0
+    pkg = lossless_compress_optimized(final["palette"], final["indices"], final["shape"])
+    if out_path:
+        save_compressed(pkg, out_path)
+    return final, pkg, {"region_map_roi_fraction": float(region_map.mean()), "roi_regions": len(roi_regions), "nonroi_regions": len(nonroi_regions),
+                        "seconds": {k: round(v, 3) for k, v in t.items()}}
+
+
+def report(png, artefact, out_path):
+    from decoder.uncompression.uncompression import load_compressed, lossless_decompress, decompress_color_quantization
+    img = np.asarray(Image.open(png).convert("RGB"), dtype=np.uint8)
+    final, pkg, info = notebook_flow(img, out_path=out_path)
+    rec = np.asarray(decompress_color_quantization(lossless_decompress(load_compressed(out_path)))["image"])
+
+    def stats(a):
+        mse = float(np.mean((a.astype(np.float64) - img.astype(np.float64)) ** 2))
+        return {"colours": int(len(np.unique(a.reshape(-1, 3), axis=0))), "psnr": round(10 * np.log10(255.0 ** 2 / mse), 2)}
+    ref = np.asarray(decompress_color_quantization(lossless_decompress(load_compressed(artefact)))["image"])
+    return {"image": os.path.basename(png), "this_build": dict(stats(rec), bytes=os.path.getsize(out_path)),
+            "reference_artefact": dict(stats(ref), bytes=os.path.getsize(artefact)), **info}
+
+
+if __name__ == "__main__":
+    g = os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "tests", "golden")
+    pairs = [(os.path.join(g, "Lenna.png"), os.path.join(g, "Lenna_compressed_20_10.rhccq")), (os.path.join(g, "kodak_23.png"), os.path.join(g, "compressed_23.rhccq"))]
+    if len(sys.argv) > 2:
+        pairs = [(sys.argv[1], sys.argv[2])]
+    os.makedirs("gpurun_out", exist_ok=True)
+    for png, art in pairs:
+        print(report(png, art, os.path.join("gpurun_out", "flow_" + os.path.basename(png) + ".rhccq")), flush=True)
