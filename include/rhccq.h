@@ -346,6 +346,10 @@ int rhccq_binary_sobel(rhccq_ctx* ctx, const uint8_t* mask, int32_t H, int32_t W
 int rhccq_lut_u8(rhccq_ctx* ctx, const uint8_t* in, const uint8_t* lut256, int64_t n, uint8_t* out);
 int rhccq_label_sum(rhccq_ctx* ctx, const int32_t* labels, const void* values, int32_t value_bytes, int64_t n_pixels, int32_t n_labels,
                     uint64_t* sums);
+/* hist (device u64[n_bins], n_bins <= 4096): histogram of the u16 plane over the pixels where mask is set (larger values ignored);
+ * rhccq_value_mask: out = 255 where values[p] >= min_value and (mask is NULL or set), else 0 */
+int rhccq_masked_hist(rhccq_ctx* ctx, const uint8_t* mask, const uint16_t* values, int64_t n_pixels, int32_t n_bins, uint64_t* hist);
+int rhccq_value_mask(rhccq_ctx* ctx, const uint8_t* mask, const uint16_t* values, int64_t n_pixels, int32_t min_value, uint8_t* out);
 
 /* ---- EXTENSION (no reference counterpart; named by BASELINE.json's north_star only): pixel-space DBSCAN ----
  * Features (x, y, L, a, b); q is a neighbour of p when dx^2 + dy^2 <= radius^2 (radius 0..4) and

@@ -81,6 +81,8 @@ PROTOTYPES = {
     "rhccq_binary_sobel": (c_int32, [c_void_p, c_void_p, c_int32, c_int32, c_void_p, c_void_p]),
     "rhccq_lut_u8": (c_int32, [c_void_p, c_void_p, c_void_p, c_int64, c_void_p]),
     "rhccq_label_sum": (c_int32, [c_void_p, c_void_p, c_void_p, c_int32, c_int64, c_int32, c_void_p]),
+    "rhccq_masked_hist": (c_int32, [c_void_p, c_void_p, c_void_p, c_int64, c_int32, c_void_p]),
+    "rhccq_value_mask": (c_int32, [c_void_p, c_void_p, c_void_p, c_int64, c_int32, c_void_p]),
     "rhccq_mt_uniforms": (c_int32, [c_void_p, c_void_p, c_int64, c_int64, c_void_p]),
     "rhccq_mbk_order_bytes": (c_int64, [c_int64]),
     "rhccq_mbk_order": (c_int32, [c_void_p, c_void_p, C.POINTER(MbkProblem), c_int32, c_void_p, c_void_p, c_void_p, c_int64]),

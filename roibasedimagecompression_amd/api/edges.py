@@ -175,8 +175,8 @@ def compute_adaptive_canny_thresholds(image, method="otsu", sensitivity=1.0):
     return EdgeAnalysis(image).thresholds(method, sensitivity)
 
 
-def find_best_edges_by_quality(image_rgb, debug=False, _analysis=None):
-    a = _analysis or EdgeAnalysis(image_rgb)
+def _best_thresholds(a, debug=False):
+    """the threshold search of edges.py:40-71 on one EdgeAnalysis: -> (low, high, method)"""
     best_score, best = -1, None
     cache = {}
     for method in ("otsu", "percentile", "gradient", "hybrid"):
@@ -191,14 +191,24 @@ def find_best_edges_by_quality(image_rgb, debug=False, _analysis=None):
                 best_score, best = score, (lo, hi, method)
     if best is None:
         raise UnboundLocalError("find_best_edges_by_quality: no threshold pair produced an edge")
-    lo, hi, method = best
+    return best
+
+
+def find_best_edges_by_quality(image_rgb, debug=False):
+    a = EdgeAnalysis(image_rgb)
+    lo, hi, method = _best_thresholds(a, debug)
     return a.canny(lo, hi).cpu().numpy(), lo, hi, method
 
 
+def edge_map_resident(image_rgb, rh=None):
+    """get_edge_map with the result left on the device: -> (EdgeAnalysis, uint8[H,W] device plane, 0 / 255)"""
+    a = EdgeAnalysis(image_rgb, rh)
+    lo, hi, _ = _best_thresholds(a)
+    return a, a.canny(lo, hi, colour=True)
+
+
 def get_edge_map(image_rgb):
-    a = EdgeAnalysis(image_rgb)
-    _, lo, hi, _ = find_best_edges_by_quality(image_rgb, _analysis=a)
-    return a.canny(lo, hi, colour=True).cpu().numpy()
+    return edge_map_resident(image_rgb)[1].cpu().numpy()
 
 
 def evaluate_edge_quality(edges, gray):

@@ -272,15 +272,8 @@ def directional_region_unification(binary_image, border_sensitivity=0.3, min_reg
     return cleaned, (cleaned > 0).astype(np.uint8)
 
 
-def process_and_unify_borders(edge_map, edge_density, original_image, density_threshold=0.3, border_sensitivity=0.3, min_region_size=30,
-                              max_gap_to_bridge=10, noise_aggressiveness=2, unification_strength=0.4):
-    """roi.py:527-607 -> (unified_borders, region_map, roi_image, nonroi_image, roi_mask, nonroi_mask)"""
-    edge_map, edge_density = np.asarray(edge_map), np.asarray(edge_density)
-    borders = edge_map.copy()
-    borders[~(edge_density > density_threshold)] = 0
-    d = _Dev()
-    m = d.up(borders > 0)
-    m = d.remove_thin(m, 0.10, 25)
+def _unify_borders(d, borders_dev, original_image):
+    m = d.remove_thin(borders_dev, 0.10, 25)
     m = d.remove_small_noise(m, 75)
     m = d.rh.morph_close(m, ellipse_half_widths(11))
     m = d.bridge(m, 100, 0.2, 15, 25)
@@ -289,10 +282,28 @@ def process_and_unify_borders(edge_map, edge_density, original_image, density_th
     return (unified, region_map) + tuple(_roi.extract_roi_nonroi(original_image, region_map, rh=d.rh))
 
 
+def process_and_unify_borders(edge_map, edge_density, original_image, density_threshold=0.3, border_sensitivity=0.3, min_region_size=30,
+                              max_gap_to_bridge=10, noise_aggressiveness=2, unification_strength=0.4):
+    """roi.py:527-607 -> (unified_borders, region_map, roi_image, nonroi_image, roi_mask, nonroi_mask)"""
+    edge_map, edge_density = np.asarray(edge_map), np.asarray(edge_density)
+    borders = edge_map.copy()
+    borders[~(edge_density > density_threshold)] = 0
+    d = _Dev()
+    return _unify_borders(d, d.up(borders > 0), original_image)
+
+
 def get_regions(image_rgb):
-    """roi.py:14-40"""
+    """roi.py:14-40.  Edge map, 3x3 densities, the automatic threshold and the chain stay on the device: the threshold
+    mean(density at the edge pixels) / 100 comes from the histogram of the window counts at the edge pixels (the densities take ten
+    values, the smallest non-zero one is 1/9, the threshold a few thousandths: its last bits cannot move the mask)."""
     image_rgb = np.asarray(image_rgb)
-    edge_map = _edges.get_edge_map(image_rgb)
-    density = _edges.compute_local_density(edge_map, kernel_size=3)
-    threshold = _edges.suggest_automatic_threshold(density, edge_map, method="mean") / 100
-    return process_and_unify_borders(edge_map, density, image_rgb, density_threshold=threshold, min_region_size=_roi.min_region_size(image_rgb))
+    d = _Dev()
+    _, edge = _edges.edge_map_resident(image_rgb, d.rh)
+    counts = d.rh.box_count(edge, 3)
+    hist = d.rh.masked_hist(edge, counts, 10)
+    table = _density_table(3)
+    n_edge = int(hist.sum())
+    threshold = (float(np.dot(hist, table.astype(np.float64))) / n_edge if n_edge else 0.1) / 100
+    above = np.flatnonzero(table > np.float32(threshold))
+    borders = d.rh.value_mask(counts, int(above[0]) if len(above) else 10, edge)
+    return _unify_borders(d, borders, image_rgb)

@@ -22,15 +22,25 @@ namespace rhccq {
 
 constexpr int kCclStat = 6;   // area, min x, max x, min y, max y, ordering key
 
-__device__ __forceinline__ int ccl_find(const int32_t* parent, int x) {
+// walk to the root; kHalve: path halving on the way -- a node that is not a root is re-pointed at its grandparent (still an
+// ancestor; only roots are ever compare-and-swapped, and a node that stopped being a root never becomes one again, so the plain
+// re-pointing cannot undo a link).  The flatten pass walks WITHOUT halving: a late re-pointing by another wave could otherwise
+// overwrite the final parent[p] = root with an older ancestor.
+template <bool kHalve>
+__device__ __forceinline__ int ccl_find(int32_t* parent, int x) {
   int p = __hip_atomic_load(parent + x, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-  while (p != x) { x = p; p = __hip_atomic_load(parent + x, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); }
+  while (p != x) {
+    const int gp = __hip_atomic_load(parent + p, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    if (kHalve && gp != p) __hip_atomic_store(parent + x, gp, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    x = p;
+    p = gp;
+  }
   return x;
 }
 __device__ __forceinline__ void ccl_union(int32_t* parent, int a, int b) {
   while (true) {
-    a = ccl_find(parent, a);
-    b = ccl_find(parent, b);
+    a = ccl_find<true>(parent, a);
+    b = ccl_find<true>(parent, b);
     if (a == b) return;
     if (a > b) { const int s = a; a = b; b = s; }
     const int old = atomicCAS(&parent[b], b, a);          // the larger root goes under the smaller: a root is its component's first pixel
@@ -130,7 +140,7 @@ __global__ __launch_bounds__(256) void ccl_flatten_kernel(int32_t* parent, int H
   const uint64_t b = __ballot(fg);
   const bool is_start = fg && (lane == 0 || !((b >> (lane - 1)) & 1ull));
   int r = -1;
-  if (is_start) r = ccl_find(parent, p);
+  if (is_start) r = ccl_find<false>(parent, p);
   const uint64_t zeros_below = ~b & ((1ull << lane) - 1ull);
   const int start = zeros_below ? 64 - __clzll((long long)zeros_below) : 0;
   const int rs = __shfl(r, start);

@@ -158,22 +158,66 @@ __global__ __launch_bounds__(256) void lut_u8_kernel(const uint8_t* __restrict__
   if (p < n) out[p] = lut[in[p]];
 }
 
-// ---- per label: sum of a u16 plane (box counts) or of an int32 plane (fixed-point distances), int64 accumulators
+// ---- per label: sum of a u16 plane (box counts) or of an int32 plane (fixed-point distances), int64 accumulators.  A workgroup
+// walks a contiguous chunk of pixels and gathers its sums in an LDS table keyed by label (the background and the large
+// components would otherwise serialise a hundred thousand atomics on one address: 69 ms at 4K); only the occupied slots reach
+// global memory
+constexpr int kLsSlots = 256, kLsEmpty = -1;
 template <typename T>
-__global__ __launch_bounds__(256) void label_sum_kernel(const int32_t* __restrict__ labels, const T* __restrict__ val, long long n, unsigned long long* sums) {
-  const long long p = (long long)blockIdx.x * 256 + threadIdx.x;
+__global__ __launch_bounds__(256) void label_sum_kernel(const int32_t* __restrict__ labels, const T* __restrict__ val, long long n, long long chunk,
+                                                        unsigned long long* sums) {
+  __shared__ int s_key[kLsSlots];
+  __shared__ unsigned long long s_sum[kLsSlots];
+  s_key[threadIdx.x] = kLsEmpty;
+  s_sum[threadIdx.x] = 0;
+  __syncthreads();
   const int lane = threadIdx.x & 63;
-  const int l = p < n ? labels[p] : -1;
-  const unsigned long long in = __ballot(l >= 0);
-  if (!in) return;
-  unsigned long long v = l >= 0 ? (unsigned long long)val[p] : 0ull;
-  const int lead = __shfl(l, __builtin_ctzll(in));
-  if (__ballot(l >= 0 && l != lead) == 0) {
-    for (int o = 32; o > 0; o >>= 1) v += __shfl_down(v, o, 64);
-    if (lane == 0 && v) atomicAdd(&sums[lead], v);
-  } else if (l >= 0 && v) {
-    atomicAdd(&sums[l], v);
+  const long long begin = (long long)blockIdx.x * chunk, end = min(n, begin + chunk);
+  for (long long base = begin; base < end; base += 256) {
+    const long long p = base + threadIdx.x;
+    const int l = p < end ? labels[p] : -1;
+    const unsigned long long v = l >= 0 ? (unsigned long long)val[p] : 0ull;
+    unsigned long long todo = __ballot(l >= 0);
+    while (todo) {
+      const int first = __builtin_ctzll(todo);
+      const int lead = __shfl(l, first);
+      const unsigned long long same = __ballot(l == lead);
+      todo &= ~same;
+      unsigned long long part = l == lead ? v : 0ull;
+      for (int o = 32; o > 0; o >>= 1) part += __shfl_down(part, o, 64);
+      if (lane == 0 && part) {
+        int slot = (int)(((unsigned)lead * 2654435761u) >> 24);
+        bool done = false;
+        for (int probe = 0; probe < 8 && !done; ++probe, slot = (slot + 1) & (kLsSlots - 1)) {
+          const int old = atomicCAS(&s_key[slot], kLsEmpty, lead);
+          if (old == kLsEmpty || old == lead) { atomicAdd(&s_sum[slot], part); done = true; }
+        }
+        if (!done) atomicAdd(&sums[lead], part);
+      }
+    }
   }
+  __syncthreads();
+  if (s_key[threadIdx.x] != kLsEmpty && s_sum[threadIdx.x]) atomicAdd(&sums[s_key[threadIdx.x]], s_sum[threadIdx.x]);
+}
+
+// ---- histogram (int64[n_bins]) of a u16 plane over the pixels where `mask` is set; out = 255 where values[p] >= min_value and
+// (mask is NULL or set)
+__global__ __launch_bounds__(256) void masked_hist_kernel(const uint8_t* __restrict__ mask, const uint16_t* __restrict__ values, long long n, int n_bins,
+                                                          unsigned long long* hist) {
+  extern __shared__ unsigned int s_h[];
+  for (int i = threadIdx.x; i < n_bins; i += 256) s_h[i] = 0;
+  __syncthreads();
+  for (long long p = (long long)blockIdx.x * 256 + threadIdx.x; p < n; p += (long long)gridDim.x * 256)
+    if (mask[p] != 0 && values[p] < n_bins) atomicAdd(&s_h[values[p]], 1u);
+  __syncthreads();
+  for (int i = threadIdx.x; i < n_bins; i += 256)
+    if (s_h[i]) atomicAdd(&hist[i], (unsigned long long)s_h[i]);
+}
+
+__global__ __launch_bounds__(256) void value_mask_kernel(const uint8_t* __restrict__ mask, const uint16_t* __restrict__ values, long long n, int min_value,
+                                                         uint8_t* __restrict__ out) {
+  const long long p = (long long)blockIdx.x * 256 + threadIdx.x;
+  if (p < n) out[p] = ((int)values[p] >= min_value && (!mask || mask[p] != 0)) ? 255 : 0;
 }
 
 }  // namespace rhccq
@@ -241,11 +285,31 @@ int rhccq_label_sum(rhccq_ctx* ctx, const int32_t* labels, const void* values, i
   if (!ctx || !labels || !values || !sums || n_pixels <= 0 || n_labels < 0 || (value_bytes != 2 && value_bytes != 4))
     return rhccq_fail(ctx, RHCCQ_E_ARG, "label_sum: bad argument");
   RHCCQ_HIP(ctx, hipMemsetAsync(sums, 0, sizeof(uint64_t) * ((size_t)n_labels + 1), ctx->stream));
-  const unsigned grid = (unsigned)((n_pixels + 255) / 256);
+  long long chunk = (((n_pixels + 2047) / 2048) + 255) & ~255ll;        // <= 2048 workgroups, whole 256-pixel rounds each
+  if (chunk < 4096) chunk = 4096;
+  const unsigned grid = (unsigned)((n_pixels + chunk - 1) / chunk);
   if (value_bytes == 2)
-    hipLaunchKernelGGL(label_sum_kernel<uint16_t>, dim3(grid), dim3(256), 0, ctx->stream, labels, (const uint16_t*)values, (long long)n_pixels, (unsigned long long*)sums);
+    hipLaunchKernelGGL(label_sum_kernel<uint16_t>, dim3(grid), dim3(256), 0, ctx->stream, labels, (const uint16_t*)values, (long long)n_pixels, chunk,
+                       (unsigned long long*)sums);
   else
-    hipLaunchKernelGGL(label_sum_kernel<int32_t>, dim3(grid), dim3(256), 0, ctx->stream, labels, (const int32_t*)values, (long long)n_pixels, (unsigned long long*)sums);
+    hipLaunchKernelGGL(label_sum_kernel<int32_t>, dim3(grid), dim3(256), 0, ctx->stream, labels, (const int32_t*)values, (long long)n_pixels, chunk,
+                       (unsigned long long*)sums);
+  RHCCQ_LAUNCH_CHECK(ctx);
+  return 0;
+}
+
+int rhccq_masked_hist(rhccq_ctx* ctx, const uint8_t* mask, const uint16_t* values, int64_t n_pixels, int32_t n_bins, uint64_t* hist) {
+  if (!ctx || !mask || !values || !hist || n_pixels <= 0 || n_bins <= 0 || n_bins > 4096) return rhccq_fail(ctx, RHCCQ_E_ARG, "masked_hist: bad argument");
+  RHCCQ_HIP(ctx, hipMemsetAsync(hist, 0, sizeof(uint64_t) * (size_t)n_bins, ctx->stream));
+  const unsigned grid = (unsigned)((n_pixels + 255) / 256 < 1024 ? (n_pixels + 255) / 256 : 1024);
+  hipLaunchKernelGGL(masked_hist_kernel, dim3(grid), dim3(256), (size_t)n_bins * 4, ctx->stream, mask, values, (long long)n_pixels, n_bins, (unsigned long long*)hist);
+  RHCCQ_LAUNCH_CHECK(ctx);
+  return 0;
+}
+
+int rhccq_value_mask(rhccq_ctx* ctx, const uint8_t* mask, const uint16_t* values, int64_t n_pixels, int32_t min_value, uint8_t* out) {
+  if (!ctx || !values || !out || n_pixels <= 0) return rhccq_fail(ctx, RHCCQ_E_ARG, "value_mask: bad argument");
+  hipLaunchKernelGGL(value_mask_kernel, dim3((unsigned)((n_pixels + 255) / 256)), dim3(256), 0, ctx->stream, mask, values, (long long)n_pixels, min_value, out);
   RHCCQ_LAUNCH_CHECK(ctx);
   return 0;
 }

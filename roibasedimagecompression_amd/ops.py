@@ -822,6 +822,18 @@ class Rhccq:
         self._check(self.lib.rhccq_lut_u8(self.ctx, self._p(plane), self._p(self.dev(np.asarray(lut256, np.uint8))), plane.numel(), self._p(out)), "lut_u8")
         return out
 
+    def masked_hist(self, mask, values, n_bins):
+        """-> np.int64[n_bins]: histogram of the uint16 plane (int16 storage) over the pixels where mask is set"""
+        hist = self.empty((n_bins,), torch.int64)
+        self._check(self.lib.rhccq_masked_hist(self.ctx, self._p(mask), self._p(values), values.numel(), int(n_bins), self._p(hist)), "masked_hist")
+        return hist.cpu().numpy()
+
+    def value_mask(self, values, min_value, mask=None):
+        """-> uint8 plane: 255 where values >= min_value (and mask set, when given)"""
+        out = self.empty(tuple(values.shape), torch.uint8)
+        self._check(self.lib.rhccq_value_mask(self.ctx, self._p(mask), self._p(values), values.numel(), int(min_value), self._p(out)), "value_mask")
+        return out
+
     def label_sum(self, labels, n, values):
         """-> np.uint64[n + 1]: per label (0 = background included) the sum of a uint16 (int16 storage) or non-negative int32 plane"""
         sums = self.empty((n + 1,), torch.int64)
