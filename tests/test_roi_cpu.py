@@ -117,3 +117,37 @@ def test_edge_front_end_restatements():
     assert 40 <= O.cv_otsu(bim) < 200
     d = O.local_density(np.pad(np.full((1, 1), 255, np.uint8), 3), 3)
     assert d.dtype == np.float32 and d[3, 3] == np.float32(1) / np.float32(9) and d[0, 0] == 0 and (d > 0).sum() == 9
+
+
+def test_host_arithmetic_of_the_edge_front_end():
+    """the host half of api/edges.py and api/roi_chain.py needs no GPU: percentiles and gradient statistics from histograms vs numpy on
+    the expanded data, Otsu vs the oracle, OpenCV's ellipse, the density tables and count thresholds"""
+    from roibasedimagecompression_amd.api import edges as E
+    from roibasedimagecompression_amd.api import roi_chain as C
+    rng = np.random.default_rng(8)
+    for n in (1, 2, 7, 1000, 4321):
+        x = np.sort(rng.integers(0, 60, n))
+        v, c = np.unique(x, return_counts=True)
+        for q in (0, 10, 25, 50, 70, 75, 90, 100):
+            assert E._percentile(v.astype(np.float64), c, q) == np.percentile(x.astype(np.float64), q), (n, q)
+        assert E._percentile(v, c, 25) == np.percentile(x.astype(np.uint8), 25)
+    gray = rng.integers(0, 256, (60, 80)).astype(np.uint8)
+    gray[:, :40] //= 3
+    assert E._otsu(np.bincount(gray.ravel(), minlength=256)) == O.cv_otsu(gray)
+    gx, gy = O.cv_sobel3(gray, "reflect")
+    m2 = (gx * gx + gy * gy).ravel()
+    v, c = np.unique(m2, return_counts=True)
+    g = E._Gradient(v, c, m2.size)
+    mag = np.sqrt(gx.astype(np.float64) ** 2 + gy.astype(np.float64) ** 2)
+    assert abs(g.mean() - np.mean(mag)) < 1e-9 and abs(g.std() - np.std(mag)) < 1e-9
+    assert g.percentile_nonzero(70) == np.percentile(mag[mag > 0], 70) and g.percentile_nonzero(90) == np.percentile(mag[mag > 0], 90)
+    for k in (1, 3, 5, 11, 15, 21):
+        assert C.ellipse_half_widths(k) == O.cv_ellipse_half_widths(k)
+    assert C.ellipse_half_widths(5) == [0, 2, 2, 2, 0]                      # OpenCV's 5x5 ellipse: 00100 / 11111 / 11111 / 11111 / 00100
+    one = np.zeros((9, 9), np.uint8)
+    one[4, 4] = 255
+    for k in (3, 5, 15):
+        t = C._density_table(k)
+        d = O.local_density(one, k)
+        assert t[1] == d[4, 4] and t[0] == 0 and len(t) == k * k + 1
+    assert C._count_threshold(25, 0.2) == 126 and C._count_threshold(3, 0.0041) == 1 and C._count_threshold(15, 0.2, np.float64) == 45
