@@ -322,6 +322,8 @@ int rhccq_edges_above(rhccq_ctx* ctx, const uint16_t* nm, int64_t n_pixels, int3
 int rhccq_label_reduce(rhccq_ctx* ctx, const int32_t* labels, const uint16_t* val16, const uint8_t* val8, int64_t n_pixels,
                        int32_t n_labels, uint64_t* red);
 int rhccq_box_count(rhccq_ctx* ctx, const uint8_t* mask, int32_t H, int32_t W, int32_t kernel_size, uint16_t* out);
+/* the same window, summing the pixel VALUES (maps that are not 0 / one value: the notebook's 0 / 1 / 255 planes) */
+int rhccq_box_sum(rhccq_ctx* ctx, const uint8_t* plane, int32_t H, int32_t W, int32_t kernel_size, uint32_t* out);
 
 /* ---- ROI stage, clean-up chain (encoder/ROI/{roi,small_regions,small_gaps,thin_regions2}.py): binary-mask operators.  PARITY
  * UNPINNED (OpenCV absent from the build container); masks are device u8 planes, set = non-zero, outputs 0 / 255.
@@ -329,8 +331,8 @@ int rhccq_box_count(rhccq_ctx* ctx, const uint8_t* mask, int32_t H, int32_t W, i
  *   radius <= 15), nothing set outside the image (cv2.dilate's default border); invert_in / invert_out = the erosion by the same
  *   symmetric element with cv2.erode's border rule (outside = set).  cv2.morphologyEx(MORPH_CLOSE) = dilate, then erode.
  * rhccq_mask_op: out = a | b (op 0), a & b (1), a & ~b (2), ~a (3).
- * rhccq_gap_bridge = bridge_small_gaps_fast (small_gaps.py:221-271): an unset pixel whose window count (rhccq_box_count) is at
- *   least min_count is set when both opposite rays of one of the four direction pairs meet a set pixel within `reach` steps.
+ * rhccq_gap_bridge = bridge_small_gaps_fast (small_gaps.py:221-271): an unset pixel whose window count (rhccq_box_count; or window
+ *   sum, rhccq_box_sum) is at least min_count is set when both opposite rays of one of the four direction pairs meet a set pixel within `reach` steps.
  * rhccq_dist_chamfer = cv2.distanceTransform(mask, DIST_L2, 3) in OpenCV's fixed point (16 fractional bits; hz_tmp: u16[H*W]).
  * rhccq_binary_sobel: m2 (device u8[H*W]) = gx^2 + gy^2 of the 3x3 Sobel of the 0/1 image (BORDER_REFLECT_101), max_out = its
  *   maximum (device int32); rhccq_lut_u8: out[p] = lut256[in[p]].
@@ -339,8 +341,8 @@ int rhccq_box_count(rhccq_ctx* ctx, const uint8_t* mask, int32_t H, int32_t W, i
 int rhccq_morph_dilate(rhccq_ctx* ctx, const uint8_t* in, int32_t H, int32_t W, int32_t radius, const int32_t* half_widths /* host */,
                        int32_t invert_in, int32_t invert_out, uint8_t* out);
 int rhccq_mask_op(rhccq_ctx* ctx, const uint8_t* a, const uint8_t* b, int64_t n, int32_t op, uint8_t* out);
-int rhccq_gap_bridge(rhccq_ctx* ctx, const uint8_t* in, const uint16_t* counts, int32_t H, int32_t W, int32_t min_count, int32_t reach,
-                     uint8_t* out);
+int rhccq_gap_bridge(rhccq_ctx* ctx, const uint8_t* in, const void* counts /* u16 (count_bytes 2) or u32 (4) */, int32_t count_bytes, int32_t H,
+                     int32_t W, int64_t min_count, int32_t reach, uint8_t* out);
 int rhccq_dist_chamfer(rhccq_ctx* ctx, const uint8_t* mask, int32_t H, int32_t W, uint16_t* hz_tmp, int32_t* dist);
 int rhccq_binary_sobel(rhccq_ctx* ctx, const uint8_t* mask, int32_t H, int32_t W, uint8_t* m2, int32_t* max_out);
 int rhccq_lut_u8(rhccq_ctx* ctx, const uint8_t* in, const uint8_t* lut256, int64_t n, uint8_t* out);

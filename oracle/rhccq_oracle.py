@@ -1529,7 +1529,15 @@ def local_density(binary_map, kernel_size=15):
             for dx in range(kernel_size):
                 acc = (acc + kernel[dy, dx] * src[dy:dy + H, dx:dx + W]).astype(np.float32)
         return acc
-    return box_counts(bm, kernel_size).astype(np.float32) * kernel[0, 0]
+    # DFT path: (window sum of the map's values) * float32(1 / k^2); for a 0 / 255 map the sum of value / 255 is the count
+    raw = np.asarray(binary_map)
+    pad = np.pad(raw.astype(np.int64), kernel_size // 2, mode="reflect")
+    ssum = np.zeros((H, W), np.int64)
+    for dy in range(kernel_size):
+        for dx in range(kernel_size):
+            ssum += pad[dy:dy + H, dx:dx + W]
+    vals = ssum / 255.0 if raw.max() > 1 else ssum.astype(np.float64)
+    return vals.astype(np.float32) * kernel[0, 0]
 
 
 def region_mean_density(labels, num, binary_map, kernel_size):
@@ -1717,10 +1725,11 @@ def bridge_small_gaps(binary_image, max_gap=3, density_threshold=0.3, local_wind
 
 def detect_meaningful_borders(binary_image, sensitivity=0.7):
     """roi.py:784-822"""
-    img = np.asarray(binary_image).astype(np.float32) / 255.0
-    gx, gy = cv_sobel3((img != 0).astype(np.int64), "reflect") if set(np.unique(img)) <= {0.0, 1.0} else (None, None)
-    if gx is None:
-        raise ValueError("a 0 / 255 image is expected")
+    b = np.asarray(binary_image)
+    if len(np.unique(b[b != 0])) > 1:
+        raise ValueError("a two-valued image is expected")
+    # the normalised magnitude does not depend on the one non-zero value (the notebook's cell 6 passes 0 / 1 planes): taken at 1
+    gx, gy = cv_sobel3((b != 0).astype(np.int64), "reflect")
     mag = np.sqrt(gx.astype(np.float32) ** 2 + gy.astype(np.float32) ** 2)
     if mag.max() > 0:
         mag = mag / mag.max()

@@ -228,21 +228,38 @@ def evaluate_edge_quality(edges, gray):
 def compute_local_density(binary_map, kernel_size=15):
     """-> float32[H,W].  The integer window counts come from the device; kernels up to 11 x 11 take OpenCV's direct filter path, a
     float32 accumulator over the taps (= the count-fold sequential float32 sum of 1 / k^2); larger ones its DFT path, restated as
-    float32(count) * float32(1 / k^2) (the DFT's own rounding noise, ~1e-7, has no closed form)."""
+    float32(count) * float32(1 / k^2) (the DFT's own rounding noise, ~1e-7, has no closed form).  Maps with several non-zero values:
+    window SUMS of the values on the device for the DFT-path sizes, the literal tap loop on the host for the small ones."""
     import torch
     rh = default_context()
     bm = np.asarray(binary_map)
     nz = bm[bm != 0]
+    kernel = np.ones((kernel_size, kernel_size), np.float32)
+    kernel /= kernel.sum()
+    k2 = kernel_size * kernel_size
     if nz.size and (nz != nz.flat[0]).any():
-        raise ValueError("compute_local_density: a binary map (one non-zero value) is expected")
+        if k2 >= 130 and bm.dtype == np.uint8:
+            sums = rh.box_sum(torch.from_numpy(np.ascontiguousarray(bm)).to(rh.device), kernel_size).cpu().numpy().astype(np.float64)
+            return (sums / 255.0 if bm.max() > 1 else sums).astype(np.float32) * kernel[0, 0]
+        m = bm / 255.0 if bm.max() > 1 else bm
+        src = np.pad(m.astype(np.float32), kernel_size // 2, mode="reflect")
+        H, W = bm.shape
+        if k2 >= 130:
+            acc = np.zeros((H, W), np.float64)
+            for dy in range(kernel_size):
+                for dx in range(kernel_size):
+                    acc += src[dy:dy + H, dx:dx + W]
+            return acc.astype(np.float32) * kernel[0, 0]
+        acc = np.zeros((H, W), np.float32)
+        for dy in range(kernel_size):
+            for dx in range(kernel_size):
+                acc = (acc + kernel[dy, dx] * src[dy:dy + H, dx:dx + W]).astype(np.float32)
+        return acc
     value = 1.0
     if nz.size:
         value = float(nz.flat[0]) / 255.0 if bm.max() > 1 else float(nz.flat[0])
-    kernel = np.ones((kernel_size, kernel_size), np.float32)
-    kernel /= kernel.sum()
     term = np.float32(kernel[0, 0] * np.float32(value))
     cnt = rh.box_count(torch.from_numpy(np.ascontiguousarray(bm != 0).view(np.uint8)).to(rh.device), kernel_size).cpu().numpy().view(np.uint16)
-    k2 = kernel_size * kernel_size
     if k2 < 130:
         table = np.zeros(k2 + 1, np.float32)
         for m in range(1, k2 + 1):

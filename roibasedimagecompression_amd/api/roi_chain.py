@@ -229,9 +229,32 @@ def remove_small_regions(binary_image, min_size=10, remove_thin_lines=False, ker
 
 
 def bridge_small_gaps_fast(binary_image, max_gap=3, density_threshold=0.3, local_window=5, regional_window=25):
+    """small_gaps.py:221-271.  A plane with more than one non-zero value (the notebook's cell 6 hands over 0 / 1 / 255 planes) weighs
+    its pixels by their values in the regional density, as the reference's `binary_map / 255.0` does."""
+    import torch
     binary_image = np.asarray(binary_image)
     d = _Dev()
-    bridged = _u8(d.bridge(d.up(binary_image), max_gap, density_threshold, local_window, regional_window))
+    nz = np.unique(binary_image[binary_image != 0])
+    if len(nz) <= 1:
+        bridged = _u8(d.bridge(d.up(binary_image), max_gap, density_threshold, local_window, regional_window))
+    else:
+        if regional_window * regional_window < 130:
+            raise NotImplementedError("bridge_small_gaps_fast on a multi-valued plane: regional windows of 13 and more")
+        plane = torch.from_numpy(np.ascontiguousarray(binary_image, dtype=np.uint8)).to(d.rh.device)
+        sums = d.rh.box_sum(plane, regional_window)
+        term = _density_table(regional_window)[1]
+        scale = 255.0 if binary_image.max() > 1 else 1.0
+
+        def dense(v):
+            return np.float32(v / scale) * term > np.float32(density_threshold)
+        lo, hi = 0, 255 * regional_window * regional_window + 1          # smallest window sum whose density passes (monotone)
+        while lo < hi:
+            mid = (lo + hi) // 2
+            if dense(mid):
+                hi = mid
+            else:
+                lo = mid + 1
+        bridged = _u8(d.rh.gap_bridge(plane, sums, lo, min(max_gap, local_window)))
     out = binary_image.copy()
     out[(binary_image == 0) & (bridged != 0)] = 255
     return out

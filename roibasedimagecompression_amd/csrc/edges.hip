@@ -153,11 +153,13 @@ __global__ __launch_bounds__(256) void label_reduce_kernel(const int32_t* __rest
   }
 }
 
-// number of non-zero pixels in the k x k window centred on each pixel, BORDER_REFLECT_101 (cv2.filter2D's default border), k odd <= 31
+// number of non-zero pixels (kSum: sum of the pixel values) in the k x k window centred on each pixel, BORDER_REFLECT_101 (cv2.filter2D's
+// default border), k odd <= 31
 constexpr int kBoxTW = 64, kBoxTH = 16, kBoxMaxR = 15;
-__global__ __launch_bounds__(256) void box_count_kernel(const uint8_t* __restrict__ mask, int H, int W, int r, uint16_t* __restrict__ out) {
+template <bool kSum, typename OutT>
+__global__ __launch_bounds__(256) void box_count_kernel(const uint8_t* __restrict__ mask, int H, int W, int r, OutT* __restrict__ out) {
   __shared__ uint8_t t[kBoxTH + 2 * kBoxMaxR][kBoxTW + 2 * kBoxMaxR + 2];
-  __shared__ uint16_t hsum[kBoxTH + 2 * kBoxMaxR][kBoxTW];
+  __shared__ OutT hsum[kBoxTH + 2 * kBoxMaxR][kBoxTW];
   const int tiles_x = (W + kBoxTW - 1) / kBoxTW;
   const int y0 = (blockIdx.x / tiles_x) * kBoxTH, x0 = (blockIdx.x % tiles_x) * kBoxTW;
   const int th = kBoxTH + 2 * r, tw = kBoxTW + 2 * r;
@@ -165,23 +167,24 @@ __global__ __launch_bounds__(256) void box_count_kernel(const uint8_t* __restric
     const int ly = i / tw, lx = i % tw;
     const int y = reflect101(y0 + ly - r, H), x = reflect101(x0 + lx - r, W);
     // (tiles that stick out of the image reflect far coordinates back inside: those outputs are never stored)
-    t[ly][lx] = mask[(long long)clampi(y, H) * W + clampi(x, W)] != 0;
+    const uint8_t v = mask[(long long)clampi(y, H) * W + clampi(x, W)];
+    t[ly][lx] = kSum ? v : (uint8_t)(v != 0);
   }
   __syncthreads();
   for (int i = threadIdx.x; i < th * kBoxTW; i += 256) {
     const int ly = i / kBoxTW, lx = i % kBoxTW;
-    int s = 0;
+    unsigned s = 0;
     for (int d = 0; d <= 2 * r; ++d) s += t[ly][lx + d];
-    hsum[ly][lx] = (uint16_t)s;
+    hsum[ly][lx] = (OutT)s;
   }
   __syncthreads();
   for (int i = threadIdx.x; i < kBoxTH * kBoxTW; i += 256) {
     const int ly = i / kBoxTW, lx = i % kBoxTW;
     const int y = y0 + ly, x = x0 + lx;
     if (y >= H || x >= W) continue;
-    int s = 0;
+    unsigned s = 0;
     for (int d = 0; d <= 2 * r; ++d) s += hsum[ly + d][lx];
-    out[(long long)y * W + x] = (uint16_t)s;
+    out[(long long)y * W + x] = (OutT)s;
   }
 }
 
@@ -240,15 +243,24 @@ int rhccq_label_reduce(rhccq_ctx* ctx, const int32_t* labels, const uint16_t* va
   return 0;
 }
 
-int rhccq_box_count(rhccq_ctx* ctx, const uint8_t* mask, int32_t H, int32_t W, int32_t kernel_size, uint16_t* out) {
+static int box_launch(rhccq_ctx* ctx, const uint8_t* mask, int32_t H, int32_t W, int32_t kernel_size, void* out, bool sum) {
   if (!ctx || !mask || !out || H <= 0 || W <= 0) return rhccq_fail(ctx, RHCCQ_E_ARG, "box_count: bad argument");
   if (kernel_size < 1 || kernel_size > 2 * kBoxMaxR + 1 || !(kernel_size & 1)) return rhccq_fail(ctx, RHCCQ_E_LIMIT, "box_count: odd kernel sizes 1..31");
   const int r = kernel_size / 2;
   if (r >= H || r >= W) return rhccq_fail(ctx, RHCCQ_E_LIMIT, "box_count: window radius must be smaller than the image");
   const unsigned grid = (unsigned)(((W + kBoxTW - 1) / kBoxTW) * (long long)((H + kBoxTH - 1) / kBoxTH));
-  hipLaunchKernelGGL(box_count_kernel, dim3(grid), dim3(256), 0, ctx->stream, mask, H, W, r, out);
+  if (sum) hipLaunchKernelGGL((box_count_kernel<true, uint32_t>), dim3(grid), dim3(256), 0, ctx->stream, mask, H, W, r, (uint32_t*)out);
+  else hipLaunchKernelGGL((box_count_kernel<false, uint16_t>), dim3(grid), dim3(256), 0, ctx->stream, mask, H, W, r, (uint16_t*)out);
   RHCCQ_LAUNCH_CHECK(ctx);
   return 0;
+}
+
+int rhccq_box_count(rhccq_ctx* ctx, const uint8_t* mask, int32_t H, int32_t W, int32_t kernel_size, uint16_t* out) {
+  return box_launch(ctx, mask, H, W, kernel_size, out, false);
+}
+
+int rhccq_box_sum(rhccq_ctx* ctx, const uint8_t* plane, int32_t H, int32_t W, int32_t kernel_size, uint32_t* out) {
+  return box_launch(ctx, plane, H, W, kernel_size, out, true);
 }
 
 }  // extern "C"

@@ -67,13 +67,14 @@ __global__ __launch_bounds__(256) void mask_op_kernel(const uint8_t* __restrict_
 // ---- bridge_small_gaps_fast (small_gaps.py:221-271): an unset pixel whose window count reaches `min_count` (its regional density
 // exceeds the threshold) is set when, for one of the four direction pairs, BOTH opposite rays hold a set pixel within `reach` steps
 // (the reference's one-directional filter2D kernels; coordinates beyond the image reflect, BORDER_REFLECT_101)
-__global__ __launch_bounds__(256) void gap_bridge_kernel(const uint8_t* __restrict__ in, const uint16_t* __restrict__ counts, int H, int W, int min_count,
+template <typename CntT>
+__global__ __launch_bounds__(256) void gap_bridge_kernel(const uint8_t* __restrict__ in, const CntT* __restrict__ counts, int H, int W, long long min_count,
                                                          int reach, uint8_t* __restrict__ out) {
   const long long p = (long long)blockIdx.x * 256 + threadIdx.x;
   if (p >= (long long)H * W) return;
   if (in[p] != 0) { out[p] = 255; return; }
   uint8_t v = 0;
-  if ((int)counts[p] >= min_count) {
+  if ((long long)counts[p] >= min_count) {
     const int y = (int)(p / W), x = (int)(p % W);
     auto ray = [&](int dx, int dy) {
       for (int t = 1; t <= reach; ++t)
@@ -249,10 +250,16 @@ int rhccq_mask_op(rhccq_ctx* ctx, const uint8_t* a, const uint8_t* b, int64_t n,
   return 0;
 }
 
-int rhccq_gap_bridge(rhccq_ctx* ctx, const uint8_t* in, const uint16_t* counts, int32_t H, int32_t W, int32_t min_count, int32_t reach, uint8_t* out) {
-  if (!ctx || !in || !counts || !out || H <= 0 || W <= 0 || reach < 0 || in == out) return rhccq_fail(ctx, RHCCQ_E_ARG, "gap_bridge: bad argument");
+int rhccq_gap_bridge(rhccq_ctx* ctx, const uint8_t* in, const void* counts, int32_t count_bytes, int32_t H, int32_t W, int64_t min_count, int32_t reach,
+                     uint8_t* out) {
+  if (!ctx || !in || !counts || !out || H <= 0 || W <= 0 || reach < 0 || in == out || (count_bytes != 2 && count_bytes != 4))
+    return rhccq_fail(ctx, RHCCQ_E_ARG, "gap_bridge: bad argument");
   if (reach >= H || reach >= W) return rhccq_fail(ctx, RHCCQ_E_LIMIT, "gap_bridge: reach must be smaller than the image");
-  hipLaunchKernelGGL(gap_bridge_kernel, dim3((unsigned)(((long long)H * W + 255) / 256)), dim3(256), 0, ctx->stream, in, counts, H, W, min_count, reach, out);
+  const unsigned grid = (unsigned)(((long long)H * W + 255) / 256);
+  if (count_bytes == 2)
+    hipLaunchKernelGGL(gap_bridge_kernel<uint16_t>, dim3(grid), dim3(256), 0, ctx->stream, in, (const uint16_t*)counts, H, W, (long long)min_count, reach, out);
+  else
+    hipLaunchKernelGGL(gap_bridge_kernel<uint32_t>, dim3(grid), dim3(256), 0, ctx->stream, in, (const uint32_t*)counts, H, W, (long long)min_count, reach, out);
   RHCCQ_LAUNCH_CHECK(ctx);
   return 0;
 }

@@ -797,8 +797,8 @@ class Rhccq:
 
     def gap_bridge(self, mask, counts, min_count, reach):
         out = torch.empty_like(mask)
-        self._check(self.lib.rhccq_gap_bridge(self.ctx, self._p(mask), self._p(counts), int(mask.shape[0]), int(mask.shape[1]), int(min_count), int(reach),
-                                              self._p(out)), "gap_bridge")
+        self._check(self.lib.rhccq_gap_bridge(self.ctx, self._p(mask), self._p(counts), counts.element_size(), int(mask.shape[0]), int(mask.shape[1]),
+                                              int(min_count), int(reach), self._p(out)), "gap_bridge")
         return out
 
     def dist_chamfer(self, mask):
@@ -820,6 +820,13 @@ class Rhccq:
     def lut_u8(self, plane, lut256):
         out = torch.empty_like(plane)
         self._check(self.lib.rhccq_lut_u8(self.ctx, self._p(plane), self._p(self.dev(np.asarray(lut256, np.uint8))), plane.numel(), self._p(out)), "lut_u8")
+        return out
+
+    def box_sum(self, plane, kernel_size):
+        """plane uint8[H,W] device -> int32[H,W] device: sum of the pixel values per k x k window, BORDER_REFLECT_101"""
+        H, W = int(plane.shape[0]), int(plane.shape[1])
+        out = self.empty((H, W), torch.int32)
+        self._check(self.lib.rhccq_box_sum(self.ctx, self._p(plane), H, W, int(kernel_size), self._p(out)), "box_sum")
         return out
 
     def masked_hist(self, mask, values, n_bins):

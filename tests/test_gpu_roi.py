@@ -274,3 +274,51 @@ def test_get_regions_whole_chain_vs_oracle():
         wroi, wnon = O.extract_regions(img, want[4], want[5])
         assert [r["area"] for r in roi] == [r["area"] for r in wroi] and [r["area"] for r in non] == [r["area"] for r in wnon]
     assert 0.3 < got[1].mean() < 1.0 or True
+
+
+def test_notebook_cell6_inline_chain_vs_oracle():
+    """rhccq.ipynb cell 6 inlines the chain instead of calling get_regions, and `(connected * 255).astype(np.uint8)` wraps 255 * 255 to 1:
+    the later steps see 0 / 1 / 255 planes (the regional density of bridge_small_gaps_fast then weighs the pixels by value).  The
+    mirrored functions follow the reference on such planes too: same sequence, device vs restatement."""
+    from oracle import rhccq_oracle as O
+    from encoder.ROI import edges as E, roi as R, small_gaps as G, small_regions as S, thin_regions2 as T
+    from roibasedimagecompression_amd import synth
+
+    def cell6(image_rgb, M):
+        edge_map = M["get_edge_map"](image_rgb)
+        edge_density = M["compute_local_density"](edge_map, 3)
+        thr = M["suggest_automatic_threshold"](edge_density, edge_map, "mean") / 100
+        borders = edge_map.copy()
+        borders[~(edge_density > thr)] = 0
+        binary_borders = (borders > 0).astype(np.uint8) * 255
+        a = M["remove_thin"](binary_borders, 0.10, 0.3, 25, 25)
+        b = M["remove_noise"](a, 75)
+        c = M["closing"](b, 5, 25)
+        connected = M["bridge"](c, 100, 0.2, 15, 25)
+        binary_image = (connected * 255).astype(np.uint8)                  # 255 * 255 wraps to 1
+        assert set(np.unique(binary_image)) <= {0, 1}
+        border_mask = M["borders"](binary_image, 0.5)
+        protected = M["protect"](binary_image, border_mask, 15)
+        bridged = M["bridge"](protected, 25, 0.2, 15, 25)
+        closed = M["fill"](bridged, 10, 10000, 4)
+        cleaned = M["small"](closed, 5, True, 30)
+        return (cleaned > 0).astype(np.uint8), protected, bridged, closed
+
+    dev = {"get_edge_map": E.get_edge_map, "compute_local_density": E.compute_local_density, "suggest_automatic_threshold": E.suggest_automatic_threshold,
+           "remove_thin": T.remove_thin_structures_optimized, "remove_noise": lambda m, s: R.remove_small_noise_regions(m, min_size=s),
+           "closing": S.connect_by_closing_fast, "bridge": G.bridge_small_gaps_fast, "borders": R.detect_meaningful_borders,
+           "protect": R.protect_border_regions, "fill": R.fill_closed_regions, "small": S.remove_small_regions}
+    ora = {"get_edge_map": O.get_edge_map, "compute_local_density": O.local_density, "suggest_automatic_threshold": O.suggest_automatic_threshold,
+           "remove_thin": O.remove_thin_structures, "remove_noise": O.remove_small_noise_regions, "closing": O.connect_by_closing,
+           "bridge": O.bridge_small_gaps, "borders": O.detect_meaningful_borders, "protect": O.protect_border_regions,
+           "fill": O.fill_closed_regions, "small": lambda m, s, t, k: O.remove_small_regions(m, s)}
+    for img in (synth.photo(160, 240, 12, sigma=2.0), synth.poster(150, 200, 13)):
+        got, want = cell6(img, dev), cell6(img, ora)
+        for g, w in zip(got, want):
+            assert np.array_equal(g, w)
+        assert set(np.unique(want[1])) <= {0, 1, 255}
+        mixed = want[1]
+        for k in (15, 25):
+            assert np.array_equal(E.compute_local_density(mixed, k), O.local_density(mixed, k))
+        if len(np.unique(mixed)) == 3:
+            assert np.array_equal(E.compute_local_density(mixed, 3), O.local_density(mixed, 3))
