@@ -278,6 +278,16 @@ int rhccq_slic_assign(rhccq_ctx* ctx, const double* img, const uint8_t* mask, co
 int rhccq_slic_connectivity_host(const int32_t* labels_host, int32_t H, int32_t W, int32_t min_size, int32_t max_size,
                                  int32_t* out_host);
 
+/* resize of enhanced_slic_with_texture (slic.py:42-44,82,101 -> skimage.transform.resize): scipy.ndimage.gaussian_filter1d along one axis of
+ * a device float64 array viewed as [outer][len][inner] (mode 'mirror'; weights: device double[radius + 1] = centre, then offsets
+ * 1..radius; scipy's summation order), scipy.ndimage.zoom order 1 / 0 with the per-axis index and weight tables computed on the host
+ * (yi, wy: [2][oh]; xi, wx: [2][ow] for order 1; [oh], [ow] for order 0); zoom_linear clips to [lo, hi] as resize does. */
+int rhccq_gauss1d_f64(rhccq_ctx* ctx, const double* in, int64_t outer, int32_t len, int64_t inner, const double* weights, int32_t radius, double* out);
+int rhccq_zoom_linear_f64(rhccq_ctx* ctx, const double* in, int32_t H, int32_t W, int32_t C, const int32_t* yi, const double* wy, const int32_t* xi,
+                          const double* wx, int32_t oh, int32_t ow, double lo, double hi, double* out);
+int rhccq_zoom_nearest(rhccq_ctx* ctx, const void* in, int32_t elem_bytes, int32_t H, int32_t W, int32_t C, const int32_t* yi, const int32_t* xi,
+                       int32_t oh, int32_t ow, void* out);
+
 /* ---- ROI stage, region extraction (encoder/ROI/roi.py)
  * Connected components of a binary mask with statistics: what the reference takes from
  * cv2.connectedComponentsWithStats (roi.py:285-294 extract_connected_regions_fast, :229 fuse_adjacent_regions_optimized, and every

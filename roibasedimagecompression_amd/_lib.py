@@ -84,6 +84,10 @@ PROTOTYPES = {
     "rhccq_label_sum": (c_int32, [c_void_p, c_void_p, c_void_p, c_int32, c_int64, c_int32, c_void_p]),
     "rhccq_masked_hist": (c_int32, [c_void_p, c_void_p, c_void_p, c_int64, c_int32, c_void_p]),
     "rhccq_value_mask": (c_int32, [c_void_p, c_void_p, c_void_p, c_int64, c_int32, c_void_p]),
+    "rhccq_gauss1d_f64": (c_int32, [c_void_p, c_void_p, c_int64, c_int32, c_int64, c_void_p, c_int32, c_void_p]),
+    "rhccq_zoom_linear_f64": (c_int32, [c_void_p, c_void_p, c_int32, c_int32, c_int32, c_void_p, c_void_p, c_void_p, c_void_p, c_int32, c_int32,
+                                        c_double, c_double, c_void_p]),
+    "rhccq_zoom_nearest": (c_int32, [c_void_p, c_void_p, c_int32, c_int32, c_int32, c_int32, c_void_p, c_void_p, c_int32, c_int32, c_void_p]),
     "rhccq_mt_uniforms": (c_int32, [c_void_p, c_void_p, c_int64, c_int64, c_void_p]),
     "rhccq_mbk_order_bytes": (c_int64, [c_int64]),
     "rhccq_mbk_order": (c_int32, [c_void_p, c_void_p, C.POINTER(MbkProblem), c_int32, c_void_p, c_void_p, c_void_p, c_int64]),

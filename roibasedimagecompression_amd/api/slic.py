@@ -4,9 +4,11 @@ The reference downsamples the region to <= 500 pixels, runs scikit-image's maske
 10 sweeps, connectivity enforced) and upsamples the labels.  scikit-image is absent from the build container and
 unpinned by the reference: PARITY UNPINNED -- `transform.resize` and `segmentation.slic(mask=...)` are restated from
 their published algorithms on top of scipy.ndimage / scipy.cluster (which scikit-image itself calls).  What runs where:
-the 20 assignment sweeps on the MI355X (csrc/slic.hip `slic_assign_kernel`, float64, the operations of `_slic_cython` in
-their order); the connectivity enforcement as a native host routine of the same library (a serial raster scan);
-resize / Gaussian / centroid seeding (RandomState(123) + kmeans2) / centroid means on the host, as in scikit-image."""
+the resize (scipy's anti-aliasing Gaussian over the FULL-resolution region and its order-0 / order-1 zoom, restated operation for
+operation: `gauss1d_kernel`, `zoom_linear_kernel`, `zoom_nearest_kernel`) and the 20 assignment sweeps (`slic_assign_kernel`, float64,
+the operations of `_slic_cython` in their order) on the MI355X (csrc/slic.hip); the connectivity enforcement as a native host routine
+of the same library (a serial raster scan); on the <= 500-pixel image: the sigma-1 Gaussian of the Lab image, centroid seeding
+(RandomState(123) + kmeans2) and centroid means on the host, as in scikit-image."""
 import ctypes as C
 import math
 import warnings
@@ -30,19 +32,82 @@ def _rgb2lab(rgb_u8):
     return np.stack([116.0 * f[1] - 16.0, 500.0 * (f[0] - f[1]), 200.0 * (f[1] - f[2])], axis=-1)
 
 
+def _mirror_index(i, n):
+    """scipy's 'mirror' extension for integer sample positions (d c b | a b c d | c b a)"""
+    if n == 1:
+        return np.zeros_like(i)
+    period = 2 * n - 2
+    i = np.mod(i, period)
+    return np.where(i >= n, period - i, i)
+
+
+def _zoom_coordinates(n_in, n_out):
+    """input coordinate of every output sample: scipy.ndimage.zoom(grid_mode=True, mode='mirror'), NI_ZoomShift's arithmetic"""
+    c = (np.arange(n_out, dtype=np.float64) + 0.5) * (n_in / n_out) - 0.5
+    if n_in <= 1:
+        return np.zeros_like(c)
+    sz2 = 2 * n_in - 2
+    neg = c < 0
+    t = np.where(neg, sz2 * np.floor(-c / sz2) + c, c)
+    t = np.where(neg, np.where(t <= 1 - n_in, t + sz2, -t), t)
+    big = ~neg & (c > n_in - 1)
+    u = np.where(big, c - sz2 * np.floor(c / sz2), t)
+    return np.where(big, np.where(u >= n_in, sz2 - u, u), u)
+
+
+def _gaussian_weights(sigma, radius):
+    """scipy.ndimage._filters._gaussian_kernel1d(sigma, 0, radius), as (centre, offset 1, ..., offset radius)"""
+    x = np.arange(-radius, radius + 1)
+    phi = np.exp(-0.5 / (sigma * sigma) * x ** 2)
+    phi = phi / phi.sum()
+    return np.ascontiguousarray(phi[radius:])
+
+
 def _resize(image, out_hw, order, anti_aliasing):
-    """skimage.transform.resize(image, out_hw, order, mode='reflect', preserve_range=True, anti_aliasing=...)"""
-    from scipy import ndimage as ndi
-    img = np.asarray(image)
-    out_shape = tuple(out_hw) + img.shape[2:]
-    work = img.astype(np.float64) if order > 0 else (img.astype(np.uint8) if img.dtype == bool else img)
-    factors = np.divide(img.shape, out_shape)
+    """skimage.transform.resize(image, out_hw, order, mode='reflect', preserve_range=True, anti_aliasing=...) on the device:
+    scipy.ndimage.gaussian_filter (sigma = (factor - 1) / 2 per resized axis, mode 'mirror', truncate 4) and scipy.ndimage.zoom
+    (order 0 / 1, grid_mode) restated operation for operation (csrc/slic.hip); the per-axis coordinate / weight tables are host numpy."""
+    import torch
+    rh = default_context()
+    img = np.ascontiguousarray(image)
+    H, W = img.shape[:2]
+    oh, ow = int(out_hw[0]), int(out_hw[1])
+    C3 = int(np.prod(img.shape[2:])) if img.ndim > 2 else 1
+    cy, cx = _zoom_coordinates(H, oh), _zoom_coordinates(W, ow)
+    if order == 0:
+        src = img.astype(np.uint8) if img.dtype == bool else img
+        if src.dtype not in (np.uint8, np.int32):
+            raise TypeError("nearest-neighbour resize: uint8 / bool / int32 arrays")
+        yi = _mirror_index(np.floor(cy + 0.5).astype(np.int64), H).astype(np.int32)
+        xi = _mirror_index(np.floor(cx + 0.5).astype(np.int64), W).astype(np.int32)
+        d_in = torch.from_numpy(src).to(rh.device)
+        out = torch.empty((oh, ow) + tuple(img.shape[2:]), dtype=d_in.dtype, device=rh.device)
+        d_yi, d_xi = rh.dev(yi), rh.dev(xi)                  # (named: a temporary would be freed, and its block reused, before the launch)
+        rh._check(rh.lib.rhccq_zoom_nearest(rh.ctx, rh._p(d_in), src.dtype.itemsize, H, W, C3, rh._p(d_yi), rh._p(d_xi), oh, ow, rh._p(out)),
+                  "zoom_nearest")
+        return out.cpu().numpy()
+    work = torch.from_numpy(np.array(img, order="C")).to(rh.device).to(torch.float64)
     if anti_aliasing:
-        work = ndi.gaussian_filter(work, np.maximum(0, (factors - 1) / 2), cval=0, mode="mirror")
-    out = ndi.zoom(work, [1 / f for f in factors], order=order, mode="mirror", cval=0, grid_mode=True)
-    if order > 0:
-        out = np.clip(out, img.min(), img.max())
-    return out
+        for axis, (n_in, n_out) in enumerate(((H, oh), (W, ow))):
+            sigma = max(0.0, (n_in / n_out - 1) / 2)
+            if sigma <= 1e-15:
+                continue
+            radius = int(4.0 * sigma + 0.5)
+            outer, length, inner = (1, H, W * C3) if axis == 0 else (H, W, C3)
+            nxt = torch.empty_like(work)
+            d_w = rh.dev(_gaussian_weights(sigma, radius))
+            rh._check(rh.lib.rhccq_gauss1d_f64(rh.ctx, rh._p(work), outer, length, inner, rh._p(d_w), radius, rh._p(nxt)), "gauss1d_f64")
+            work = nxt
+    y0, x0 = np.floor(cy).astype(np.int64), np.floor(cx).astype(np.int64)
+    ty, tx = cy - np.floor(cy), cx - np.floor(cx)
+    yi = np.stack([_mirror_index(y0, H), _mirror_index(y0 + 1, H)]).astype(np.int32)
+    xi = np.stack([_mirror_index(x0, W), _mirror_index(x0 + 1, W)]).astype(np.int32)
+    wy, wx = np.stack([1 - ty, ty]), np.stack([1 - tx, tx])
+    out = torch.empty((oh, ow) + tuple(img.shape[2:]), dtype=torch.float64, device=rh.device)
+    d_yi, d_wy, d_xi, d_wx = rh.dev(yi), rh.dev(wy), rh.dev(xi), rh.dev(wx)
+    rh._check(rh.lib.rhccq_zoom_linear_f64(rh.ctx, rh._p(work), H, W, C3, rh._p(d_yi), rh._p(d_wy), rh._p(d_xi), rh._p(d_wx), oh, ow,
+                                           float(img.min()), float(img.max()), rh._p(out)), "zoom_linear_f64")
+    return out.cpu().numpy()
 
 
 def _mask_centroids(mask, n_centroids):

@@ -57,6 +57,59 @@ __global__ __launch_bounds__(256) void slic_assign_kernel(const double* __restri
   labels[p] = best;
 }
 
+// ---- skimage.transform.resize of enhanced_slic_with_texture (slic.py:42-44,82,101): scipy.ndimage.gaussian_filter (anti-aliasing) and
+// scipy.ndimage.zoom(order 0 / 1, mode 'mirror', grid_mode) restated operation for operation (float64, no contraction):
+//   correlate1d with a symmetric kernel: t = x[c] w[0]; for j = R .. 1: t += (x[c - j] + x[c + j]) w[j]   (outermost pair first)
+//   zoom, order 1: t = 0; for (dy, dx) in (0,0), (0,1), (1,0), (1,1): t += (x[y_dy][x_dx] * wy[dy]) * wx[dx]
+// Coordinates, weights and mirrored indices are tiny per-axis tables computed on the host exactly as scipy computes them.
+__global__ __launch_bounds__(256) void gauss1d_kernel(const double* __restrict__ in, long long outer, int len, long long inner,
+                                                      const double* __restrict__ w /* [R + 1]: centre, then offsets 1 .. R */, int R,
+                                                      double* __restrict__ out) {
+  const long long i = (long long)blockIdx.x * 256 + threadIdx.x;
+  if (i >= outer * len * inner) return;
+  const long long k = i % inner, c = (i / inner) % len, o = i / (inner * len);
+  const double* base = in + o * len * inner + k;
+  auto at = [&](long long p) {                             // mode 'mirror': reflect about the centre of the edge samples
+    if (len == 1) return base[0];
+    const long long period = 2ll * len - 2;
+    p %= period;
+    if (p < 0) p += period;
+    if (p >= len) p = period - p;
+    return base[p * inner];
+  };
+  double t = at(c) * w[0];
+  for (int j = R; j >= 1; --j) t += (at(c - j) + at(c + j)) * w[j];
+  out[i] = t;
+}
+
+__global__ __launch_bounds__(256) void zoom_linear_kernel(const double* __restrict__ in, int W, int C, const int32_t* __restrict__ yi /* [2][oh] */,
+                                                          const double* __restrict__ wy /* [2][oh] */, const int32_t* __restrict__ xi /* [2][ow] */,
+                                                          const double* __restrict__ wx, int oh, int ow, double lo, double hi, double* __restrict__ out) {
+  const long long i = (long long)blockIdx.x * 256 + threadIdx.x;
+  if (i >= (long long)oh * ow * C) return;
+  const int ch = (int)(i % C), x = (int)((i / C) % ow), y = (int)(i / ((long long)C * ow));
+  double t = 0.0;
+#pragma unroll
+  for (int dy = 0; dy < 2; ++dy)
+#pragma unroll
+    for (int dx = 0; dx < 2; ++dx) {
+      double c = in[((long long)yi[dy * oh + y] * W + xi[dx * ow + x]) * C + ch];
+      c *= wy[dy * oh + y];
+      c *= wx[dx * ow + x];
+      t += c;
+    }
+  out[i] = t < lo ? lo : (t > hi ? hi : t);                // resize(..., preserve_range) clips to the input's range
+}
+
+template <typename T>
+__global__ __launch_bounds__(256) void zoom_nearest_kernel(const T* __restrict__ in, int W, int C, const int32_t* __restrict__ yi, const int32_t* __restrict__ xi,
+                                                           int oh, int ow, T* __restrict__ out) {
+  const long long i = (long long)blockIdx.x * 256 + threadIdx.x;
+  if (i >= (long long)oh * ow * C) return;
+  const int ch = (int)(i % C), x = (int)((i / C) % ow), y = (int)(i / ((long long)C * ow));
+  out[i] = in[((long long)yi[y] * W + xi[x]) * C + ch];
+}
+
 }  // namespace rhccq
 
 using namespace rhccq;
@@ -115,6 +168,37 @@ int rhccq_slic_connectivity_host(const int32_t* labels_host, int32_t H, int32_t 
       }
     }
   }
+  return 0;
+}
+
+int rhccq_gauss1d_f64(rhccq_ctx* ctx, const double* in, int64_t outer, int32_t len, int64_t inner, const double* weights, int32_t radius, double* out) {
+  if (!ctx || !in || !weights || !out || in == out || outer <= 0 || len <= 0 || inner <= 0 || radius < 0)
+    return rhccq_fail(ctx, RHCCQ_E_ARG, "gauss1d_f64: bad argument");
+  const long long n = (long long)outer * len * inner;
+  hipLaunchKernelGGL(gauss1d_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, ctx->stream, in, (long long)outer, len, (long long)inner, weights, radius, out);
+  RHCCQ_LAUNCH_CHECK(ctx);
+  return 0;
+}
+
+int rhccq_zoom_linear_f64(rhccq_ctx* ctx, const double* in, int32_t H, int32_t W, int32_t C, const int32_t* yi, const double* wy, const int32_t* xi,
+                          const double* wx, int32_t oh, int32_t ow, double lo, double hi, double* out) {
+  if (!ctx || !in || !yi || !wy || !xi || !wx || !out || H <= 0 || W <= 0 || C <= 0 || oh <= 0 || ow <= 0)
+    return rhccq_fail(ctx, RHCCQ_E_ARG, "zoom_linear_f64: bad argument");
+  const long long n = (long long)oh * ow * C;
+  hipLaunchKernelGGL(zoom_linear_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, ctx->stream, in, W, C, yi, wy, xi, wx, oh, ow, lo, hi, out);
+  RHCCQ_LAUNCH_CHECK(ctx);
+  return 0;
+}
+
+int rhccq_zoom_nearest(rhccq_ctx* ctx, const void* in, int32_t elem_bytes, int32_t H, int32_t W, int32_t C, const int32_t* yi, const int32_t* xi, int32_t oh,
+                       int32_t ow, void* out) {
+  if (!ctx || !in || !yi || !xi || !out || H <= 0 || W <= 0 || C <= 0 || oh <= 0 || ow <= 0 || (elem_bytes != 1 && elem_bytes != 4))
+    return rhccq_fail(ctx, RHCCQ_E_ARG, "zoom_nearest: bad argument");
+  const long long n = (long long)oh * ow * C;
+  const unsigned grid = (unsigned)((n + 255) / 256);
+  if (elem_bytes == 1) hipLaunchKernelGGL(zoom_nearest_kernel<uint8_t>, dim3(grid), dim3(256), 0, ctx->stream, (const uint8_t*)in, W, C, yi, xi, oh, ow, (uint8_t*)out);
+  else hipLaunchKernelGGL(zoom_nearest_kernel<int32_t>, dim3(grid), dim3(256), 0, ctx->stream, (const int32_t*)in, W, C, yi, xi, oh, ow, (int32_t*)out);
+  RHCCQ_LAUNCH_CHECK(ctx);
   return 0;
 }
 

@@ -710,7 +710,8 @@ class Rhccq:
     def ccl_select(self, labels, lut):
         """labels int32[H,W] device, lut uint8[n + 1] (numpy) -> uint8[H,W] device = lut[labels]"""
         out = self.empty(tuple(labels.shape), torch.uint8)
-        self._check(self.lib.rhccq_ccl_select(self.ctx, self._p(labels), self._p(self.dev(np.asarray(lut, np.uint8))), labels.numel(), self._p(out)), "ccl_select")
+        d_lut = self.dev(np.asarray(lut, np.uint8))           # (named: a temporary would be freed before the launch)
+        self._check(self.lib.rhccq_ccl_select(self.ctx, self._p(labels), self._p(d_lut), labels.numel(), self._p(out)), "ccl_select")
         return out
 
     def roi_buffer(self, region_map, rgb, buffer_size=3):
@@ -819,7 +820,8 @@ class Rhccq:
 
     def lut_u8(self, plane, lut256):
         out = torch.empty_like(plane)
-        self._check(self.lib.rhccq_lut_u8(self.ctx, self._p(plane), self._p(self.dev(np.asarray(lut256, np.uint8))), plane.numel(), self._p(out)), "lut_u8")
+        d_lut = self.dev(np.asarray(lut256, np.uint8))
+        self._check(self.lib.rhccq_lut_u8(self.ctx, self._p(plane), self._p(d_lut), plane.numel(), self._p(out)), "lut_u8")
         return out
 
     def box_sum(self, plane, kernel_size):

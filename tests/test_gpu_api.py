@@ -321,3 +321,23 @@ def test_adaptive_quality_metrics_vs_oracle():
             y, x = int(rng.integers(0, H)), int(rng.integers(0, W))
             b[y, x] = 255 - b[y, x]
         check(calculate_adaptive_quality_metrics(a, b), O.adaptive_quality_metrics(a, b))
+
+
+def test_resize_on_the_device_equals_scipy():
+    """skimage.transform.resize as enhanced_slic_with_texture uses it (anti-aliased order-1 downscale, order-0 masks, order-0 label
+    upscale): the device kernels restate scipy.ndimage.gaussian_filter / zoom operation for operation -> bit-identical to scipy"""
+    from oracle import rhccq_oracle as O
+    from roibasedimagecompression_amd.api.slic import _resize
+    from roibasedimagecompression_amd import synth
+    rng = np.random.default_rng(4)
+    for (h, w), (oh, ow) in (((300, 700), (214, 500)), ((540, 960), (281, 500)), ((120, 160), (120, 160)), ((997, 131), (498, 65)), ((64, 2000), (16, 500))):
+        img = synth.photo(h, w, h + w)
+        got, want = _resize(img, (oh, ow), 1, True), O.sk_resize(img, (oh, ow), 1, True)
+        assert got.dtype == np.float64 and np.array_equal(got, want), ((h, w), (oh, ow), np.abs(got - want).max())
+        assert np.array_equal(_resize(img, (oh, ow), 1, False), O.sk_resize(img, (oh, ow), 1, False))
+        mask = rng.random((h, w)) < 0.6
+        assert np.array_equal(_resize(mask, (oh, ow), 0, False), O.sk_resize(mask, (oh, ow), 0, False))
+        lab = rng.integers(0, 90, (oh, ow)).astype(np.int32)
+        assert np.array_equal(_resize(lab, (h, w), 0, False), O.sk_resize(lab, (h, w), 0, False))          # nearest-neighbour UPscale
+    big = synth.photo(2160, 3840, 3)
+    assert np.array_equal(_resize(big, (281, 500), 1, True), O.sk_resize(big, (281, 500), 1, True))
