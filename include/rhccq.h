@@ -331,6 +331,10 @@ int rhccq_canny_nms(rhccq_ctx* ctx, const uint8_t* img, int32_t H, int32_t W, in
 int rhccq_edges_above(rhccq_ctx* ctx, const uint16_t* nm, int64_t n_pixels, int32_t low, uint8_t* mask);
 int rhccq_label_reduce(rhccq_ctx* ctx, const int32_t* labels, const uint16_t* val16, const uint8_t* val8, int64_t n_pixels,
                        int32_t n_labels, uint64_t* red);
+/* Canny's hysteresis verdict and the quality score's sums on the device: stats = rhccq_ccl's (device int32[n + 1][5]), red = rhccq_label_reduce's;
+ * out4 (device u64[4]) = {components whose max exceeds high, their pixels, their sum of val8, their sum of val8^2}; lut (device u8[n + 1], may
+ * be NULL) = 255 for those components (for rhccq_ccl_select) */
+int rhccq_edge_score(rhccq_ctx* ctx, const int32_t* stats, const uint64_t* red, int32_t n_labels, int32_t high, uint64_t* out4, uint8_t* lut);
 int rhccq_box_count(rhccq_ctx* ctx, const uint8_t* mask, int32_t H, int32_t W, int32_t kernel_size, uint16_t* out);
 /* the same window, summing the pixel VALUES (maps that are not 0 / one value: the notebook's 0 / 1 / 255 planes) */
 int rhccq_box_sum(rhccq_ctx* ctx, const uint8_t* plane, int32_t H, int32_t W, int32_t kernel_size, uint32_t* out);

@@ -148,14 +148,9 @@ class EdgeAnalysis:
         low, high = math.floor(low), math.floor(high)
         if low > high:
             low, high = high, low
-        n, _, areas, red = self.rh.canny_components(self.nm(False), low, self.gray)
-        strong = red[:, 0] > high
-        strong[0] = False
-        n_comp = int(strong.sum())
-        n_edge = int(areas[strong].sum())
+        _, _, (n_comp, n_edge, s1, s2) = self.rh.canny_components(self.nm(False), low, max(high, 0), self.gray)
         if n_comp == 0:
             return float("nan"), 0.0
-        s1, s2 = int(red[strong, 1].sum()), int(red[strong, 2].sum())
         contrast = math.sqrt(n_edge * s2 - s1 * s1) / n_edge       # population standard deviation from exact integer sums
         return (n_edge / n_comp) * contrast, n_edge / (self.H * self.W)
 
@@ -164,9 +159,7 @@ class EdgeAnalysis:
         low, high = math.floor(low), math.floor(high)
         if low > high:
             low, high = high, low
-        n, labels, _, red = self.rh.canny_components(self.nm(colour), low, None)
-        lut = np.where(red[:, 0] > high, 255, 0).astype(np.uint8)
-        lut[0] = 0
+        labels, lut, _ = self.rh.canny_components(self.nm(colour), low, max(high, 0), None, want_lut=True)
         return self.rh.ccl_select(labels, lut)
 
 

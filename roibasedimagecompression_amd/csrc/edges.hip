@@ -153,6 +153,32 @@ __global__ __launch_bounds__(256) void label_reduce_kernel(const int32_t* __rest
   }
 }
 
+// hysteresis verdict per component and the four numbers the quality score needs, without a trip to the host: a component is an edge
+// when its largest magnitude exceeds `high`; out = {edge components, edge pixels, sum of gray, sum of gray^2 over the edge pixels};
+// lut (optional): 255 for edge components, 0 otherwise (label 0 = background: 0)
+__global__ __launch_bounds__(256) void edge_score_kernel(const int32_t* __restrict__ stats /* [n + 1][5], column 4 = area */,
+                                                         const unsigned long long* __restrict__ red /* [n + 1][3] */, int n, int high,
+                                                         unsigned long long* out, uint8_t* __restrict__ lut) {
+  __shared__ unsigned long long s_acc[4];
+  if (threadIdx.x < 4) s_acc[threadIdx.x] = 0;
+  __syncthreads();
+  const int l = blockIdx.x * 256 + threadIdx.x;             // label l, 0 = background
+  unsigned long long v[4] = {0, 0, 0, 0};
+  if (l <= n) {
+    const bool edge = l > 0 && red[3ll * l] > (unsigned long long)high;
+    if (lut) lut[l] = edge ? 255 : 0;
+    if (edge) { v[0] = 1; v[1] = (unsigned long long)stats[5ll * l + 4]; v[2] = red[3ll * l + 1]; v[3] = red[3ll * l + 2]; }
+  }
+#pragma unroll
+  for (int k = 0; k < 4; ++k) {
+    unsigned long long t = v[k];
+    for (int o = 32; o > 0; o >>= 1) t += __shfl_down(t, o, 64);
+    if ((threadIdx.x & 63) == 0 && t) atomicAdd(&s_acc[k], t);
+  }
+  __syncthreads();
+  if (threadIdx.x < 4 && s_acc[threadIdx.x]) atomicAdd(&out[threadIdx.x], s_acc[threadIdx.x]);
+}
+
 // number of non-zero pixels (kSum: sum of the pixel values) in the k x k window centred on each pixel, BORDER_REFLECT_101 (cv2.filter2D's
 // default border), k odd <= 31
 constexpr int kBoxTW = 64, kBoxTH = 16, kBoxMaxR = 15;
@@ -239,6 +265,15 @@ int rhccq_label_reduce(rhccq_ctx* ctx, const int32_t* labels, const uint16_t* va
   RHCCQ_HIP(ctx, hipMemsetAsync(red, 0, 3 * sizeof(uint64_t) * ((size_t)n_labels + 1), ctx->stream));
   hipLaunchKernelGGL(label_reduce_kernel, dim3((unsigned)((n_pixels + 255) / 256)), dim3(256), 0, ctx->stream, labels, val16, val8, (long long)n_pixels,
                      (unsigned long long*)red);
+  RHCCQ_LAUNCH_CHECK(ctx);
+  return 0;
+}
+
+int rhccq_edge_score(rhccq_ctx* ctx, const int32_t* stats, const uint64_t* red, int32_t n_labels, int32_t high, uint64_t* out4, uint8_t* lut) {
+  if (!ctx || !stats || !red || !out4 || n_labels < 0 || high < 0) return rhccq_fail(ctx, RHCCQ_E_ARG, "edge_score: bad argument");
+  RHCCQ_HIP(ctx, hipMemsetAsync(out4, 0, 4 * sizeof(uint64_t), ctx->stream));
+  hipLaunchKernelGGL(edge_score_kernel, dim3((unsigned)((n_labels + 1 + 255) / 256)), dim3(256), 0, ctx->stream, stats, (const unsigned long long*)red, n_labels,
+                     high, (unsigned long long*)out4, lut);
   RHCCQ_LAUNCH_CHECK(ctx);
   return 0;
 }

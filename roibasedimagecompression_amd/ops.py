@@ -684,7 +684,7 @@ class Rhccq:
         return part.cpu().numpy().sum(axis=0), h[:10], h[10:]
 
     # -- ROI stage: connected components, buffer zone ---------------------------------------------------
-    def ccl(self, mask, connectivity=8, cap=4096, numbering="opencv"):
+    def ccl(self, mask, connectivity=8, cap=4096, numbering="opencv", host_stats=True):
         """mask uint8 / bool [H,W] device -> (n, labels int32[H,W] device, stats np.int32[n + 1, 5]) with cv2's conventions:
         label 0 = background, components numbered as cv2.connectedComponentsWithStats numbers them (csrc/ccl.hip), stats
         columns CC_STAT_LEFT, TOP, WIDTH, HEIGHT, AREA.  numbering="raster": components numbered by their first pixel in
@@ -705,12 +705,12 @@ class Rhccq:
             if n <= cap:
                 break
             cap = n
-        return n, labels, stats[:n + 1].cpu().numpy()
+        return n, labels, (stats[:n + 1].cpu().numpy() if host_stats else stats)   # host_stats=False: the device tensor [cap + 1][5]
 
     def ccl_select(self, labels, lut):
-        """labels int32[H,W] device, lut uint8[n + 1] (numpy) -> uint8[H,W] device = lut[labels]"""
+        """labels int32[H,W] device, lut uint8[n + 1] (numpy, or a device tensor) -> uint8[H,W] device = lut[labels]"""
         out = self.empty(tuple(labels.shape), torch.uint8)
-        d_lut = self.dev(np.asarray(lut, np.uint8))           # (named: a temporary would be freed before the launch)
+        d_lut = lut if torch.is_tensor(lut) else self.dev(np.asarray(lut, np.uint8))   # (named: a temporary would be freed before the launch)
         self._check(self.lib.rhccq_ccl_select(self.ctx, self._p(labels), self._p(d_lut), labels.numel(), self._p(out)), "ccl_select")
         return out
 
@@ -753,15 +753,20 @@ class Rhccq:
         self._check(self.lib.rhccq_canny_nms(self.ctx, self._p(img), H, W, cn, self._p(mag), self._p(dxy), self._p(nm)), "canny_nms")
         return nm
 
-    def canny_components(self, nm, low, gray=None):
-        """components of {nm > low}: -> (n, labels int32[H,W] device, areas np.int64[n + 1], red np.uint64[n + 1, 3] = per label
-        max nm, sum gray, sum gray^2); an edge component of cv2.Canny(img, low, high) is one whose max exceeds `high`"""
+    def canny_components(self, nm, low, high, gray=None, want_lut=False):
+        """Canny's hysteresis on the device: components of {nm > low} (rhccq_ccl), per-label max of nm (+ sums of gray), verdict "max > high".
+        -> (labels int32[H,W] device, lut uint8[n + 1] device or None, (edge components, edge pixels, sum gray, sum gray^2) as Python ints);
+        only the component count and those four numbers cross to the host"""
         H, W = int(nm.shape[0]), int(nm.shape[1])
         mask = self.empty((H, W), torch.uint8)
         self._check(self.lib.rhccq_edges_above(self.ctx, self._p(nm), H * W, int(low), self._p(mask)), "edges_above")
-        n, labels, stats = self.ccl(mask, 8, cap=1 << 16)
-        red = self.label_reduce(labels, n, nm, gray)
-        return n, labels, stats[:, 4].astype(np.int64), red
+        n, labels, stats = self.ccl(mask, 8, cap=1 << 16, host_stats=False)
+        red = self.empty((n + 1, 3), torch.int64)
+        self._check(self.lib.rhccq_label_reduce(self.ctx, self._p(labels), self._p(nm), self._p(gray), labels.numel(), n, self._p(red)), "label_reduce")
+        out4 = self.empty((4,), torch.int64)
+        lut = self.empty((n + 1,), torch.uint8) if want_lut else None
+        self._check(self.lib.rhccq_edge_score(self.ctx, self._p(stats), self._p(red), n, int(high), self._p(out4), self._p(lut)), "edge_score")
+        return labels, lut, tuple(int(v) for v in out4.cpu().numpy())
 
     def label_reduce(self, labels, n, val16=None, val8=None):
         """-> np.uint64[n + 1, 3]: per label {max of val16, sum of val8, sum of val8^2}"""
