@@ -219,6 +219,35 @@ def pixel_probe(rh, rgb, iters=10):
             "expansion_s": t_e, "clusters": int(torch.unique(labels).numel()) - 1, "Mpixels_per_s_neighbours_plus_expansion": H * W / (t_n + t_e) / 1e6}
 
 
+def roi_stage_probe(rh, img):
+    """UPSTREAM of the timed path (parity unpinned): the reference's ROI stage on the same frame -- get_regions (21 Canny
+    passes, the morphological clean-up chain) + extract_regions -- through the mirrored API: numpy frame in host memory in, numpy masks
+    and region dicts out; connected-component labelling alone by HIP events (25 B/px algorithmic)."""
+    import torch
+    from roibasedimagecompression_amd.api import roi as R, roi_chain as C
+    H, W = img.shape[:2]
+    C.get_regions(img)                                                 # warm-up
+    t0 = time.perf_counter()
+    out = C.get_regions(img)
+    t1 = time.perf_counter()
+    roi, non = R.extract_regions(img, out[4], out[5])
+    t2 = time.perf_counter()
+    mask = torch.from_numpy(np.ascontiguousarray(out[0] != 0)).to(rh.device)
+    rh.ccl(mask, 8)
+    ev = [torch.cuda.Event(enable_timing=True) for _ in range(2)]
+    ev[0].record()
+    for _ in range(5):
+        n, _, _ = rh.ccl(mask, 8, host_stats=False)
+    ev[1].record()
+    torch.cuda.synchronize()
+    t_ccl = ev[0].elapsed_time(ev[1]) * 1e-3 / 5
+    return {"upstream_stage": True, "parity": "unpinned (OpenCV restated)", "get_regions_s": t1 - t0, "extract_regions_s": t2 - t1,
+            "Mpixels_per_s": H * W / (t2 - t0) / 1e6, "roi_fraction": float(out[1].mean()), "regions": [len(roi), len(non)],
+            "ccl": {"kernel": "ccl_* (csrc/ccl.hip), region map of the frame", "components": n, "avg_call_s": t_ccl,
+                    "algorithmic_bytes_per_call": 25 * H * W, "achieved_GB_s": 25 * H * W / t_ccl / 1e9,
+                    "frac_of_hbm_peak": 25 * H * W / t_ccl / 1e9 / HBM_PEAK_GBS}}
+
+
 def neighbour_probe(rh):
     """K3/K4 eps-components microbench of SURVEY.md 8d (`palette-only`): 256 palettes x 4000 colours."""
     rng = np.random.default_rng(99)
@@ -450,6 +479,7 @@ def main():
                 roof["dominant_kernel"] = dom
             line["neighbour_pass"] = neighbour_probe(rh)
             line["pixel_neighbour_pass_extension"] = pixel_probe(rh, rgb)
+            line["roi_stage_upstream"] = roi_stage_probe(rh, img)
         line["roofline"] = roof
         if args.cpu_sample and world == 1 and mode == "frame":
             line["cpu_baseline"] = cpu_baseline(img, lr, ln, min(args.cpu_sample, H, W), (q_roi, q_bg))
