@@ -129,14 +129,16 @@ __device__ __forceinline__ void ccl_stat_reset(int32_t* s, int key) {
 // parent[p] = root.  Only the first pixel of each horizontal run walks the tree (the other pixels of a run still point at it:
 // they are never roots, so no union ever touched them); roots take a compact id and reset their statistics row.
 // key_is_root (4-connectivity, or raster numbering asked for): the ordering key of a component is its first pixel = the root
-__global__ __launch_bounds__(256) void ccl_flatten_kernel(int32_t* parent, int H, int W, int segs, int32_t* __restrict__ cid, int cap,
-                                                          int32_t* __restrict__ stats, int32_t* count, int key_is_root) {
-  int y, seg, lane;
-  if (!ccl_wave_pos(H, segs, y, seg, lane)) return;
+__global__ __launch_bounds__(1024) void ccl_flatten_kernel(int32_t* parent, int H, int W, int segs, int32_t* __restrict__ cid, int cap,
+                                                           int32_t* __restrict__ stats, int32_t* count, int key_is_root) {
+  __shared__ int s_cnt[16], s_base;
+  int y = 0, seg = 0, lane = 0;
+  const bool valid = ccl_wave_pos(H, segs, y, seg, lane);
+  const int wave = threadIdx.x >> 6;
   const int x = seg * 64 + lane;
   const int p = y * W + x;
-  if (p == 0) ccl_stat_reset(stats + (long long)cap * kCclStat, -1);     // row `cap` = background (label 0 of cv2's stats)
-  const bool fg = x < W && parent[p] >= 0;
+  if (valid && p == 0) ccl_stat_reset(stats + (long long)cap * kCclStat, -1);     // row `cap` = background (label 0 of cv2's stats)
+  const bool fg = valid && x < W && parent[p] >= 0;
   const uint64_t b = __ballot(fg);
   const bool is_start = fg && (lane == 0 || !((b >> (lane - 1)) & 1ull));
   int r = -1;
@@ -147,13 +149,20 @@ __global__ __launch_bounds__(256) void ccl_flatten_kernel(int32_t* parent, int H
   if (fg && !is_start) r = rs;
   if (fg) parent[p] = r;
   const bool root = fg && r == p;
-  const uint64_t roots = __ballot(root);                     // one counter update per wave
-  if (!roots) return;
-  int base = 0;
-  const int leader = __builtin_ctzll(roots);
-  if (lane == leader) base = atomicAdd(count, __popcll(roots));
-  base = __shfl(base, leader);
+  // compact ids: one counter update per WORKGROUP (a noisy 4K edge map has a root in almost every wave: 130 000 atomics on one
+  // word cost 0.65 ms)
+  const uint64_t roots = __ballot(root);
+  if (lane == 0) s_cnt[wave] = __popcll(roots);
+  __syncthreads();
+  if (threadIdx.x == 0) {
+    int total = 0;
+    for (int w = 0; w < (int)(blockDim.x >> 6); ++w) total += s_cnt[w];
+    s_base = total ? atomicAdd(count, total) : 0;
+  }
+  __syncthreads();
   if (root) {
+    int base = s_base;
+    for (int w = 0; w < wave; ++w) base += s_cnt[w];
     const int id = base + __popcll(roots & ((1ull << lane) - 1ull));
     cid[p] = id;
     if (id < cap) ccl_stat_reset(stats + (long long)id * kCclStat, key_is_root ? r : 0x7fffffff);
@@ -437,7 +446,8 @@ int rhccq_ccl(rhccq_ctx* ctx, const uint8_t* mask, int32_t H, int32_t W, int32_t
     hipLaunchKernelGGL(ccl_merge_kernel<4>, dim3(wgrid), dim3(256), 0, ctx->stream, bits, H, W, segs, parent);
   else
     hipLaunchKernelGGL(ccl_merge_kernel<8>, dim3(wgrid), dim3(256), 0, ctx->stream, bits, H, W, segs, parent);
-  hipLaunchKernelGGL(ccl_flatten_kernel, dim3(wgrid), dim3(256), 0, ctx->stream, parent, H, W, segs, cid, cap, raw, count, key_is_root);
+  hipLaunchKernelGGL(ccl_flatten_kernel, dim3((unsigned)((units_total + 15) / 16)), dim3(1024), 0, ctx->stream, parent, H, W, segs, cid, cap, raw, count,
+                     key_is_root);
   hipLaunchKernelGGL(ccl_stats_kernel, dim3((unsigned)((units_total + units - 1) / units)), dim3(1024), 0, ctx->stream, parent, cid, H, W, segs, cap, raw,
                      key_is_root, units);
   const unsigned cgrid = (unsigned)((cap + 1 + 255) / 256);
