@@ -360,6 +360,8 @@ int rhccq_gap_bridge(rhccq_ctx* ctx, const uint8_t* in, const void* counts /* u1
 int rhccq_dist_chamfer(rhccq_ctx* ctx, const uint8_t* mask, int32_t H, int32_t W, uint16_t* hz_tmp, int32_t* dist);
 int rhccq_binary_sobel(rhccq_ctx* ctx, const uint8_t* mask, int32_t H, int32_t W, uint8_t* m2, int32_t* max_out);
 int rhccq_lut_u8(rhccq_ctx* ctx, const uint8_t* in, const uint8_t* lut256, int64_t n, uint8_t* out);
+/* out[p] = table[values[p]]: float32 table (device, n_table entries) indexed by a u16 plane (window counts -> densities) */
+int rhccq_lut_u16_f32(rhccq_ctx* ctx, const uint16_t* values, const float* table, int32_t n_table, int64_t n, float* out);
 int rhccq_label_sum(rhccq_ctx* ctx, const int32_t* labels, const void* values, int32_t value_bytes, int64_t n_pixels, int32_t n_labels,
                     uint64_t* sums);
 /* hist (device u64[n_bins], n_bins <= 4096): histogram of the u16 plane over the pixels where mask is set (larger values ignored);

@@ -252,14 +252,17 @@ def compute_local_density(binary_map, kernel_size=15):
     if nz.size:
         value = float(nz.flat[0]) / 255.0 if bm.max() > 1 else float(nz.flat[0])
     term = np.float32(kernel[0, 0] * np.float32(value))
-    cnt = rh.box_count(torch.from_numpy(np.ascontiguousarray(bm != 0).view(np.uint8)).to(rh.device), kernel_size).cpu().numpy().view(np.uint16)
+    cnt = rh.box_count(torch.from_numpy(np.ascontiguousarray(bm != 0).view(np.uint8)).to(rh.device), kernel_size)
     if k2 < 130:
         table = np.zeros(k2 + 1, np.float32)
         for m in range(1, k2 + 1):
             table[m] = np.float32(table[m - 1] + term)
     else:
         table = (np.arange(k2 + 1, dtype=np.float32) * term).astype(np.float32)
-    return table[cnt]
+    d_table = rh.dev(table)
+    out = rh.empty(tuple(cnt.shape), torch.float32)
+    rh._check(rh.lib.rhccq_lut_u16_f32(rh.ctx, rh._p(cnt), rh._p(d_table), len(table), cnt.numel(), rh._p(out)), "lut_u16_f32")
+    return out.cpu().numpy()
 
 
 def suggest_automatic_threshold(edge_density_map, edge_map, method="mean"):

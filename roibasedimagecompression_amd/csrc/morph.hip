@@ -159,6 +159,13 @@ __global__ __launch_bounds__(256) void lut_u8_kernel(const uint8_t* __restrict__
   if (p < n) out[p] = lut[in[p]];
 }
 
+// out[p] = table[values[p]] (float32 table indexed by a u16 plane: window counts -> OpenCV's float32 densities)
+__global__ __launch_bounds__(256) void lut_u16_f32_kernel(const uint16_t* __restrict__ values, const float* __restrict__ table, int n_table, long long n,
+                                                          float* __restrict__ out) {
+  const long long p = (long long)blockIdx.x * 256 + threadIdx.x;
+  if (p < n) out[p] = table[min((int)values[p], n_table - 1)];
+}
+
 // ---- per label: sum of a u16 plane (box counts) or of an int32 plane (fixed-point distances), int64 accumulators.  A workgroup
 // walks a contiguous chunk of pixels and gathers its sums in an LDS table keyed by label (the background and the large
 // components would otherwise serialise a hundred thousand atomics on one address: 69 ms at 4K); only the occupied slots reach
@@ -284,6 +291,13 @@ int rhccq_binary_sobel(rhccq_ctx* ctx, const uint8_t* mask, int32_t H, int32_t W
 int rhccq_lut_u8(rhccq_ctx* ctx, const uint8_t* in, const uint8_t* lut256, int64_t n, uint8_t* out) {
   if (!ctx || !in || !lut256 || !out || n <= 0) return rhccq_fail(ctx, RHCCQ_E_ARG, "lut_u8: bad argument");
   hipLaunchKernelGGL(lut_u8_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, ctx->stream, in, lut256, (long long)n, out);
+  RHCCQ_LAUNCH_CHECK(ctx);
+  return 0;
+}
+
+int rhccq_lut_u16_f32(rhccq_ctx* ctx, const uint16_t* values, const float* table, int32_t n_table, int64_t n, float* out) {
+  if (!ctx || !values || !table || !out || n <= 0 || n_table <= 0) return rhccq_fail(ctx, RHCCQ_E_ARG, "lut_u16_f32: bad argument");
+  hipLaunchKernelGGL(lut_u16_f32_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, ctx->stream, values, table, n_table, (long long)n, out);
   RHCCQ_LAUNCH_CHECK(ctx);
   return 0;
 }
