@@ -143,16 +143,34 @@ class EdgeAnalysis:
         hi = max(lo + 10, min(255, hi))
         return lo, hi
 
-    def score(self, low, high):
-        """evaluate_edge_quality(cv2.Canny(gray, low, high), gray) without the edge map: (score, fraction of edge pixels)"""
+    @staticmethod
+    def _norm(low, high):
         low, high = math.floor(low), math.floor(high)
-        if low > high:
-            low, high = high, low
-        _, _, (n_comp, n_edge, s1, s2) = self.rh.canny_components(self.nm(False), low, max(high, 0), self.gray)
+        return (high, low) if low > high else (low, high)
+
+    def _score_of(self, four):
+        n_comp, n_edge, s1, s2 = four
         if n_comp == 0:
             return float("nan"), 0.0
         contrast = math.sqrt(n_edge * s2 - s1 * s1) / n_edge       # population standard deviation from exact integer sums
         return (n_edge / n_comp) * contrast, n_edge / (self.H * self.W)
+
+    def score(self, low, high):
+        """evaluate_edge_quality(cv2.Canny(gray, low, high), gray) without the edge map: (score, fraction of edge pixels)"""
+        low, high = self._norm(low, high)
+        return self._score_of(self.rh.canny_components(self.nm(False), low, max(high, 0), self.gray)[2])
+
+    def scores(self, pairs):
+        """{(low, high): score(low, high)} for several threshold pairs: pairs that share `low` share the labelling of {nm > low} and the
+        per-label reduction; only the verdict against `high` (32 bytes back) is repeated"""
+        out, by_low = {}, {}
+        for lo, hi in pairs:
+            by_low.setdefault(self._norm(lo, hi)[0], set()).add((lo, hi))
+        for low, group in by_low.items():
+            n, _, stats, red = self.rh.canny_label(self.nm(False), low, self.gray)
+            for lo, hi in group:
+                out[(lo, hi)] = self._score_of(self.rh.canny_verdict(n, stats, red, max(self._norm(lo, hi)[1], 0))[1])
+        return out
 
     def canny(self, low, high, colour=False):
         """cv2.Canny(gray or colour image, low, high) -> uint8[H,W] device (0 / 255)"""
@@ -171,17 +189,15 @@ def compute_adaptive_canny_thresholds(image, method="otsu", sensitivity=1.0):
 def _best_thresholds(a, debug=False):
     """the threshold search of edges.py:40-71 on one EdgeAnalysis: -> (low, high, method)"""
     best_score, best = -1, None
-    cache = {}
-    for method in ("otsu", "percentile", "gradient", "hybrid"):
-        for sensitivity in (0.5, 0.7, 1.0, 1.3, 1.5):
-            lo, hi = a.thresholds(method, sensitivity)
-            if (lo, hi) not in cache:
-                cache[(lo, hi)] = a.score(lo, hi)
-            score, density = cache[(lo, hi)]
-            if debug:
-                print(f"{method} (sens: {sensitivity}): ({lo}, {hi}) -> density: {density:.4f}, score: {score:.4f}")
-            if score > best_score:
-                best_score, best = score, (lo, hi, method)
+    grid = [(method, sensitivity) + a.thresholds(method, sensitivity) for method in ("otsu", "percentile", "gradient", "hybrid")
+            for sensitivity in (0.5, 0.7, 1.0, 1.3, 1.5)]
+    cache = a.scores({(lo, hi) for _, _, lo, hi in grid})
+    for method, sensitivity, lo, hi in grid:                  # the reference's iteration order: the first best score wins
+        score, density = cache[(lo, hi)]
+        if debug:
+            print(f"{method} (sens: {sensitivity}): ({lo}, {hi}) -> density: {density:.4f}, score: {score:.4f}")
+        if score > best_score:
+            best_score, best = score, (lo, hi, method)
     if best is None:
         raise UnboundLocalError("find_best_edges_by_quality: no threshold pair produced an edge")
     return best

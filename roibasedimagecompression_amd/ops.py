@@ -753,20 +753,30 @@ class Rhccq:
         self._check(self.lib.rhccq_canny_nms(self.ctx, self._p(img), H, W, cn, self._p(mag), self._p(dxy), self._p(nm)), "canny_nms")
         return nm
 
-    def canny_components(self, nm, low, high, gray=None, want_lut=False):
-        """Canny's hysteresis on the device: components of {nm > low} (rhccq_ccl), per-label max of nm (+ sums of gray), verdict "max > high".
-        -> (labels int32[H,W] device, lut uint8[n + 1] device or None, (edge components, edge pixels, sum gray, sum gray^2) as Python ints);
-        only the component count and those four numbers cross to the host"""
+    def canny_label(self, nm, low, gray=None):
+        """first half of Canny's hysteresis on the device: components of {nm > low} (rhccq_ccl) and per label the max of nm (+ sums of gray).
+        -> (n, labels int32[H,W] device, stats device int32[cap + 1][5], red device int64[n + 1][3]); only the component count crosses to the host"""
         H, W = int(nm.shape[0]), int(nm.shape[1])
         mask = self.empty((H, W), torch.uint8)
         self._check(self.lib.rhccq_edges_above(self.ctx, self._p(nm), H * W, int(low), self._p(mask)), "edges_above")
         n, labels, stats = self.ccl(mask, 8, cap=1 << 16, host_stats=False)
         red = self.empty((n + 1, 3), torch.int64)
         self._check(self.lib.rhccq_label_reduce(self.ctx, self._p(labels), self._p(nm), self._p(gray), labels.numel(), n, self._p(red)), "label_reduce")
+        return n, labels, stats, red
+
+    def canny_verdict(self, n, stats, red, high, want_lut=False):
+        """second half: a component is an edge when its max exceeds `high`.  -> (lut uint8[n + 1] device or None, (edge components, edge
+        pixels, sum gray, sum gray^2) as Python ints): 32 bytes cross to the host"""
         out4 = self.empty((4,), torch.int64)
         lut = self.empty((n + 1,), torch.uint8) if want_lut else None
         self._check(self.lib.rhccq_edge_score(self.ctx, self._p(stats), self._p(red), n, int(high), self._p(out4), self._p(lut)), "edge_score")
-        return labels, lut, tuple(int(v) for v in out4.cpu().numpy())
+        return lut, tuple(int(v) for v in out4.cpu().numpy())
+
+    def canny_components(self, nm, low, high, gray=None, want_lut=False):
+        """both halves -> (labels, lut or None, the four numbers)"""
+        n, labels, stats, red = self.canny_label(nm, low, gray)
+        lut, four = self.canny_verdict(n, stats, red, high, want_lut)
+        return labels, lut, four
 
     def label_reduce(self, labels, n, val16=None, val8=None):
         """-> np.uint64[n + 1, 3]: per label {max of val16, sum of val8, sum of val8^2}"""
