@@ -22,6 +22,14 @@ Parity pins (see DESIGN.md "Oracle"):
     stable (tests/golden/make_golden_mbk.py, G11); wherever that step does not trigger (k < 500) the untouched fit, i.e.
     the reference's own result, is reproduced.
 
+  * PARITY UNPINNED (say so wherever these are cited): the stages UPSTREAM of the hot path lean on libraries that are absent
+    from the build container -- scikit-image (split score, masked SLIC, SSIM: sk_* / slic_* / structural_similarity_win7) and
+    OpenCV (the whole ROI stage: cv_* , get_edge_map, the clean-up chain, connected components and their numbering).  They
+    are restated from the libraries' published algorithms; what pins them is (a) scipy, wherever the reference itself or
+    scikit-image calls it (extract_roi_nonroi's dilations, resize's gaussian_filter / zoom), (b) known answers that need no
+    library (tests/test_roi_cpu.py), and (c) Tier B end to end: the whole script flow lands within 0.15 dB / 3.2 % of the
+    artefacts the reference ships (tests/test_gpu_notebook.py).
+
 Canonical k-means arithmetic "KM64" (shared with csrc/):
   * points are integer colours p in [0,255]^3;
   * k-means++ works on EXACT integer squared distances between data points
