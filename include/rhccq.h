@@ -127,6 +127,13 @@ int rhccq_job_index(rhccq_ctx* ctx, const uint8_t* rgb, int32_t H, int32_t W, in
  * r2: double[n_prob].  labels_out int32 (same offsets), ncomp_out int32[n_prob]. */
 int rhccq_eps_components(rhccq_ctx* ctx, const uint32_t* keys, const int32_t* desc, const double* r2,
                          int32_t n_prob, int32_t max_n, int32_t* labels_out, int32_t* ncomp_out);
+/* DBSCAN with min_samples > 1 (clustering.py:233-271: noise points exist then).  rhccq_eps_counts: counts[i] = number of palette points
+ * within eps of point i, itself included (a core point has >= min_samples); rhccq_eps_border: labels_out[i] = core_label[i] for a core
+ * point (its component's label from rhccq_eps_components on the core subset, in sklearn's order), else the smallest label among its
+ * core neighbours, -1 (noise) if it has none.  thr / boundary / r2 as in rhccq_eps_components (rhccq_eps_threshold). */
+int rhccq_eps_counts(rhccq_ctx* ctx, const uint32_t* keys, int32_t n, int32_t thr, int32_t boundary, double r2, int32_t* counts);
+int rhccq_eps_border(rhccq_ctx* ctx, const uint32_t* keys, int32_t n, int32_t thr, int32_t boundary, double r2, const int32_t* core_label,
+                     int32_t* labels_out);
 
 /* ---- K2: per-cluster floor-mean colour (clustering.py:304-310,346-355) ----------------------
  * sums[k*4] (uint64 r,g,b,count) zero-initialised by the caller; labels < 0 are skipped. */

@@ -540,8 +540,49 @@ def mt_position(rs):
 # --------------------------------------------------------------------------------------
 # cluster_palette_colors_parallel  (clustering.py:160-437)
 # --------------------------------------------------------------------------------------
+def dbscan_labels(colors, eps, min_samples):
+    """sklearn DBSCAN(eps / 255, min_samples, 'euclidean').fit_predict(colors / 255) (clustering.py:233-235) for any min_samples:
+    core points = at least min_samples points within eps, itself included; dbscan_inner seeds clusters at the core points in index
+    order and grows them depth first through core points, labelling every point it reaches that has no label yet: clusters = the
+    eps-components of the core points, numbered by their lowest core index; a non-core point is first reached from the cluster
+    with the lowest number among its core neighbours; -1 = noise."""
+    colors = np.asarray(colors, dtype=np.int64).reshape(-1, 3)
+    n = len(colors)
+    if n == 0:
+        return np.zeros(0, np.int32)
+    thr, boundary = eps_threshold(eps)
+    f = colors.astype(np.float64) / np.float64(255.0)
+    r = np.float64(eps) / np.float64(255.0)
+    adj = np.zeros((n, n), bool)
+    for s0 in range(0, n, 1024):
+        a = colors[s0:s0 + 1024]
+        d2 = ((a[:, None, :] - colors[None, :, :]) ** 2).sum(-1)
+        blk = d2 <= thr
+        if boundary >= 0:
+            bi, bj = np.nonzero(d2 == boundary)
+            if len(bi):
+                t = f[s0 + bi] - f[bj]
+                blk[bi, bj] = ((t[:, 0] * t[:, 0] + t[:, 1] * t[:, 1]) + t[:, 2] * t[:, 2]) <= r * r
+        adj[s0:s0 + 1024] = blk
+    core = adj.sum(1) >= min_samples
+    labels = np.full(n, -1, np.int32)
+    nxt = 0
+    for i in range(n):                                        # dbscan_inner, literally
+        if labels[i] != -1 or not core[i]:
+            continue
+        stack = [i]
+        while stack:
+            v = stack.pop()
+            if labels[v] == -1:
+                labels[v] = nxt
+                if core[v]:
+                    stack.extend(int(u) for u in np.nonzero(adj[v] & (labels == -1))[0])
+        nxt += 1
+    return labels
+
+
 def cluster_palette(quality, palette, indices, eps, mc, kmeans=kmeans_labels,
-                    minibatch=minibatch_kmeans_labels, return_info=False):
+                    minibatch=minibatch_kmeans_labels, return_info=False, min_samples=1):
     """Returns (new_palette uint8[K,3], new_indices int64[h*w]).
 
     Order of the new palette: black rows; clusters with size <= mc in
@@ -565,14 +606,17 @@ def cluster_palette(quality, palette, indices, eps, mc, kmeans=kmeans_labels,
         labels = minibatch(nb, k)
         info["branch"] = "minibatch"
     else:
-        labels = eps_components(nb, eps)
+        labels = eps_components(nb, eps) if min_samples == 1 else dbscan_labels(nb, eps, min_samples)
         info["branch"] = "dbscan"
     new_pal = []
     mapping = np.zeros(P, np.uint16)                        # unmapped -> 0
     for b in black_idx:
         mapping[b] = len(new_pal) & 0xFFFF
         new_pal.append(palette[b])
-    present = np.unique(labels)
+    for rel in np.nonzero(labels == -1)[0]:                  # noise colours keep themselves (clustering.py:262-271)
+        mapping[nb_idx[rel]] = len(new_pal) & 0xFFFF
+        new_pal.append(palette[nb_idx[rel]])
+    present = np.unique(labels[labels >= 0])
     keys = pack_rgb(palette)
     order = np.argsort(keys, kind="stable")
     sorted_keys = keys[order]

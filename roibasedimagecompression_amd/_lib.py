@@ -90,6 +90,8 @@ PROTOTYPES = {
     "rhccq_zoom_nearest": (c_int32, [c_void_p, c_void_p, c_int32, c_int32, c_int32, c_int32, c_void_p, c_void_p, c_int32, c_int32, c_void_p]),
     "rhccq_edge_score": (c_int32, [c_void_p, c_void_p, c_void_p, c_int32, c_int32, c_void_p, c_void_p]),
     "rhccq_lut_u16_f32": (c_int32, [c_void_p, c_void_p, c_void_p, c_int32, c_int64, c_void_p]),
+    "rhccq_eps_counts": (c_int32, [c_void_p, c_void_p, c_int32, c_int32, c_int32, c_double, c_void_p]),
+    "rhccq_eps_border": (c_int32, [c_void_p, c_void_p, c_int32, c_int32, c_int32, c_double, c_void_p, c_void_p]),
     "rhccq_mt_uniforms": (c_int32, [c_void_p, c_void_p, c_int64, c_int64, c_void_p]),
     "rhccq_mbk_order_bytes": (c_int64, [c_int64]),
     "rhccq_mbk_order": (c_int32, [c_void_p, c_void_p, C.POINTER(MbkProblem), c_int32, c_void_p, c_void_p, c_void_p, c_int64]),

@@ -44,16 +44,15 @@ def compute_clustering_params(n_colors, quality, color_space="rgb"):
 
 
 def cluster_palette_colors_parallel(quality, compressed_data, eps=10.0, min_samples=2, max_colors_per_cluster=5, num_workers=None):
-    if min_samples != 1:
-        raise NotImplementedError("the RHCCQ pipeline always clusters with min_samples=1 (subregions.py:447, regions.py:65, "
-                                  "image.py:277); DBSCAN with noise points is not on the MI355X path")
+    if min_samples < 1:
+        raise ValueError("min_samples must be >= 1")              # (sklearn's own parameter check)
     rh = default_context()
     palette = np.array(compressed_data["palette"], dtype=np.uint8).reshape(-1, 3)
     h, w = compressed_data["shape"]
     keys = pack_rgb(palette)
     if not np.any(keys != 0):
         return compressed_data                                    # "only black": returned unchanged (clustering.py:197-199)
-    new_keys, mapping, info = _cluster_palette(rh, quality, keys, eps, max_colors_per_cluster)
+    new_keys, mapping, info = _cluster_palette(rh, quality, keys, eps, max_colors_per_cluster, min_samples)
     import torch
     ind = compressed_data["indices"]
     d_idx = ind.device_tensor(rh) if isinstance(ind, IndexList) else torch.from_numpy(

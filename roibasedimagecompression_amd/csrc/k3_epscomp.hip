@@ -471,6 +471,49 @@ __global__ __launch_bounds__(kEpsThreads) void eps_components_kernel(const uint3
   }
 }
 
+// ---- DBSCAN with min_samples > 1 (clustering.py:233-271; no call site of the pipeline uses it, the function's own default is 2):
+// neighbour counts (self included) by brute force over LDS tiles -- a palette on this branch has < 10 000 colours -- then, with the
+// core points' component labels known (the kernel above on the core subset), every other point takes the smallest label among its
+// core neighbours (sklearn's dbscan_inner reaches a border point first from the cluster with the lowest seed), -1 = noise.
+__global__ __launch_bounds__(256) void eps_count_kernel(const uint32_t* __restrict__ keys, int n, int thr, int boundary, double r2, int32_t* __restrict__ counts) {
+  __shared__ uint32_t tile[1024];
+  const int i = blockIdx.x * 256 + threadIdx.x;
+  const uint32_t ka = i < n ? keys[i] : 0u;
+  int cnt = 0;
+  for (int t0 = 0; t0 < n; t0 += 1024) {
+    for (int j = threadIdx.x; j < 1024; j += 256) tile[j] = t0 + j < n ? keys[t0 + j] : 0u;
+    __syncthreads();
+    const int m = min(1024, n - t0);
+    if (i < n)
+      for (int j = 0; j < m; ++j) cnt += is_neighbor(ka, tile[j], thr, boundary, r2) ? 1 : 0;
+    __syncthreads();
+  }
+  if (i < n) counts[i] = cnt;
+}
+
+__global__ __launch_bounds__(256) void eps_border_kernel(const uint32_t* __restrict__ keys, int n, int thr, int boundary, double r2,
+                                                         const int32_t* __restrict__ core_label /* -1: not a core point */, int32_t* __restrict__ out) {
+  __shared__ uint32_t tile[1024];
+  __shared__ int32_t tlab[1024];
+  const int i = blockIdx.x * 256 + threadIdx.x;
+  const uint32_t ka = i < n ? keys[i] : 0u;
+  const int mine = i < n ? core_label[i] : 0;
+  int best = 0x7fffffff;
+  for (int t0 = 0; t0 < n; t0 += 1024) {
+    for (int j = threadIdx.x; j < 1024; j += 256) {
+      tile[j] = t0 + j < n ? keys[t0 + j] : 0u;
+      tlab[j] = t0 + j < n ? core_label[t0 + j] : -1;
+    }
+    __syncthreads();
+    const int m = min(1024, n - t0);
+    if (i < n && mine < 0)
+      for (int j = 0; j < m; ++j)
+        if (tlab[j] >= 0 && tlab[j] < best && is_neighbor(ka, tile[j], thr, boundary, r2)) best = tlab[j];
+    __syncthreads();
+  }
+  if (i < n) out[i] = mine >= 0 ? mine : (best == 0x7fffffff ? -1 : best);
+}
+
 }  // namespace rhccq
 
 using namespace rhccq;
@@ -497,6 +540,21 @@ extern "C" int rhccq_eps_components(rhccq_ctx* ctx, const uint32_t* keys, const 
   hipLaunchKernelGGL(eps_components_lds_kernel, dim3(n_prob), dim3(kEpsThreads), 0, ctx->stream, keys, desc, r2, labels_out, ncomp_out);
   if (max_n > RHCCQ_EPS_LDS_MAX)
     hipLaunchKernelGGL(eps_components_kernel, dim3(n_prob), dim3(kEpsThreads), 0, ctx->stream, keys, desc, r2, labels_out, ncomp_out, gwork, stride);
+  RHCCQ_LAUNCH_CHECK(ctx);
+  return 0;
+}
+
+extern "C" int rhccq_eps_counts(rhccq_ctx* ctx, const uint32_t* keys, int32_t n, int32_t thr, int32_t boundary, double r2, int32_t* counts) {
+  if (!ctx || !keys || !counts || n <= 0) return rhccq_fail(ctx, RHCCQ_E_ARG, "eps_counts: bad argument");
+  hipLaunchKernelGGL(eps_count_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, ctx->stream, keys, n, thr, boundary, r2, counts);
+  RHCCQ_LAUNCH_CHECK(ctx);
+  return 0;
+}
+
+extern "C" int rhccq_eps_border(rhccq_ctx* ctx, const uint32_t* keys, int32_t n, int32_t thr, int32_t boundary, double r2, const int32_t* core_label,
+                                int32_t* labels_out) {
+  if (!ctx || !keys || !core_label || !labels_out || n <= 0) return rhccq_fail(ctx, RHCCQ_E_ARG, "eps_border: bad argument");
+  hipLaunchKernelGGL(eps_border_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, ctx->stream, keys, n, thr, boundary, r2, core_label, labels_out);
   RHCCQ_LAUNCH_CHECK(ctx);
   return 0;
 }

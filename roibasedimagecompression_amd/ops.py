@@ -364,6 +364,29 @@ class Rhccq:
         nc = ncomp.cpu().numpy()
         return [lab[offs[i]:offs[i + 1]] for i in range(n_prob)], [int(v) for v in nc]
 
+    def dbscan_labels(self, keys, eps, min_samples):
+        """sklearn DBSCAN(eps / 255, min_samples).fit_predict on one palette (uint32 keys, < 10 000 colours): core points = at least
+        min_samples colours within eps (itself included); clusters = eps-components of the core points, numbered by their lowest core
+        index; a non-core point takes the smallest label among its core neighbours, -1 (noise) without one.  -> int32 numpy labels"""
+        keys = np.ascontiguousarray(keys).astype(np.uint32)
+        n = len(keys)
+        if n == 0:
+            return np.zeros(0, np.int32)
+        if min_samples <= 1:
+            return self.eps_components([keys], [eps])[0][0]
+        thr, bnd, rr = eps_threshold(eps)
+        d_keys = self.dev(keys.view(np.int32))
+        counts = self.empty((n,), torch.int32)
+        self._check(self.lib.rhccq_eps_counts(self.ctx, self._p(d_keys), n, thr, bnd, rr, self._p(counts)), "eps_counts")
+        core = counts.cpu().numpy() >= int(min_samples)
+        core_label = np.full(n, -1, np.int32)
+        if core.any():
+            core_label[core] = self.eps_components([keys[core]], [eps])[0][0]
+        d_core = self.dev(core_label)
+        out = self.empty((n,), torch.int32)
+        self._check(self.lib.rhccq_eps_border(self.ctx, self._p(d_keys), n, thr, bnd, rr, self._p(d_core), self._p(out)), "eps_border")
+        return out.cpu().numpy()
+
     # -- K7 -----------------------------------------------------------------------------------------
     def kmeans_split(self, key_list, k_list, return_info=False):
         """Batched KMeans(k, random_state=42).fit_predict labels (KM64).  numpy in / numpy out."""

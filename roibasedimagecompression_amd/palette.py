@@ -122,6 +122,10 @@ def cluster_palettes(rh, jobs):
             labels[s] = jb.pop("_labels")
             continue
         (mb_jobs if n >= MINIBATCH_THRESHOLD else db_jobs).append(s)
+    ms_jobs = [s for s in db_jobs if jobs[s].get("min_samples", 1) > 1]      # noise points exist (clustering.py:233-271)
+    db_jobs = [s for s in db_jobs if s not in ms_jobs]
+    for s in ms_jobs:
+        labels[s] = rh.dbscan_labels(jobs[s]["keys"][nb_idx[s]], jobs[s]["eps"], jobs[s]["min_samples"])
     if db_jobs:
         labs, _ = rh.eps_components([jobs[s]["keys"][nb_idx[s]] for s in db_jobs], [jobs[s]["eps"] for s in db_jobs])
         for s, l in zip(db_jobs, labs):
@@ -135,23 +139,31 @@ def cluster_palettes(rh, jobs):
     # oversize ones (breadth first on the device, depth-first output order)
     small_leaf = [None] * S        # per job: leaf id (within the job's small clusters) per label, -1 = oversize
     n_small = [0] * S
+    noise_of = [None] * S          # per job: indices of the noise points (label -1): each keeps its own colour, listed right
+    #                                behind the black rows in index order (clustering.py:262-271) = the first "small" leaves
     larges = [[] for _ in range(S)]
     frontier = []
     for s in range(S):
         if labels[s] is None:
             continue
         lab = labels[s]
+        noise = np.nonzero(lab < 0)[0]
+        noise_of[s] = noise
+        if len(noise):
+            lab = np.where(lab < 0, int(lab.max()) + 1, lab)   # parked behind the last real label, never "big", never "small"
         cnt = np.bincount(lab)
+        if len(noise):
+            cnt[-1] = 0
         present = cnt > 0
         big = cnt > jobs[s]["mc"]
         is_small = present & ~big
         sl = np.full(len(cnt), -1, np.int64)
-        sl[is_small] = np.arange(int(is_small.sum()))          # ascending label order
+        sl[is_small] = len(noise) + np.arange(int(is_small.sum()))          # ascending label order, behind the noise leaves
         small_leaf[s] = sl
-        n_small[s] = int(is_small.sum())
+        n_small[s] = len(noise) + int(is_small.sum())
         if big.any():
             order = _stable_order(lab)
-            starts = np.concatenate([[0], np.cumsum(cnt)])
+            starts = np.concatenate([[0], np.cumsum(np.bincount(lab))])
             for l in np.nonzero(big)[0]:                       # ascending label; ascending index inside
                 node = _Node(s, order[starts[l]:starts[l + 1]])
                 larges[s].append(node)
@@ -208,7 +220,8 @@ def cluster_palettes(rh, jobs):
                     walk(ch)
         for nd in larges[s]:
             walk(nd)
-        leaf_of = small_leaf[s][labels[s]]                      # -1 where the point sits in an oversize cluster
+        leaf_of = small_leaf[s][np.where(labels[s] < 0, 0, labels[s])]      # -1 where the point sits in an oversize cluster
+        leaf_of[noise_of[s]] = np.arange(len(noise_of[s]))
         for li, rel in enumerate(split_leaves):
             leaf_of[rel] = n_small[s] + li
         n_leaves = n_small[s] + len(split_leaves)
@@ -246,13 +259,13 @@ def cluster_palettes(rh, jobs):
                 first = order[np.searchsorted(skeys, keys[tgt], side="left")]
                 mapping[tgt[first != tgt]] = 0
         info = {"branch": "minibatch" if len(nb) >= MINIBATCH_THRESHOLD else "dbscan",
-                "n_clusters": n_small[s] + len(larges[s]), "n_large": len(larges[s])}
+                "n_clusters": n_small[s] - len(noise_of[s]) + len(larges[s]), "n_large": len(larges[s]), "n_noise": int(len(noise_of[s]))}
         results.append((new_keys, mapping, info))
     return results
 
 
-def cluster_palette(rh, quality, keys, eps, mc):
-    return cluster_palettes(rh, [{"keys": keys, "quality": quality, "eps": eps, "mc": mc}])[0]
+def cluster_palette(rh, quality, keys, eps, mc, min_samples=1):
+    return cluster_palettes(rh, [{"keys": keys, "quality": quality, "eps": eps, "mc": mc, "min_samples": int(min_samples)}])[0]
 
 
 def merge_components(rh, comps, bbox):

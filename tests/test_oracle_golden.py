@@ -125,6 +125,40 @@ def test_g4_cluster_palette():
     assert tiers["A"] + tiers["A'"] >= 18
 
 
+def test_g13_dbscan_with_noise_points():
+    """cluster_palette_colors_parallel with min_samples > 1 (the function's own default is 2; the pipeline passes 1): sklearn's DBSCAN
+    labels -- core points, border points, noise (-1) -- on all 24 recorded palettes, then the function's output: noise colours keep
+    themselves right behind the black rows (clustering.py:262-271).  Tiers as in G4."""
+    g = load("g13_dbscan_min_samples.npz")
+    tiers = {"A": 0, "A'": 0, "B": 0}
+    noise_cases = exact_without_split = 0
+    for i in range(int(g["n"])):
+        img, (q, ms) = g[f"img{i}"], (int(v) for v in g[f"qm{i}"])
+        pal, idx = O.unique_colors(img)
+        eps, _, mc = O.clustering_params(len(pal), q)
+        nb = pal[~np.all(pal == 0, axis=1)]
+        lab = O.dbscan_labels(nb, eps, ms)
+        assert np.array_equal(lab, g[f"lab{i}"]), (i, q, ms)                      # sklearn's labels, every case
+        noise_cases += bool((lab == -1).any())
+        npal, nidx, info = O.cluster_palette(q, pal, idx, eps, mc, min_samples=ms, return_info=True)
+        gp, gi = g[f"pal{i}"], g[f"idx{i}"]
+        if np.array_equal(npal, gp) and np.array_equal(nidx, gi):
+            tiers["A"] += 1
+            exact_without_split += info["n_large"] == 0
+        elif info["n_large"] == 0:
+            raise AssertionError(("no KMeans split involved, yet not identical to the reference", i, q, ms))
+        elif len(npal) == len(gp) and np.array_equal(npal[nidx], gp[gi]):
+            tiers["A'"] += 1
+        else:
+            # (the oversize-cluster KMeans split with exactly tied k-means++ potentials, as in G4; the 8-step lattice crop ties most)
+            tiers["B"] += 1
+            assert abs(len(npal) - len(gp)) <= 0.10 * len(gp), (i, q, ms, len(npal), len(gp))
+            assert abs(psnr(gp[gi], img.reshape(-1, 3)) - psnr(npal[nidx], img.reshape(-1, 3))) < 0.5, (i, q, ms)
+    print("g13 tiers", tiers, "cases with noise", noise_cases, "exact without a split", exact_without_split)
+    assert noise_cases == 14 and exact_without_split == 5       # every case that involves no KMeans split is bit-identical (the raise above)
+    assert tiers == {"A": 8, "A'": 6, "B": 10}, tiers
+
+
 def test_g10_minibatch_reference_function_bit_exact():
     """cluster_palette_colors_parallel itself (the reference's function, MiniBatchKMeans branch, clustering.py:207-230) on a
     192x192 Lenna crop at q = 10 / 20 (k = 330 / 659): with the sklearn-faithful restatement the palette and every index are
