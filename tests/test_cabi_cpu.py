@@ -120,6 +120,8 @@ def test_reference_tree_behind_the_repository_is_not_shadowed(tmp_path):
     (ref / "decoder/uncompression/comparison.py").write_text("def plot_comparison(*a):\n    return 'reference plot'\n")
     (ref / "encoder/compression").mkdir()
     (ref / "encoder/compression/clustering.py").write_text("raise RuntimeError('the hot-path module must come from the repository')\n")
+    (ref / "encoder/compression/image.py").write_text("def fill_black_holes_vectorized(*a):\n    return 'reference filler'\n"
+                                                      "def quantize_image(*a, **k):\n    return 'reference quantize_image'\n")
     (ref / "other/jpeg.py").write_text("Q = 3\n")
     code = textwrap.dedent(f"""
         import sys
@@ -129,6 +131,8 @@ def test_reference_tree_behind_the_repository_is_not_shadowed(tmp_path):
         from encoder.enhancer.clahe import get_enhanced_image
         from decoder.uncompression.comparison import plot_comparison, calculate_quality_metrics
         import encoder.compression.clustering as c
+        from encoder.compression.image import fill_black_holes_vectorized, quantize_image     # an unused variant / the hot path
+        assert fill_black_holes_vectorized() == 'reference filler' and quantize_image.__module__.startswith('roibasedimagecompression_amd')
         import other.jpeg
         assert bridge_small_gaps() == 'reference small_gaps' and VALUE == 41 and get_enhanced_image() == 'reference clahe'
         assert plot_comparison() == 'reference plot' and calculate_quality_metrics.__module__.startswith('roibasedimagecompression_amd')
