@@ -94,20 +94,43 @@ __global__ __launch_bounds__(256) void gap_bridge_kernel(const uint8_t* __restri
 constexpr int kChamA = 62587, kChamB = 89738, kChamMax = 0x7fffffff >> 2;
 constexpr int kHzNone = 0xffff;
 
-__global__ __launch_bounds__(64) void dist_hz_kernel(const uint8_t* __restrict__ mask, int H, int W, uint16_t* __restrict__ hz) {
-  const int y = blockIdx.x * 64 + threadIdx.x;
-  if (y >= H) return;
+// hz[y][x] = horizontal distance to the nearest unset pixel of row y (kHzNone: the row has none).  One workgroup per row: a thread owns
+// a run of consecutive columns, notes its first / last unset column, the workgroup scans those (running max of "last" from the left,
+// running min of "first" from the right), then every thread walks its columns once in each direction.
+__global__ __launch_bounds__(256) void dist_hz_kernel(const uint8_t* __restrict__ mask, int H, int W, uint16_t* __restrict__ hz) {
+  __shared__ int s_last[256], s_first[256];
+  const int y = blockIdx.x, t = threadIdx.x;
   const uint8_t* row = mask + (long long)y * W;
   uint16_t* o = hz + (long long)y * W;
-  int d = kHzNone;
-  for (int x = 0; x < W; ++x) {
-    d = row[x] == 0 ? 0 : (d >= kHzNone - 1 ? kHzNone : d + 1);
-    o[x] = (uint16_t)d;
+  const int cpt = (W + 255) / 256;
+  const int x0 = min(W, t * cpt), x1 = min(W, x0 + cpt);
+  const int kFar = 0x3fffffff;
+  int last = -kFar, first = kFar;
+  for (int x = x0; x < x1; ++x)
+    if (row[x] == 0) { if (first == kFar) first = x; last = x; }
+  s_last[t] = last;
+  s_first[t] = first;
+  __syncthreads();
+  for (int d = 1; d < 256; d <<= 1) {                      // inclusive scans: max of last over threads <= t, min of first over threads >= t
+    const int a = t >= d ? s_last[t - d] : -kFar, b = t + d < 256 ? s_first[t + d] : kFar;
+    __syncthreads();
+    s_last[t] = max(s_last[t], a);
+    s_first[t] = min(s_first[t], b);
+    __syncthreads();
   }
-  d = kHzNone;
-  for (int x = W - 1; x >= 0; --x) {
-    d = row[x] == 0 ? 0 : (d >= kHzNone - 1 ? kHzNone : d + 1);
-    if (d < o[x]) o[x] = (uint16_t)d;
+  int left = t > 0 ? s_last[t - 1] : -kFar;                 // nearest unset column before this thread's run
+  const int right0 = t < 255 ? s_first[t + 1] : kFar;      // ... behind it
+  for (int x = x0; x < x1; ++x) {
+    if (row[x] == 0) left = x;
+    const int d = left == -kFar ? kHzNone : x - left;
+    o[x] = (uint16_t)(d >= kHzNone - 1 ? kHzNone : d);
+  }
+  int right = right0;
+  for (int x = x1 - 1; x >= x0; --x) {
+    if (row[x] == 0) right = x;
+    int d = right == kFar ? kHzNone : right - x;
+    if (d >= kHzNone - 1) d = kHzNone;
+    if (d < (int)o[x]) o[x] = (uint16_t)d;
   }
 }
 
@@ -274,7 +297,7 @@ int rhccq_gap_bridge(rhccq_ctx* ctx, const uint8_t* in, const void* counts, int3
 int rhccq_dist_chamfer(rhccq_ctx* ctx, const uint8_t* mask, int32_t H, int32_t W, uint16_t* hz_tmp, int32_t* dist) {
   if (!ctx || !mask || !hz_tmp || !dist || H <= 0 || W <= 0) return rhccq_fail(ctx, RHCCQ_E_ARG, "dist_chamfer: bad argument");
   if (W >= kHzNone) return rhccq_fail(ctx, RHCCQ_E_LIMIT, "dist_chamfer: rows up to 65534 pixels");
-  hipLaunchKernelGGL(dist_hz_kernel, dim3((unsigned)((H + 63) / 64)), dim3(64), 0, ctx->stream, mask, H, W, hz_tmp);
+  hipLaunchKernelGGL(dist_hz_kernel, dim3((unsigned)H), dim3(256), 0, ctx->stream, mask, H, W, hz_tmp);
   hipLaunchKernelGGL(dist_chamfer_kernel, dim3((unsigned)(((long long)H * W + 255) / 256)), dim3(256), 0, ctx->stream, hz_tmp, H, W, dist);
   RHCCQ_LAUNCH_CHECK(ctx);
   return 0;
