@@ -27,8 +27,8 @@ Parity pins (see DESIGN.md "Oracle"):
     OpenCV (the whole ROI stage: cv_* , get_edge_map, the clean-up chain, connected components and their numbering).  They
     are restated from the libraries' published algorithms; what pins them is (a) scipy, wherever the reference itself or
     scikit-image calls it (extract_roi_nonroi's dilations, resize's gaussian_filter / zoom), (b) known answers that need no
-    library (tests/test_roi_cpu.py), and (c) Tier B end to end: the whole script flow lands within 0.15 dB / 3.2 % of the
-    artefacts the reference ships (tests/test_gpu_notebook.py).
+    library (tests/test_roi_cpu.py), and (c) Tier B end to end: the whole script flow lands within 0.15 dB / 3.2 % of four
+    artefacts the reference ships and within 0.6 dB / 6.3 % of two more (tests/test_gpu_notebook.py).
 
 Canonical k-means arithmetic "KM64" (shared with csrc/):
   * points are integer colours p in [0,255]^3;

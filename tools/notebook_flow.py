@@ -61,7 +61,8 @@ def report(png, artefact, out_path):
 if __name__ == "__main__":
     g = os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "tests", "golden")
     pairs = [(os.path.join(g, "Lenna.png"), os.path.join(g, "Lenna_compressed_20_10.rhccq")), (os.path.join(g, "kodak_23.png"), os.path.join(g, "compressed_23.rhccq")),
-             (os.path.join(g, "kodak_1.png"), os.path.join(g, "compressed_1.rhccq")), (os.path.join(g, "kodak_13.png"), os.path.join(g, "compressed_13.rhccq"))]
+             (os.path.join(g, "kodak_1.png"), os.path.join(g, "compressed_1.rhccq")), (os.path.join(g, "kodak_13.png"), os.path.join(g, "compressed_13.rhccq")),
+             (os.path.join(g, "kodak_5.png"), os.path.join(g, "compressed_5.rhccq")), (os.path.join(g, "kodak_15.png"), os.path.join(g, "compressed_15.rhccq"))]
     if len(sys.argv) > 2:
         pairs = [(sys.argv[1], sys.argv[2])]
     os.makedirs("gpurun_out", exist_ok=True)
