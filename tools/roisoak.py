@@ -1,5 +1,5 @@
 """one-off soak: get_regions + extract_regions on the device vs the numpy / scipy restatement over random synthetic images:
-python tools/roisoak.py FIRST COUNT"""
+python tools/roisoak.py FIRST COUNT [MIN_EDGE MAX_EDGE]"""
 import os, sys, time
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 import numpy as np
@@ -8,11 +8,12 @@ from roibasedimagecompression_amd import synth
 from roibasedimagecompression_amd.api import roi_chain as C, roi as R
 
 first, count = int(sys.argv[1]), int(sys.argv[2])
+lo, hi = (int(sys.argv[3]), int(sys.argv[4])) if len(sys.argv) > 4 else (60, 300)            # image edge range
 bad = 0
 t0 = time.time()
 for seed in range(first, first + count):
     rng = np.random.default_rng(seed)
-    h, w = int(rng.integers(60, 300)), int(rng.integers(60, 360))
+    h, w = int(rng.integers(lo, hi)), int(rng.integers(lo, hi + 60))
     kind = seed % 3
     img = synth.photo(h, w, seed, sigma=float(rng.choice([0.5, 1.0, 2.0, 3.0]))) if kind else synth.poster(h, w, seed)
     if kind == 2:                                             # a darker flat surround: ROI and non-ROI both present
