@@ -1,7 +1,7 @@
 """one-off soak: get_regions + extract_regions on the device vs the numpy / scipy restatement over random synthetic images:
-python tools/roisoak.py FIRST COUNT [MIN_EDGE MAX_EDGE]"""
+python tests/soak/roisoak.py FIRST COUNT [MIN_EDGE MAX_EDGE]"""
 import os, sys, time
-sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__)))))
 import numpy as np
 from oracle import rhccq_oracle as O
 from roibasedimagecompression_amd import synth

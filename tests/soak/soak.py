@@ -1,8 +1,8 @@
 """one-off soak: many randomised frames, fused HIP encoder vs the oracle (same generator as tests/test_gpu_frame.py's
-fuzz test, other seeds).  python tools/soak.py FIRST COUNT"""
+fuzz test, other seeds).  python tests/soak/soak.py FIRST COUNT"""
 import os, sys, time
-sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
-sys.path.insert(0, os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "tests"))
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__)))))
+sys.path.insert(0, os.path.join(os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__)))), "tests"))
 import numpy as np
 import test_gpu_frame as T
 from roibasedimagecompression_amd.ops import Rhccq
