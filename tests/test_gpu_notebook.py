@@ -8,7 +8,6 @@ settings (tests/golden/*.rhccq, data) are the yardstick: PSNR against the origin
 import os
 import sys
 
-import numpy as np
 import pytest
 
 pytestmark = pytest.mark.gpu

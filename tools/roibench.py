@@ -1,7 +1,7 @@
 """diagnostic only: the ROI stage (get_regions + extract_regions) on a 4K synthetic photo, wall time per part (second run)"""
 import os, sys, time
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
-import numpy as np, torch
+import torch
 from roibasedimagecompression_amd import synth
 from roibasedimagecompression_amd.api import edges as E, roi_chain as C, roi as R
 
