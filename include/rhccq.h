@@ -302,7 +302,8 @@ int rhccq_zoom_nearest(rhccq_ctx* ctx, const void* in, int32_t elem_bytes, int32
  * published block-based algorithms (Grana's BBDT / Bolelli's Spaghetti, 8-connectivity) number components by their first
  * 2x2 block in block-raster order, the pixel-based 4-connectivity one by their first pixel; the partition itself is unambiguous.
  * rhccq_ccl: mask (device u8[H][W], nonzero = foreground), connectivity 4 or 8; numbering 0 = OpenCV's (above), 1 = by first
- *   pixel in raster order (scipy.ndimage.label / skimage.measure.label, roi.py:262 extract_connected_regions);
+ *   pixel in raster order (scipy.ndimage.label / skimage.measure.label, roi.py:262 extract_connected_regions), 2 = unordered ids
+ *   1..count and NO statistics (stats may be NULL; cap unused): enough to tell components apart, e.g. for Canny's hysteresis;
  *   work: rhccq_ccl_work_bytes(H, W, cap) bytes of device scratch; labels (device int32[H][W]): 0 = background, 1..count;
  *   stats (device int32[cap + 1][5]): row l = {CC_STAT_LEFT, TOP, WIDTH, HEIGHT, AREA} of label l, row 0 = the background;
  *   count (device int32): number of components.  When count > cap the labels are all 0 and the statistics meaningless:
@@ -326,7 +327,8 @@ int rhccq_roi_buffer(rhccq_ctx* ctx, const uint8_t* region_map, const uint8_t* r
  * rhccq_canny_nms: img (device u8[H][W][channels], 1 or 3) -> nm (device u16[H][W]): Canny's L1 gradient magnitude where the
  *   pixel is a local maximum along its gradient direction, 0 elsewhere (threshold independent); mag_tmp u16[H*W], dxy_tmp int32[H*W].
  * rhccq_edges_above: mask[p] = nm[p] > low.
- * rhccq_label_reduce: red (device u64[n_labels + 1][3]) = per label {max of val16, sum of val8, sum of val8^2} (either plane may be NULL: zeros).
+ * rhccq_label_reduce: red (device u64[n_labels + 1][4]) = per label {max of val16, sum of val8, sum of val8^2, pixel count} (either plane may
+ *   be NULL: zeros).
  *   With rhccq_ccl on the mask this is Canny's hysteresis: a component is an edge iff its max exceeds `high`.
  * rhccq_box_count: out (device u16[H][W]) = number of non-zero pixels in the kernel_size x kernel_size window (odd, <= 31),
  *   BORDER_REFLECT_101: the integer content of compute_local_density's normalised box filter. */
@@ -338,10 +340,10 @@ int rhccq_canny_nms(rhccq_ctx* ctx, const uint8_t* img, int32_t H, int32_t W, in
 int rhccq_edges_above(rhccq_ctx* ctx, const uint16_t* nm, int64_t n_pixels, int32_t low, uint8_t* mask);
 int rhccq_label_reduce(rhccq_ctx* ctx, const int32_t* labels, const uint16_t* val16, const uint8_t* val8, int64_t n_pixels,
                        int32_t n_labels, uint64_t* red);
-/* Canny's hysteresis verdict and the quality score's sums on the device: stats = rhccq_ccl's (device int32[n + 1][5]), red = rhccq_label_reduce's;
+/* Canny's hysteresis verdict and the quality score's sums on the device: red = rhccq_label_reduce's (device u64[n + 1][4]);
  * out4 (device u64[4]) = {components whose max exceeds high, their pixels, their sum of val8, their sum of val8^2}; lut (device u8[n + 1], may
  * be NULL) = 255 for those components (for rhccq_ccl_select) */
-int rhccq_edge_score(rhccq_ctx* ctx, const int32_t* stats, const uint64_t* red, int32_t n_labels, int32_t high, uint64_t* out4, uint8_t* lut);
+int rhccq_edge_score(rhccq_ctx* ctx, const uint64_t* red, int32_t n_labels, int32_t high, uint64_t* out4, uint8_t* lut);
 int rhccq_box_count(rhccq_ctx* ctx, const uint8_t* mask, int32_t H, int32_t W, int32_t kernel_size, uint16_t* out);
 /* the same window, summing the pixel VALUES (maps that are not 0 / one value: the notebook's 0 / 1 / 255 planes) */
 int rhccq_box_sum(rhccq_ctx* ctx, const uint8_t* plane, int32_t H, int32_t W, int32_t kernel_size, uint32_t* out);

@@ -167,9 +167,9 @@ class EdgeAnalysis:
         for lo, hi in pairs:
             by_low.setdefault(self._norm(lo, hi)[0], set()).add((lo, hi))
         for low, group in by_low.items():
-            n, _, stats, red = self.rh.canny_label(self.nm(False), low, self.gray)
+            n, _, red = self.rh.canny_label(self.nm(False), low, self.gray)
             for lo, hi in group:
-                out[(lo, hi)] = self._score_of(self.rh.canny_verdict(n, stats, red, max(self._norm(lo, hi)[1], 0))[1])
+                out[(lo, hi)] = self._score_of(self.rh.canny_verdict(n, red, max(self._norm(lo, hi)[1], 0))[1])
         return out
 
     def canny(self, low, high, colour=False):

@@ -137,7 +137,7 @@ __global__ __launch_bounds__(1024) void ccl_flatten_kernel(int32_t* parent, int 
   const int wave = threadIdx.x >> 6;
   const int x = seg * 64 + lane;
   const int p = y * W + x;
-  if (valid && p == 0) ccl_stat_reset(stats + (long long)cap * kCclStat, -1);     // row `cap` = background (label 0 of cv2's stats)
+  if (valid && p == 0 && stats) ccl_stat_reset(stats + (long long)cap * kCclStat, -1);   // row `cap` = background (label 0 of cv2's stats)
   const bool fg = valid && x < W && parent[p] >= 0;
   const uint64_t b = __ballot(fg);
   const bool is_start = fg && (lane == 0 || !((b >> (lane - 1)) & 1ull));
@@ -165,7 +165,7 @@ __global__ __launch_bounds__(1024) void ccl_flatten_kernel(int32_t* parent, int 
     for (int w = 0; w < wave; ++w) base += s_cnt[w];
     const int id = base + __popcll(roots & ((1ull << lane) - 1ull));
     cid[p] = id;
-    if (id < cap) ccl_stat_reset(stats + (long long)id * kCclStat, key_is_root ? r : 0x7fffffff);
+    if (stats && id < cap) ccl_stat_reset(stats + (long long)id * kCclStat, key_is_root ? r : 0x7fffffff);
   }
 }
 
@@ -319,7 +319,10 @@ __global__ __launch_bounds__(256) void ccl_relabel_kernel(const int32_t* __restr
   if (p >= n) return;
   const int r = parent[p];
   int v = 0;
-  if (r >= 0 && *count <= cap) v = rank[cid[r]];              // more components than `cap`: the caller repeats the call; labels stay 0
+  if (r >= 0) {
+    if (!rank) v = cid[r] + 1;                                // unordered ids (numbering 2)
+    else if (*count <= cap) v = rank[cid[r]];                 // more components than `cap`: the caller repeats the call; labels stay 0
+  }
   labels[p] = v;
 }
 
@@ -419,9 +422,10 @@ int64_t rhccq_ccl_work_bytes(int32_t H, int32_t W, int32_t cap) {
 
 int rhccq_ccl(rhccq_ctx* ctx, const uint8_t* mask, int32_t H, int32_t W, int32_t connectivity, int32_t numbering, void* work, int64_t work_bytes,
               int32_t cap, int32_t* labels, int32_t* stats, int32_t* count) {
-  if (!ctx || !mask || !work || !labels || !stats || !count || H <= 0 || W <= 0 || cap < 0) return rhccq_fail(ctx, RHCCQ_E_ARG, "ccl: bad argument");
+  if (!ctx || !mask || !work || !labels || !count || H <= 0 || W <= 0 || cap < 0) return rhccq_fail(ctx, RHCCQ_E_ARG, "ccl: bad argument");
   if (connectivity != 4 && connectivity != 8) return rhccq_fail(ctx, RHCCQ_E_ARG, "ccl: connectivity must be 4 or 8");
-  if (numbering != 0 && numbering != 1) return rhccq_fail(ctx, RHCCQ_E_ARG, "ccl: numbering must be 0 (OpenCV) or 1 (raster)");
+  if (numbering < 0 || numbering > 2) return rhccq_fail(ctx, RHCCQ_E_ARG, "ccl: numbering must be 0 (OpenCV), 1 (raster) or 2 (unordered ids)");
+  if (numbering != 2 && !stats) return rhccq_fail(ctx, RHCCQ_E_ARG, "ccl: statistics buffer missing");
   if ((long long)H * W >= 0x7fffffffLL) return rhccq_fail(ctx, RHCCQ_E_LIMIT, "ccl: more than 2^31 pixels");
   if (work_bytes < rhccq_ccl_work_bytes(H, W, cap)) return rhccq_fail(ctx, RHCCQ_E_ARG, "ccl: work buffer too small");
   const int key_is_root = (connectivity == 4 || numbering == 1) ? 1 : 0;
@@ -446,6 +450,14 @@ int rhccq_ccl(rhccq_ctx* ctx, const uint8_t* mask, int32_t H, int32_t W, int32_t
     hipLaunchKernelGGL(ccl_merge_kernel<4>, dim3(wgrid), dim3(256), 0, ctx->stream, bits, H, W, segs, parent);
   else
     hipLaunchKernelGGL(ccl_merge_kernel<8>, dim3(wgrid), dim3(256), 0, ctx->stream, bits, H, W, segs, parent);
+  if (numbering == 2) {
+    // unordered ids: labels = compact id + 1; no statistics, no numbering (Canny's hysteresis only needs to tell components apart)
+    hipLaunchKernelGGL(ccl_flatten_kernel, dim3((unsigned)((units_total + 15) / 16)), dim3(1024), 0, ctx->stream, parent, H, W, segs, cid, 0,
+                       (int32_t*)nullptr, count, 0);
+    hipLaunchKernelGGL(ccl_relabel_kernel, dim3(pgrid), dim3(256), 0, ctx->stream, parent, cid, (const int32_t*)nullptr, count, cap, n, labels);
+    RHCCQ_LAUNCH_CHECK(ctx);
+    return 0;
+  }
   hipLaunchKernelGGL(ccl_flatten_kernel, dim3((unsigned)((units_total + 15) / 16)), dim3(1024), 0, ctx->stream, parent, H, W, segs, cid, cap, raw, count,
                      key_is_root);
   hipLaunchKernelGGL(ccl_stats_kernel, dim3((unsigned)((units_total + units - 1) / units)), dim3(1024), 0, ctx->stream, parent, cid, H, W, segs, cap, raw,

@@ -122,7 +122,7 @@ __global__ __launch_bounds__(256) void edges_above_kernel(const uint16_t* __rest
   if (p < n) mask[p] = nm[p] > low;
 }
 
-// per label: red[l] = {largest value of `val16`, sum of `val8`, sum of val8^2} over the label's pixels (int64 each); one wave
+// per label: red[l] = {largest value of `val16`, sum of `val8`, sum of val8^2, number of pixels} over the label's pixels (int64 each); one wave
 // covers 64 consecutive pixels: when all its foreground lanes share one label (the common case on edge maps: short runs) the
 // wave reduces first and issues three atomics
 __global__ __launch_bounds__(256) void label_reduce_kernel(const int32_t* __restrict__ labels, const uint16_t* __restrict__ val16,
@@ -144,20 +144,21 @@ __global__ __launch_bounds__(256) void label_reduce_kernel(const int32_t* __rest
       s2 += __shfl_down(s2, o, 64);
     }
     if (lane == 0) {
-      atomicMax(&red[3ll * lead], mx);
-      if (s1) { atomicAdd(&red[3ll * lead + 1], s1); atomicAdd(&red[3ll * lead + 2], s2); }
+      atomicMax(&red[4ll * lead], mx);
+      if (s1) { atomicAdd(&red[4ll * lead + 1], s1); atomicAdd(&red[4ll * lead + 2], s2); }
+      atomicAdd(&red[4ll * lead + 3], (unsigned long long)__popcll(fg));
     }
   } else if (l) {
-    atomicMax(&red[3ll * l], v16);
-    if (v8) { atomicAdd(&red[3ll * l + 1], v8); atomicAdd(&red[3ll * l + 2], v8 * v8); }
+    atomicMax(&red[4ll * l], v16);
+    if (v8) { atomicAdd(&red[4ll * l + 1], v8); atomicAdd(&red[4ll * l + 2], v8 * v8); }
+    atomicAdd(&red[4ll * l + 3], 1ull);
   }
 }
 
 // hysteresis verdict per component and the four numbers the quality score needs, without a trip to the host: a component is an edge
 // when its largest magnitude exceeds `high`; out = {edge components, edge pixels, sum of gray, sum of gray^2 over the edge pixels};
 // lut (optional): 255 for edge components, 0 otherwise (label 0 = background: 0)
-__global__ __launch_bounds__(256) void edge_score_kernel(const int32_t* __restrict__ stats /* [n + 1][5], column 4 = area */,
-                                                         const unsigned long long* __restrict__ red /* [n + 1][3] */, int n, int high,
+__global__ __launch_bounds__(256) void edge_score_kernel(const unsigned long long* __restrict__ red /* [n + 1][4] */, int n, int high,
                                                          unsigned long long* out, uint8_t* __restrict__ lut) {
   __shared__ unsigned long long s_acc[4];
   if (threadIdx.x < 4) s_acc[threadIdx.x] = 0;
@@ -165,9 +166,9 @@ __global__ __launch_bounds__(256) void edge_score_kernel(const int32_t* __restri
   const int l = blockIdx.x * 256 + threadIdx.x;             // label l, 0 = background
   unsigned long long v[4] = {0, 0, 0, 0};
   if (l <= n) {
-    const bool edge = l > 0 && red[3ll * l] > (unsigned long long)high;
+    const bool edge = l > 0 && red[4ll * l] > (unsigned long long)high;
     if (lut) lut[l] = edge ? 255 : 0;
-    if (edge) { v[0] = 1; v[1] = (unsigned long long)stats[5ll * l + 4]; v[2] = red[3ll * l + 1]; v[3] = red[3ll * l + 2]; }
+    if (edge) { v[0] = 1; v[1] = red[4ll * l + 3]; v[2] = red[4ll * l + 1]; v[3] = red[4ll * l + 2]; }
   }
 #pragma unroll
   for (int k = 0; k < 4; ++k) {
@@ -262,18 +263,18 @@ int rhccq_edges_above(rhccq_ctx* ctx, const uint16_t* nm, int64_t n_pixels, int3
 int rhccq_label_reduce(rhccq_ctx* ctx, const int32_t* labels, const uint16_t* val16, const uint8_t* val8, int64_t n_pixels, int32_t n_labels,
                        uint64_t* red) {
   if (!ctx || !labels || !red || n_pixels <= 0 || n_labels < 0) return rhccq_fail(ctx, RHCCQ_E_ARG, "label_reduce: bad argument");
-  RHCCQ_HIP(ctx, hipMemsetAsync(red, 0, 3 * sizeof(uint64_t) * ((size_t)n_labels + 1), ctx->stream));
+  RHCCQ_HIP(ctx, hipMemsetAsync(red, 0, 4 * sizeof(uint64_t) * ((size_t)n_labels + 1), ctx->stream));
   hipLaunchKernelGGL(label_reduce_kernel, dim3((unsigned)((n_pixels + 255) / 256)), dim3(256), 0, ctx->stream, labels, val16, val8, (long long)n_pixels,
                      (unsigned long long*)red);
   RHCCQ_LAUNCH_CHECK(ctx);
   return 0;
 }
 
-int rhccq_edge_score(rhccq_ctx* ctx, const int32_t* stats, const uint64_t* red, int32_t n_labels, int32_t high, uint64_t* out4, uint8_t* lut) {
-  if (!ctx || !stats || !red || !out4 || n_labels < 0 || high < 0) return rhccq_fail(ctx, RHCCQ_E_ARG, "edge_score: bad argument");
+int rhccq_edge_score(rhccq_ctx* ctx, const uint64_t* red, int32_t n_labels, int32_t high, uint64_t* out4, uint8_t* lut) {
+  if (!ctx || !red || !out4 || n_labels < 0 || high < 0) return rhccq_fail(ctx, RHCCQ_E_ARG, "edge_score: bad argument");
   RHCCQ_HIP(ctx, hipMemsetAsync(out4, 0, 4 * sizeof(uint64_t), ctx->stream));
-  hipLaunchKernelGGL(edge_score_kernel, dim3((unsigned)((n_labels + 1 + 255) / 256)), dim3(256), 0, ctx->stream, stats, (const unsigned long long*)red, n_labels,
-                     high, (unsigned long long*)out4, lut);
+  hipLaunchKernelGGL(edge_score_kernel, dim3((unsigned)((n_labels + 1 + 255) / 256)), dim3(256), 0, ctx->stream, (const unsigned long long*)red, n_labels, high,
+                     (unsigned long long*)out4, lut);
   RHCCQ_LAUNCH_CHECK(ctx);
   return 0;
 }

@@ -711,7 +711,7 @@ class Rhccq:
         """mask uint8 / bool [H,W] device -> (n, labels int32[H,W] device, stats np.int32[n + 1, 5]) with cv2's conventions:
         label 0 = background, components numbered as cv2.connectedComponentsWithStats numbers them (csrc/ccl.hip), stats
         columns CC_STAT_LEFT, TOP, WIDTH, HEIGHT, AREA.  numbering="raster": components numbered by their first pixel in
-        raster order (scipy.ndimage.label, skimage.measure.label)."""
+        raster order (scipy.ndimage.label, skimage.measure.label); numbering="ids": unordered ids 1..n, no statistics (None)."""
         if mask.dtype == torch.bool:
             mask = mask.view(torch.uint8)
         assert mask.dtype == torch.uint8 and mask.dim() == 2 and mask.is_contiguous()
@@ -722,12 +722,14 @@ class Rhccq:
             wb = int(self.lib.rhccq_ccl_work_bytes(H, W, cap))
             work = self.empty((wb,), torch.uint8)
             stats = self.empty((cap + 1, 5), torch.int32)
-            self._check(self.lib.rhccq_ccl(self.ctx, self._p(mask), H, W, int(connectivity), 0 if numbering == "opencv" else 1, self._p(work), wb,
-                                           cap, self._p(labels), self._p(stats), self._p(count)), "ccl")
+            self._check(self.lib.rhccq_ccl(self.ctx, self._p(mask), H, W, int(connectivity), {"opencv": 0, "raster": 1, "ids": 2}[numbering], self._p(work),
+                                           wb, cap, self._p(labels), self._p(None if numbering == "ids" else stats), self._p(count)), "ccl")
             n = int(count.cpu()[0])
-            if n <= cap:
+            if n <= cap or numbering == "ids":
                 break
             cap = n
+        if numbering == "ids":
+            return n, labels, None
         return n, labels, (stats[:n + 1].cpu().numpy() if host_stats else stats)   # host_stats=False: the device tensor [cap + 1][5]
 
     def ccl_select(self, labels, lut):
@@ -777,33 +779,34 @@ class Rhccq:
         return nm
 
     def canny_label(self, nm, low, gray=None):
-        """first half of Canny's hysteresis on the device: components of {nm > low} (rhccq_ccl) and per label the max of nm (+ sums of gray).
-        -> (n, labels int32[H,W] device, stats device int32[cap + 1][5], red device int64[n + 1][3]); only the component count crosses to the host"""
+        """first half of Canny's hysteresis on the device: components of {nm > low} (unordered ids: their numbering does not matter here) and
+        per label the max of nm, the sums of gray and gray^2, the pixel count.  -> (n, labels int32[H,W] device, red device int64[n + 1][4]);
+        only the component count crosses to the host"""
         H, W = int(nm.shape[0]), int(nm.shape[1])
         mask = self.empty((H, W), torch.uint8)
         self._check(self.lib.rhccq_edges_above(self.ctx, self._p(nm), H * W, int(low), self._p(mask)), "edges_above")
-        n, labels, stats = self.ccl(mask, 8, cap=1 << 16, host_stats=False)
-        red = self.empty((n + 1, 3), torch.int64)
+        n, labels, _ = self.ccl(mask, 8, cap=0, numbering="ids")
+        red = self.empty((n + 1, 4), torch.int64)
         self._check(self.lib.rhccq_label_reduce(self.ctx, self._p(labels), self._p(nm), self._p(gray), labels.numel(), n, self._p(red)), "label_reduce")
-        return n, labels, stats, red
+        return n, labels, red
 
-    def canny_verdict(self, n, stats, red, high, want_lut=False):
+    def canny_verdict(self, n, red, high, want_lut=False):
         """second half: a component is an edge when its max exceeds `high`.  -> (lut uint8[n + 1] device or None, (edge components, edge
         pixels, sum gray, sum gray^2) as Python ints): 32 bytes cross to the host"""
         out4 = self.empty((4,), torch.int64)
         lut = self.empty((n + 1,), torch.uint8) if want_lut else None
-        self._check(self.lib.rhccq_edge_score(self.ctx, self._p(stats), self._p(red), n, int(high), self._p(out4), self._p(lut)), "edge_score")
+        self._check(self.lib.rhccq_edge_score(self.ctx, self._p(red), n, int(high), self._p(out4), self._p(lut)), "edge_score")
         return lut, tuple(int(v) for v in out4.cpu().numpy())
 
     def canny_components(self, nm, low, high, gray=None, want_lut=False):
         """both halves -> (labels, lut or None, the four numbers)"""
-        n, labels, stats, red = self.canny_label(nm, low, gray)
-        lut, four = self.canny_verdict(n, stats, red, high, want_lut)
+        n, labels, red = self.canny_label(nm, low, gray)
+        lut, four = self.canny_verdict(n, red, high, want_lut)
         return labels, lut, four
 
     def label_reduce(self, labels, n, val16=None, val8=None):
-        """-> np.uint64[n + 1, 3]: per label {max of val16, sum of val8, sum of val8^2}"""
-        red = self.empty((n + 1, 3), torch.int64)
+        """-> np.uint64[n + 1, 4]: per label {max of val16, sum of val8, sum of val8^2, pixel count}"""
+        red = self.empty((n + 1, 4), torch.int64)
         self._check(self.lib.rhccq_label_reduce(self.ctx, self._p(labels), self._p(val16), self._p(val8), labels.numel(), n, self._p(red)), "label_reduce")
         return red.cpu().numpy().view(np.uint64)
 
