@@ -9,6 +9,9 @@ import os as _os
 # queues.  Read by the HIP runtime when it initialises (first device call), so this must run before that -- import this
 # package before touching the GPU; an explicit setting in the environment wins.
 _os.environ.setdefault("GPU_MAX_HW_QUEUES", "8")
+# Kernel arguments in device memory: the mini-batch step loop is three dependent launches per step, and fetching each kernel's
+# arguments from host memory costs 7 % on a 4K frame (measured with the variable forced to 0; unset behaves like 1 on ROCm 7.2).
+_os.environ.setdefault("HIP_FORCE_DEV_KERNARG", "1")
 
 from ._lib import RhccqError, load as load_library  # noqa: E402,F401
 
