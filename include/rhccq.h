@@ -46,9 +46,10 @@ const char* rhccq_last_error(const rhccq_ctx* ctx);
  *                              most this many 64-sample blocks (0..4096, default 4096), in global memory beyond;
  *   RHCCQ_OPT_INIT_MAX_ITEMS   capacity of the shared (candidate, block) work list (1..12288, default 12288);
  *                              picks that exceed it evaluate each candidate by its own enumeration instead;
- *   RHCCQ_OPT_INIT_KERNEL      0 (default): the second-generation k-means++ chain whenever the block tables fit LDS;
- *                              1: the first-generation chain always (same picks; kept for problems beyond LDS and as
- *                              a cross-check);
+ *   RHCCQ_OPT_INIT_KERNEL      0 (default): the newest k-means++ chain whose tables fit LDS -- third generation (leaves of
+ *                              16 samples) up to 98 304 init samples, second generation (blocks of 64) up to 262 144, first
+ *                              generation beyond; 1: the first-generation chain always; 2: the second generation whenever its
+ *                              tables fit (same picks everywhere; the older chains serve larger problems and as cross-checks);
  *   RHCCQ_OPT_INIT_SHARDS      workgroups (CUs) per problem of the second-generation chain: 1 (default) = one; 2 / 4 / 8 =
  *                              up to that many, each owning a range of the draws, when every shard keeps >= 4096 init
  *                              samples and at most 64 workgroups result (they wait for each other inside the launch, so

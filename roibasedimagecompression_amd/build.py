@@ -42,9 +42,8 @@ def build(force=False, verbose=True):
             continue
         obj = os.path.join(objdir, src.replace(".hip", ".o"))
         objs.append(obj)
-        if (not force and os.path.exists(obj) and os.path.getmtime(obj) > max(
-                os.path.getmtime(sp), os.path.getmtime(os.path.join(CSRC, "rhccq_common.h")),
-                os.path.getmtime(os.path.join(HERE, "..", "include", "rhccq.h")))):
+        headers = [os.path.join(CSRC, f) for f in os.listdir(CSRC) if f.endswith(".h")] + [os.path.join(HERE, "..", "include", "rhccq.h")]
+        if not force and os.path.exists(obj) and os.path.getmtime(obj) > max(os.path.getmtime(f) for f in [sp] + headers):
             continue
         cmd = [cc] + FLAGS + ["-c", sp, "-o", obj]
         if verbose:

@@ -1,0 +1,490 @@
+// k-means++ chain, third generation (included by k8_minibatch.hip; init samples <= 98 304: the 4K regime).
+// Same arithmetic (exact integers) and the same picks as the first two generations; what changes is the pruning index
+// and how a pick is laid out on the CU.  Why, measured on the second generation (MI355X, k = 38 392, 115 176 samples):
+//   * SQ counters per pick: 6 800 VALU + 3 700 SALU + 720 LDS + 160 VMEM wave-instructions, waves parked 59 % of their
+//     cycles (barriers, memory waits), issue stalls 16 %: a latency / synchronisation bound chain, so both the number of
+//     instructions and the number of dependent round trips per phase count;
+//   * a CPU simulation of the chain on the bench's 4K palettes (the same exact pruning rule, other block sizes): the
+//     number of blocks a pick's candidates may improve hardly depends on the block size -- 223 / 261 / 277 / 244
+//     (candidate, block) hits per pick for blocks of 64 / 16 / 8 / 4 samples at pick 5 000 -- because most hits are blocks
+//     that really hold an improving sample (118 samples improve).  Blocks of 64 therefore evaluate 14 000 samples per
+//     pick where blocks of 16 evaluate 4 200.
+// Hence:
+//   * LEAVES of 16 Morton-consecutive samples; a QUAD of four lanes holds a leaf (4 samples per lane), so one wave
+//     instruction stream evaluates 16 (candidate, leaf) items;
+//   * two box levels -- leaf (16 samples), super (16 leaves = 256 samples): the wave that found candidate t tests ALL
+//     supers (<= 384: six independent rounds of 64 lanes, one LDS round trip for all of them), keeps the hits in a list of
+//     its own and goes on to their leaves, four supers per round and four rounds per batch -- no shared hit list, no
+//     barrier between the two levels, one atomic per batch.  (Measured on the way: a third level of 4 096-sample boxes
+//     and a shared (candidate, super) list expanded behind a barrier took 9 000 cycles per pick for these two steps: every
+//     dependent LDS round trip costs ~130 cycles and every dependent VALU instruction ~10 in this chain, so the number of
+//     DEPENDENT steps is what counts, not the number of box tests);
+//   * the candidate search walks a 64-ary tree of the draw-order sums (4 096-draw sums, 64-draw sums, samples): three
+//     whole-wave scans (the second generation: chunked u64 scans over 1 024-draw sums, a row scan, a wave scan);
+//   * a pick whose work list overflows (the first ~100 picks, when almost every leaf can still improve) is evaluated by
+//     brute force over all samples, all waves side by side (no per-candidate enumeration).
+constexpr int kG3Threads = 1024;
+constexpr int kG3Waves = kG3Threads / 64;
+constexpr int kG3MaxLeaves = 6144;                      // leaf table in LDS: 96 KB = 98 304 init samples
+constexpr int kG3MaxSamples = kG3MaxLeaves * 16;
+constexpr int kG3MaxSup = kG3MaxLeaves / 16;            // 384
+constexpr int kG3MaxDsum = kG3MaxSamples / 64;          // 64-draw sums: 1 536
+constexpr int kG3MaxTop = kG3MaxDsum / 64;              // 4 096-draw sums: 24
+constexpr int kG3MaxItems = 4096;                       // (candidate, leaf) items per pick
+constexpr int kG3WList = 128;                           // hit supers one candidate keeps (beyond: brute-force pick)
+constexpr int kG3Touch = 512;
+constexpr int kG3Keep = 3;                              // evaluation instruction streams (16 items each) a wave keeps in registers
+
+struct G3Shared {
+  unsigned long long delta[kTMaxI];
+  unsigned long long R[kTMaxI];                         // integer search targets: ceil(u * pot)
+  unsigned long long pot;
+  unsigned long long red64[kG3Waves];
+  int cand[kTMaxI];
+  uint2 ck[kTMaxI];                                     // candidate colour, its squared norm
+  int n_items, overflow, n_touch2[2];
+};
+
+__device__ __forceinline__ unsigned dpp_quad_sum(unsigned v) {
+  v += (unsigned)__builtin_amdgcn_update_dpp(0, (int)v, 0xB1, 0xF, 0xF, true);    // quad_perm [1,0,3,2]
+  v += (unsigned)__builtin_amdgcn_update_dpp(0, (int)v, 0x4E, 0xF, 0xF, true);    // quad_perm [2,3,0,1]
+  return v;
+}
+__device__ __forceinline__ unsigned dpp_quad_max(unsigned v) {
+  v = max(v, (unsigned)__builtin_amdgcn_update_dpp(0, (int)v, 0xB1, 0xF, 0xF, true));
+  v = max(v, (unsigned)__builtin_amdgcn_update_dpp(0, (int)v, 0x4E, 0xF, 0xF, true));
+  return v;
+}
+
+// commit of one improved sample: both copies of the sample, the two levels of draw-order sums
+__device__ __forceinline__ void g3_store1(int imp, int newcp, unsigned nx, uint32_t x, uint32_t y, int m, uint2* samp, uint2* dsamp, uint32_t* dsum,
+                                          uint32_t* dtop) {
+  if (imp > 0) {
+    const uint32_t dpos = j_dpos(x, y);
+    samp[m].y = ((uint32_t)newcp & 0x7ffffu) | (y & 0xfff80000u);
+    dsamp[dpos].y = (uint32_t)(newcp + (int)nx);
+    atomicSub(&dsum[dpos >> 6], (unsigned)imp);
+    atomicSub(&dtop[dpos >> 12], (unsigned)imp);
+  }
+}
+
+// one quad = one leaf (lane j of the quad holds samples 4j .. 4j+3 in a, bb): lower closest[] against the new centre,
+// refresh the leaf's max, note its super as touched.  Straight-line code but for the stores.
+__device__ __forceinline__ void g3_commit_quad(bool on, int b, uint32_t ck, int na, const uint4& a, const uint4& bb, uint2* samp, uint2* dsamp,
+                                               uint4* blk, uint32_t* dsum, uint32_t* dtop, int* touch, int* n_touch) {
+  const int j = threadIdx.x & 3;
+  const int e0 = 2 * (int)__builtin_amdgcn_udot4(ck, a.x, 0u, false), e1 = 2 * (int)__builtin_amdgcn_udot4(ck, a.z, 0u, false);
+  const int e2 = 2 * (int)__builtin_amdgcn_udot4(ck, bb.x, 0u, false), e3 = 2 * (int)__builtin_amdgcn_udot4(ck, bb.z, 0u, false);
+  const int c0 = j_cprime(a.y), c1 = j_cprime(a.w), c2 = j_cprime(bb.y), c3 = j_cprime(bb.w);
+  const int i0 = c0 - na + e0, i1 = c1 - na + e1, i2 = c2 - na + e2, i3 = c3 - na + e3;       // improvements (> 0: the sample moves)
+  const unsigned n0 = norm2_key(a.x & 0xffffffu), n1 = norm2_key(a.z & 0xffffffu), n2 = norm2_key(bb.x & 0xffffffu), n3 = norm2_key(bb.z & 0xffffffu);
+  const int w0 = i0 > 0 ? na - e0 : c0, w1 = i1 > 0 ? na - e1 : c1, w2 = i2 > 0 ? na - e2 : c2, w3 = i3 > 0 ? na - e3 : c3;   // new c' = d - |x|^2
+  if (on && max(max(i0, i1), max(i2, i3)) > 0) {
+    const int m0 = (b << 4) + 4 * j;
+    g3_store1(i0, w0, n0, a.x, a.y, m0, samp, dsamp, dsum, dtop);
+    g3_store1(i1, w1, n1, a.z, a.w, m0 + 1, samp, dsamp, dsum, dtop);
+    g3_store1(i2, w2, n2, bb.x, bb.y, m0 + 2, samp, dsamp, dsum, dtop);
+    g3_store1(i3, w3, n3, bb.z, bb.w, m0 + 3, samp, dsamp, dsum, dtop);
+  }
+  unsigned mx = max(max((unsigned)(w0 + (int)n0), (unsigned)(w1 + (int)n1)), max((unsigned)(w2 + (int)n2), (unsigned)(w3 + (int)n3)));
+  mx = dpp_quad_max(on ? mx : 0u);
+  if (on && j == 0) {
+    blk[b].w = mx;
+    const int slot = atomicAdd(n_touch, 1);
+    if (slot < kG3Touch) touch[slot] = b >> 4;
+  }
+}
+
+__global__ __launch_bounds__(kG3Threads) void mbk_init3_kernel(const uint32_t* __restrict__ keys, const MbkP* __restrict__ probs,
+                                                               const int32_t* __restrict__ init_idx, const int32_t* __restrict__ perm,
+                                                               const double* __restrict__ rand, double* __restrict__ centres,
+                                                               int32_t* __restrict__ chosen, uint32_t* scratch,
+                                                               const long long* __restrict__ scratch_off, int max_items) {
+  __shared__ G3Shared sh;
+  __shared__ uint4 blk[kG3MaxLeaves];                    // per leaf: box (3 pairs), max closest
+  __shared__ uint4 sup[kG3MaxSup];                       // per super: box, max of the leaves' max (may lag high)
+  __shared__ uint32_t dsum[kG3MaxDsum];                  // per 64 consecutive draws: sum of closest
+  __shared__ uint32_t dtop[kG3MaxTop];                   // per 4 096 consecutive draws
+  __shared__ uint32_t items[kG3MaxItems];
+  __shared__ uint32_t wlist[kTMaxI * kG3WList];          // per candidate: the supers it may improve
+  __shared__ int s_touch[2 * kG3Touch];
+  const MbkP P = probs[blockIdx.x];
+  const int tid = threadIdx.x, lane = tid & 63;
+  const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);     // wave-uniform BY CONSTRUCTION: loops and branches on it stay scalar
+  const int n = (int)P.init_n, k = (int)P.k, T = P.T;
+  const int nd = (n + 63) >> 6, np = nd << 6;                     // 64-draw blocks; padded sample count
+  const int nb = np >> 4, nsb = (nb + 15) >> 4, ntop = (nd + 63) >> 6;
+  uint2* samp = reinterpret_cast<uint2*>(scratch + scratch_off[blockIdx.x]);
+  uint2* dsamp = samp + np;
+  int32_t* cho = chosen + P.koff;
+  const int rq = lane >> 4, rj = lane & 15;
+  const int quad = lane >> 2, qj = lane & 3;
+  // ---- gather the sample (both orders), first centre, tables ---------------------------------------------
+  const uint32_t kf = keys[P.off + init_idx[P.init_off + P.first]];
+  {
+    const int last_d = perm[P.init_off + n - 1];
+    for (int i = tid; i < np; i += kG3Threads) {
+      const int d = i < n ? perm[P.init_off + i] : i;     // padding: the last Morton sample again, closest = 0, unused draw slots
+      const uint32_t kk = keys[P.off + init_idx[P.init_off + (i < n ? d : last_d)]];
+      const unsigned cl = i < n ? (unsigned)dist2_keys(kk, kf) : 0u;
+      samp[i] = jpack(kk, (int)cl - (int)norm2_key(kk), (uint32_t)d);
+      dsamp[d] = make_uint2(kk, cl);
+    }
+  }
+  __syncthreads();
+  for (int b0 = wave * 4; b0 < nb; b0 += kG3Waves * 4) {   // one row of 16 lanes per leaf (nb is a multiple of 4)
+    const int b = b0 + rq;
+    const uint2 sv = samp[(b << 4) + rj];
+    const uint32_t kk = sv.x & 0xffffffu;
+    const unsigned r1 = dpp_row_max(key_r(kk)), r0 = 255u - dpp_row_max(255u - key_r(kk));
+    const unsigned g1 = dpp_row_max(key_g(kk)), g0 = 255u - dpp_row_max(255u - key_g(kk));
+    const unsigned b1 = dpp_row_max(key_b(kk)), bl0 = 255u - dpp_row_max(255u - key_b(kk));
+    const unsigned dm = dpp_row_max((unsigned)(j_cprime(sv.y) + (int)norm2_key(kk)));
+    if (rj == 0) blk[b] = make_uint4(box_pair(r0, r1), box_pair(g0, g1), box_pair(bl0, b1), dm);
+  }
+  for (int d = wave; d < nd; d += kG3Waves) {
+    const unsigned ds = wave_sum_u32(dsamp[(d << 6) + lane].y);
+    if (lane == 0) dsum[d] = ds;
+  }
+  __syncthreads();
+  for (int sb = tid; sb < nsb; sb += kG3Threads) {
+    int r0 = 255, g0 = 255, b0 = 255, r1 = 0, g1 = 0, b1 = 0;
+    unsigned m = 0;
+    for (int b = sb * 16; b < min(sb * 16 + 16, nb); ++b) {
+      const uint4 be = blk[b];
+      r0 = min(r0, pair_lo(be.x)); g0 = min(g0, pair_lo(be.y)); b0 = min(b0, pair_lo(be.z));
+      r1 = max(r1, pair_hi(be.x)); g1 = max(g1, pair_hi(be.y)); b1 = max(b1, pair_hi(be.z));
+      m = max(m, be.w);
+    }
+    sup[sb] = make_uint4(box_pair((unsigned)r0, (unsigned)r1), box_pair((unsigned)g0, (unsigned)g1), box_pair((unsigned)b0, (unsigned)b1), m);
+  }
+  unsigned long long psum = 0;
+  for (int tt = tid; tt < ntop; tt += kG3Threads) {
+    unsigned sum = 0;                                     // 4 096 x 195 075 fits 32 bits
+    for (int d = tt * 64; d < min(tt * 64 + 64, nd); ++d) sum += dsum[d];
+    dtop[tt] = sum;
+    psum += sum;
+  }
+  psum = block_sum<unsigned long long>(psum, sh.red64);
+  if (tid == 0) { cho[0] = P.first; sh.n_touch2[0] = 0; sh.n_touch2[1] = 0; sh.pot = psum; sh.n_items = 0; sh.overflow = 0; }
+  if (tid < kTMaxI) sh.delta[tid] = 0;
+  if (tid < T && k > 1) sh.R[tid] = (unsigned long long)ceil(rand[P.rand_off + tid] * (double)psum);
+  __syncthreads();
+  const unsigned long long below = (1ull << lane) - 1ull;
+#ifdef RHCCQ_STAMPS
+  unsigned long long _acc[16] = {0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0};
+  unsigned long long _last = clock64();
+  unsigned long long _wacc[8] = {0, 0, 0, 0, 0, 0, 0, 0}, _wt = 0;
+#define WSPLIT(ph) do { const unsigned long long _t2 = clock64(); _wacc[ph] += _t2 - _wt; _wt = _t2; } while (0)
+#else
+#define WSPLIT(ph) do {} while (0)
+#endif
+  for (int c = 1; c < k; ++c) {
+    WBEGIN();
+    // the next pick's uniforms are a cold line in HBM: fetch them now, use them at the end of the pick
+    double u_next = 0.0;
+    if (tid < T && c + 1 < k) u_next = rand[P.rand_off + (size_t)c * T + tid];
+    const unsigned long long pot = sh.pot;
+    if (tid < T) sh.delta[tid] = 0;                      // (read for the arg-max before the previous pick's closing barrier)
+    const int* touch_r = s_touch + (((c - 1) & 1) ? kG3Touch : 0);
+    const int n_touched = min(sh.n_touch2[(c - 1) & 1], kG3Touch);
+    // ================= phase 1: waves t < T -- candidate t, the supers and the leaves it may improve ================
+    if (wave < T) {
+      // np.searchsorted(cumsum(closest), r, 'left') in DRAW order; cum and the target R = ceil(r) are exact integers
+      const int t = wave;
+      const unsigned long long rv = sh.R[t];
+      const unsigned long long R = ((unsigned long long)(unsigned)__builtin_amdgcn_readfirstlane((int)(rv >> 32)) << 32) |
+                                   (unsigned)__builtin_amdgcn_readfirstlane((int)(unsigned)rv);
+      int cand = R == 0 ? 0 : n - 1;                      // R = 0: position 0; a target beyond the total (cannot happen): the last
+      uint32_t ck = 0;
+      bool found = false;
+      if (R != 0) {
+        const unsigned v = lane < ntop ? dtop[lane] : 0u;
+        const unsigned long long inc = wave_incscan_limbs(v);
+        const unsigned long long exc = inc - v;
+        const unsigned long long m1 = __ballot(v > 0 && exc < R && R <= inc);
+        if (m1) {
+          const int l1 = __ffsll((long long)m1) - 1;
+          const unsigned rr = (unsigned)(R - readlane64(exc, l1));             // <= the 4 096-draw sum
+          const int d2 = l1 * 64 + lane;
+          const unsigned v2 = d2 < nd ? dsum[d2] : 0u;
+          const unsigned inc2 = wave_incscan_u32(v2);
+          const unsigned long long m2 = __ballot(v2 > 0 && (inc2 - v2) < rr && rr <= inc2);
+          if (m2) {
+            const int l2 = __ffsll((long long)m2) - 1;
+            const int bh = l1 * 64 + l2;
+            const unsigned rr3 = rr - (unsigned)__builtin_amdgcn_readlane((int)(inc2 - v2), l2);   // <= the block's sum
+            const int i = (bh << 6) + lane;
+            const uint2 sv = dsamp[i];
+            const unsigned inc3 = wave_incscan_u32(i < n ? sv.y : 0u);          // 64 x 195075 fits 32 bits
+            const unsigned long long m3 = __ballot(i < n && inc3 >= rr3);
+            const int l3 = m3 ? __ffsll((long long)m3) - 1 : min(63, n - 1 - (bh << 6));
+            cand = (bh << 6) + l3;
+            ck = (uint32_t)__builtin_amdgcn_readlane((int)sv.x, l3);
+            found = true;
+          }
+        }
+      }
+      if (!found) ck = dsamp[cand].x;
+      WSPLIT(4);
+      const CandP cp = cand_pairs(ck);
+      if (lane == 0) {
+        sh.cand[t] = cand;
+        sh.ck[t] = make_uint2(ck, norm2_key(ck));
+      }
+      // every super, 64 per round; the rounds are independent of each other (one LDS round trip for all).  The maxima may be
+      // mid-refresh by the idle waves: a stale, larger maximum is conservative
+      // (loads unconditional, indices clamped, all of them issued before the first test -- sched_barrier: left alone the compiler
+      // waits for each entry before it asks for the next, six LDS round trips instead of one)
+      unsigned long long ms[kG3MaxSup / 64];
+      bool hsv[kG3MaxSup / 64];
+      {
+        uint4 se[kG3MaxSup / 64];
+        const int nr = nsb > 128 ? kG3MaxSup / 64 : 2;      // (wave-uniform; the unrolled rounds beyond it cost a scalar branch)
+#pragma unroll
+        for (int r = 0; r < kG3MaxSup / 64; ++r) {
+          se[r] = make_uint4(0, 0, 0, 0);
+          if (r < nr) se[r] = sup[min(r * 64 + lane, nsb - 1)];
+        }
+        __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+        for (int r = 0; r < kG3MaxSup / 64; ++r) {
+          const unsigned d2 = box_dist2(cp, se[r].x, se[r].y, se[r].z);
+          hsv[r] = (bool)((int)(d2 < se[r].w) & (int)(r * 64 + lane < nsb));      // (no short circuit)
+          ms[r] = __ballot(hsv[r]);
+        }
+      }
+      WSPLIT(5);
+      uint32_t* wl = wlist + t * kG3WList;
+      int n_sup = 0;
+#pragma unroll
+      for (int r = 0; r < kG3MaxSup / 64; ++r) {
+        const int pos = n_sup + __popcll(ms[r] & below);
+        if (hsv[r] && pos < kG3WList) wl[pos] = (uint32_t)(r * 64 + lane);
+        n_sup += __popcll(ms[r]);
+      }
+      WSPLIT(6);
+#ifdef RHCCQ_STAMPS
+      if (t == 0) { _acc[13] += (unsigned long long)n_sup; _acc[14] += (unsigned long long)((n_sup + 15) >> 4); }
+#endif
+      if (n_sup > kG3WList) { if (lane == 0) sh.overflow = 1; }
+      else {
+        // the leaves of the hit supers: four supers per round (one row of lanes each), four independent rounds per batch
+        for (int h0 = 0; h0 < n_sup; h0 += 16) {
+          int bq[4];
+          bool hb[4];
+          unsigned long long mb[4];
+          uint32_t sq[4];
+          uint4 be[4];
+#pragma unroll
+          for (int q = 0; q < 4; ++q) sq[q] = wl[min(h0 + 4 * q + rq, kG3WList - 1)];
+          __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+          for (int q = 0; q < 4; ++q) {
+            const int b = (int)sq[q] * 16 + rj;
+            bq[q] = ((int)(h0 + 4 * q + rq < n_sup) & (int)(b < nb)) ? b : -1;
+            be[q] = blk[max(bq[q], 0)];
+          }
+          __builtin_amdgcn_sched_barrier(0);
+          int total = 0;
+#pragma unroll
+          for (int q = 0; q < 4; ++q) {
+            const unsigned d2 = box_dist2(cp, be[q].x, be[q].y, be[q].z);
+            hb[q] = (bool)((int)(d2 < be[q].w) & (int)(bq[q] >= 0));
+            mb[q] = __ballot(hb[q]);
+            total += __popcll(mb[q]);
+          }
+          if (total) {
+            int base = 0;
+            if (lane == 0) base = atomicAdd(&sh.n_items, total);
+            base = __builtin_amdgcn_readfirstlane(base);
+            if (base + total > max_items) { if (lane == 0) sh.overflow = 1; }
+            else {
+#pragma unroll
+              for (int q = 0; q < 4; ++q) {
+                if (hb[q]) items[base + __popcll(mb[q] & below)] = ((uint32_t)t << 24) | (uint32_t)bq[q];
+                base += __popcll(mb[q]);
+              }
+            }
+          }
+        }
+      }
+    } else {
+      // the other waves refresh the super maxima the previous winner touched
+      for (int i = tid - T * 64; i < n_touched * 16; i += kG3Threads - T * 64) {
+        const int sb = touch_r[i >> 4], b = sb * 16 + (i & 15);
+        unsigned m = b < nb ? blk[b].w : 0u;
+        m = dpp_row_max(m);
+        if ((i & 15) == 0) sup[sb].w = m;
+      }
+    }
+    WEND(0);
+    STAMP(0);
+    __syncthreads();
+    STAMP(1);
+    WBEGIN();
+    // ================= phase 3: potentials ===================================================================
+    const bool use_list = sh.overflow == 0;
+    const int n_items = use_list ? sh.n_items : 0;
+    const int n_ops = (n_items + 15) >> 4;                 // one evaluation instruction stream = 16 items, one per quad
+    const bool kept = n_ops <= kG3Waves * kG3Keep;         // every item's samples stay in the registers of its wave
+    int* touch_w = s_touch + ((c & 1) ? kG3Touch : 0);
+    int* n_touch_w = &sh.n_touch2[c & 1];
+    uint4 ka[kG3Keep], kb[kG3Keep];
+    uint32_t kw[kG3Keep];
+    if (use_list) {
+      // (wave-uniform guards; a quad beyond the list re-reads the last item and contributes nothing)
+#pragma unroll
+      for (int s = 0; s < kG3Keep; ++s) {
+        kw[s] = 0xffffffffu;
+        ka[s] = make_uint4(0, 0, 0, 0);
+        kb[s] = ka[s];
+        if (16 * (wave + s * kG3Waves) < n_items) {
+          const int ii = 16 * (wave + s * kG3Waves) + quad;
+          const uint32_t w = items[min(ii, n_items - 1)];
+          const uint4* p4 = reinterpret_cast<const uint4*>(samp + ((w & 0xffffffu) << 4) + 4 * qj);
+          ka[s] = p4[0];
+          kb[s] = p4[1];
+          kw[s] = ii < n_items ? w : (w | 0xf0000000u);    // candidate numbers are < 16: the high nibble marks a padding quad
+        }
+      }
+#pragma unroll
+      for (int s = 0; s < kG3Keep; ++s) {
+        if (16 * (wave + s * kG3Waves) < n_items) {
+          const int t = (int)(kw[s] >> 24) & (kTMaxI - 1);
+          const uint2 cc = sh.ck[t];
+          unsigned imp = j_eval4(cc.x, (int)cc.y, ka[s], kb[s]);
+          imp = dpp_quad_sum((kw[s] >> 28) ? 0u : imp);
+          if (qj == 0 && imp) atomicAdd(&sh.delta[t], (unsigned long long)imp);
+        }
+      }
+      for (int o = wave + kG3Keep * kG3Waves; o < n_ops; o += kG3Waves) {   // more items than the registers hold
+        const int ii = 16 * o + quad;
+        const uint32_t w = ii < n_items ? items[ii] : 0xffffffffu;
+        const bool on = w != 0xffffffffu;
+        unsigned imp = 0;
+        if (on) {
+          const uint4* p4 = reinterpret_cast<const uint4*>(samp + ((w & 0xffffffu) << 4) + 4 * qj);
+          const uint2 cc = sh.ck[w >> 24];
+          imp = j_eval4(cc.x, (int)cc.y, p4[0], p4[1]);
+        }
+        imp = dpp_quad_sum(imp);
+        if (on && qj == 0 && imp) atomicAdd(&sh.delta[w >> 24], (unsigned long long)imp);
+      }
+    } else {
+      // the work list overflowed (the first picks: almost every leaf can still improve): brute force, every wave its
+      // slice of the samples against four candidates at a time
+      for (int t0 = 0; t0 < T; t0 += 4) {
+        const uint2 c0 = sh.ck[t0], c1 = sh.ck[min(t0 + 1, T - 1)], c2 = sh.ck[min(t0 + 2, T - 1)], c3 = sh.ck[min(t0 + 3, T - 1)];
+        unsigned long long a0 = 0, a1 = 0, a2 = 0, a3 = 0;
+        for (int m0 = wave * 64; m0 < np; m0 += kG3Threads) {
+          const uint2 sv = samp[m0 + lane];
+          const int cpv = j_cprime(sv.y);
+          a0 += (unsigned)max(cpv - (int)c0.y + 2 * (int)__builtin_amdgcn_udot4(c0.x, sv.x, 0u, false), 0);
+          a1 += (unsigned)max(cpv - (int)c1.y + 2 * (int)__builtin_amdgcn_udot4(c1.x, sv.x, 0u, false), 0);
+          a2 += (unsigned)max(cpv - (int)c2.y + 2 * (int)__builtin_amdgcn_udot4(c2.x, sv.x, 0u, false), 0);
+          a3 += (unsigned)max(cpv - (int)c3.y + 2 * (int)__builtin_amdgcn_udot4(c3.x, sv.x, 0u, false), 0);
+        }
+        a0 = wave_sum(a0); a1 = wave_sum(a1); a2 = wave_sum(a2); a3 = wave_sum(a3);
+        if (lane == 0) {
+          if (a0) atomicAdd(&sh.delta[t0], a0);
+          if (a1 && t0 + 1 < T) atomicAdd(&sh.delta[t0 + 1], a1);
+          if (a2 && t0 + 2 < T) atomicAdd(&sh.delta[t0 + 2], a2);
+          if (a3 && t0 + 3 < T) atomicAdd(&sh.delta[t0 + 3], a3);
+        }
+      }
+    }
+    WEND(2);
+    STAMP(4);
+#ifdef RHCCQ_STAMPS
+    _acc[10] += (unsigned long long)n_items;
+    _acc[11] += use_list ? (kept ? 0 : 1) : 0;
+    _acc[12] += use_list ? 0 : 1;
+#endif
+    __syncthreads();
+    STAMP(5);
+    WBEGIN();
+    // ================= phase 4: greedy choice + commit =======================================================
+    // largest reduction == smallest potential; the first candidate wins ties
+    const unsigned long long dv = lane < T ? sh.delta[lane] : 0ull;
+    const unsigned dhi = (unsigned)(dv >> 32), dlo = (unsigned)dv;
+    const unsigned mhi = wave_max_u32(dhi);
+    const unsigned mlo = wave_max_u32(dhi == mhi ? dlo : 0u);
+    const unsigned long long bd = ((unsigned long long)mhi << 32) | mlo;
+    const int best = __ffsll((long long)__ballot(lane < T && dv == bd)) - 1;
+    const uint32_t kbest = (uint32_t)__builtin_amdgcn_readlane((int)(lane < T ? sh.ck[lane].x : 0u), best);
+    const int nabest = (int)norm2_key(kbest);
+    if (use_list && kept) {
+#pragma unroll
+      for (int s = 0; s < kG3Keep; ++s) {
+        if (16 * (wave + s * kG3Waves) < n_items) {
+          const bool mine = (int)(kw[s] >> 24) == best;     // (a padding quad's high nibble never matches)
+          if (__ballot(mine))
+            g3_commit_quad(mine, (int)(kw[s] & 0xffffffu), kbest, nabest, ka[s], kb[s], samp, dsamp, blk, dsum, dtop, touch_w, n_touch_w);
+        }
+      }
+    } else if (use_list) {
+      for (int o = wave; o < n_ops; o += kG3Waves) {
+        const int ii = 16 * o + quad;
+        const uint32_t w = ii < n_items ? items[ii] : 0xffffffffu;
+        const bool mine = w != 0xffffffffu && (int)(w >> 24) == best;
+        if (!__ballot(mine)) continue;
+        uint4 a = make_uint4(0, 0, 0, 0), bb = a;
+        if (mine) {
+          const uint4* p4 = reinterpret_cast<const uint4*>(samp + ((w & 0xffffffu) << 4) + 4 * qj);
+          a = p4[0];
+          bb = p4[1];
+        }
+        g3_commit_quad(mine, (int)(w & 0xffffffu), kbest, nabest, a, bb, samp, dsamp, blk, dsum, dtop, touch_w, n_touch_w);
+      }
+    } else {
+      // brute-force commit: one sample per lane, one row of lanes per leaf; every leaf maximum is rewritten, the levels
+      // above are rebuilt behind the closing barrier (the touch counter is pushed over its capacity below)
+      for (int m0 = wave * 64; m0 < np; m0 += kG3Threads) {
+        const int m = m0 + lane;
+        const uint2 sv = samp[m];
+        const int e = 2 * (int)__builtin_amdgcn_udot4(kbest, sv.x, 0u, false);
+        const int c0 = j_cprime(sv.y);
+        const int i0 = c0 - nabest + e;
+        const int w0 = i0 > 0 ? nabest - e : c0;
+        const unsigned n0 = norm2_key(sv.x & 0xffffffu);
+        g3_store1(i0, w0, n0, sv.x, sv.y, m, samp, dsamp, dsum, dtop);
+        const unsigned mx = dpp_row_max((unsigned)(w0 + (int)n0));
+        if (rj == 0) blk[m >> 4].w = mx;
+      }
+    }
+    if (tid == 0) {
+      cho[c] = sh.cand[best];
+      sh.pot = pot - bd;
+      sh.n_items = 0; sh.overflow = 0;
+      sh.n_touch2[(c + 1) & 1] = 0;
+    }
+    if (tid < T) sh.R[tid] = (unsigned long long)ceil(u_next * (double)(pot - bd));
+    WEND(3);
+    STAMP(6);
+    __syncthreads();
+    STAMP(7);
+    // more touched leaves than the list holds, or a brute-force pick: rebuild every super maximum
+    if (!use_list || sh.n_touch2[c & 1] > kG3Touch) {
+      for (int sb = tid; sb < nsb; sb += kG3Threads) {
+        unsigned m = 0;
+        for (int b = sb * 16; b < min(sb * 16 + 16, nb); ++b) m = max(m, blk[b].w);
+        sup[sb].w = m;
+      }
+      if (tid == 0) sh.n_touch2[c & 1] = 0;
+      __syncthreads();
+    }
+  }
+#ifdef RHCCQ_STAMPS
+  if (tid == 0 && blockIdx.x == gridDim.x - 1)
+    for (int i = 0; i < 16; ++i) g_init_stamps[i] += _acc[i];
+  if (lane == 0 && blockIdx.x == gridDim.x - 1)
+    for (int i = 0; i < 8; ++i) atomicAdd(&g_wave_stamps[i][wave], _wacc[i]);
+#endif
+  for (int j = tid; j < k; j += kG3Threads) {
+    const uint32_t kk = dsamp[cho[j]].x;
+    const double c0 = (double)key_r(kk), c1 = (double)key_g(kk), c2 = (double)key_b(kk);
+    double* C = centres + (P.koff + j) * 4;
+    C[0] = c0; C[1] = c1; C[2] = c2; C[3] = km64_csq(c0, c1, c2);
+  }
+}

@@ -117,7 +117,7 @@ struct InitTables {
 
 #ifdef RHCCQ_STAMPS   // diagnostic build only (tools/stamps.py): per-phase cycle shares of the init chain
 __device__ unsigned long long g_init_stamps[16];
-__device__ unsigned long long g_wave_stamps[4][16];       // [phase][wave]: cycles each wave spent in the phase
+__device__ unsigned long long g_wave_stamps[8][16];       // [phase][wave]: cycles each wave spent in the phase
 #define STAMP(slot)                                  \
   do {                                               \
     const unsigned long long _t = clock64();        \
@@ -1345,6 +1345,8 @@ __global__ __launch_bounds__(kJThreads) void mbk_init2_kernel(const uint32_t* __
   }
 }
 
+#include "k8_init3.h"
+
 // ------------------------------------------------------------------------------------------------
 // mini-batch steps
 // ------------------------------------------------------------------------------------------------
@@ -2421,7 +2423,7 @@ int rhccq_debug_upd_stamps(unsigned long long* out16_host) {
 }
 int rhccq_debug_wave_stamps(unsigned long long* out64_host) {
   if (hipDeviceSynchronize() != hipSuccess) return -2;
-  if (hipMemcpyFromSymbol(out64_host, HIP_SYMBOL(g_wave_stamps), sizeof(unsigned long long) * 64) != hipSuccess) return -2;
+  if (hipMemcpyFromSymbol(out64_host, HIP_SYMBOL(g_wave_stamps), sizeof(unsigned long long) * 128) != hipSuccess) return -2;
   return 0;
 }
 int rhccq_debug_stamps(unsigned long long* out16_host) {
@@ -2522,6 +2524,10 @@ int rhccq_mbk_init(rhccq_ctx* ctx, const uint32_t* keys, const rhccq_mbk_problem
   // the tables of larger problems (more than 262 144 init samples) in global memory
   bool lean = ctx->opt_init_kernel != 1;
   for (int i = 0; i < n_prob && lean; ++i) lean = (probs[i].init_n + 63) / 64 <= lds_blocks;
+  // third generation (leaves of 16 samples, k8_init3.h) whenever every problem's leaf table fits LDS: init samples <= 98 304,
+  // the regime of 4K frames; RHCCQ_OPT_INIT_KERNEL = 2 keeps the second generation (A/B runs, parity tests)
+  bool gen3 = lean && ctx->opt_init_kernel == 0 && ctx->opt_init_shards <= 1 && lds_blocks >= kInitLdsBlocks;
+  for (int i = 0; i < n_prob && gen3; ++i) gen3 = probs[i].init_n <= kG3MaxSamples;
   // sharded chain: C workgroups per problem, all resident at once (they wait for each other), so only for a handful of
   // problems; every shard must own at least one draw super-block and the pick number must fit the 24-bit granule tag
   // MEASURED (MI355X, k = 30 000, 90 000 init samples): 4.84 us per pick on one workgroup, 7.7-8.0 us on 2, 4 or 8 -- each of
@@ -2564,7 +2570,10 @@ int rhccq_mbk_init(rhccq_ctx* ctx, const uint32_t* keys, const rhccq_mbk_problem
   if (int e = put(ctx, dof, ho, 8 * (size_t)n_wg)) return e;
   if (nshard > 1) RHCCQ_HIP(ctx, hipMemsetAsync(xch, 0, xbytes, ctx->stream));
   RHCCQ_HIP(ctx, hipStreamSynchronize(ctx->stream));
-  if (nshard > 1)
+  if (gen3)
+    hipLaunchKernelGGL(mbk_init3_kernel, dim3(n_prob), dim3(kG3Threads), 0, ctx->stream, keys, dp, init_idx, perm, rand, centres, chosen, dscr, dof,
+                       max_items < kG3MaxItems ? max_items : kG3MaxItems);
+  else if (nshard > 1)
     hipLaunchKernelGGL(mbk_init2_kernel<true>, dim3(n_wg), dim3(kJThreads), 0, ctx->stream, keys, dp, init_idx, perm, rand, centres, chosen, dscr,
                        dof, max_items < kJMaxItems ? max_items : kJMaxItems, nshard, xch);
   else if (lean)

@@ -18,7 +18,7 @@ struct rhccq_ctx {
   // tuning knobs (rhccq_ctx_set_int); -1 = built-in value
   int opt_init_lds_blocks = -1;
   int opt_init_max_items = -1;
-  int opt_init_kernel = 0;   // 0 = second-generation k-means++ chain when the tables fit LDS, 1 = first generation always
+  int opt_init_kernel = 0;   // 0 = newest k-means++ chain whose tables fit LDS (third, second, first generation), 1 = first always, 2 = second (else first)
   int opt_init_shards = 1;   // workgroups per problem of the second-generation chain: 1 = one (default), 2 / 4 / 8 = at most that many
 };
 

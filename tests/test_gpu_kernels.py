@@ -215,21 +215,27 @@ def test_dct_quant_extension(rh, O, block):
     assert np.array_equal(q.cpu().numpy(), oq)
 
 
-@pytest.mark.parametrize("path", ["default", "tiny_work_list", "first_generation", "first_generation_tiny_work_list", "global_tables"])
+@pytest.mark.parametrize("path", ["default", "tiny_work_list", "small_work_list", "second_generation", "second_generation_tiny_work_list",
+                                  "first_generation", "first_generation_tiny_work_list", "global_tables"])
 def test_minibatch_init_chain_many_cases(rh, O, path):
-    """The k-means++ chains (mbk_init2_kernel: candidate search vectorised across candidates, one-phase enumeration,
-    quarter-wave evaluation with the samples kept in registers for the commit; mbk_init_kernel: the first generation,
-    still used beyond 262 144 init samples) against the oracle's exact-integer k-means++ on the same init sample in
-    sklearn's draw order, for several shapes -- every pick must be identical (this is the kernel where a reduction race
-    once hid behind lucky timing).  `tiny_work_list` / `global_tables` lower the thresholds (rhccq_ctx_set_int) so that
-    the paths of very large problems -- per-candidate evaluation when the shared work list overflows, block tables in
-    global memory -- run on inputs the oracle can check."""
+    """The k-means++ chains (mbk_init3_kernel: leaves of 16 samples under three box levels, 64-ary candidate search, quad
+    evaluation with the samples kept in registers for the commit, brute force when the work list overflows -- the default up
+    to 98 304 init samples; mbk_init2_kernel: the second generation, blocks of 64, up to 262 144; mbk_init_kernel: the first
+    generation beyond) against the oracle's exact-integer k-means++ on the same init sample in sklearn's draw order, for
+    several shapes -- every pick must be identical (this is the kernel where a reduction race once hid behind lucky timing).
+    `tiny_work_list` / `small_work_list` / `global_tables` lower the thresholds (rhccq_ctx_set_int) so that the paths of the
+    first picks and of very large problems -- brute force / per-candidate evaluation when the shared work list overflows, the
+    re-read commit when it exceeds the registers, block tables in global memory -- run on inputs the oracle can check."""
     if path == "global_tables":
         rh.set_option(rh.OPT_INIT_LDS_BLOCKS, 8)
     if path.endswith("tiny_work_list"):
         rh.set_option(rh.OPT_INIT_MAX_ITEMS, 24)
+    if path == "small_work_list":
+        rh.set_option(rh.OPT_INIT_MAX_ITEMS, 200)
     if path.startswith("first_generation"):
         rh.set_option(rh.OPT_INIT_KERNEL, 1)
+    if path.startswith("second_generation"):
+        rh.set_option(rh.OPT_INIT_KERNEL, 2)
     try:
         _init_chain_cases(rh, O)
     finally:

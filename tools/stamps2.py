@@ -13,6 +13,8 @@ img = synth.photo(2160, 3840, 1234)
 keys = (img[..., 0].astype(np.uint32) << 16) | (img[..., 1].astype(np.uint32) << 8) | img[..., 2]
 pal = np.unique(keys[:, 1920:])
 pal = pal[pal != 0]
+if len(sys.argv) > 1 and sys.argv[1] == "bench":     # the longest chain of the bench frame: k = 30 128, 90 384 init samples
+    pal = pal[:1506367]
 k = math.ceil(len(pal) * 0.2 / 10)
 print("N", len(pal), "k", k)
 t = {}
@@ -27,12 +29,12 @@ tot = v[:8].sum()
 for n, x in zip(names, v[:8]):
     print(f"{n:18s} {x:10.0f} cycles/pick  {100*x/tot:5.1f}%")
 print("total cycles/pick (thread 0)", tot)
-print("items/pick", v[10], "picks not kept", v[11], "picks overflow", v[12])
-out = (ctypes.c_ulonglong * 64)()
+print("items/pick", v[10], "picks not kept", v[11], "picks overflow", v[12], "gen 3, candidate 0: hit supers/pick", v[13], "leaf batches/pick", v[14])
+out = (ctypes.c_ulonglong * 128)()
 rh._raw.rhccq_debug_wave_stamps.argtypes = [ctypes.c_void_p]
 print("rc", rh._raw.rhccq_debug_wave_stamps(out))
-w = np.array(list(out), dtype=np.float64).reshape(4, 16) / (k - 1)
-for ph, name in enumerate(["search+E1", "E2", "evaluate", "commit"]):
+w = np.array(list(out), dtype=np.float64).reshape(8, 16) / (k - 1)
+for ph, name in enumerate(["search+E1", "E2", "evaluate", "commit", "g3:search", "g3:supers", "g3:list", "-"]):
     print(f"{name:10s} per wave:", " ".join(f"{x:5.0f}" for x in w[ph]))
 out2 = (ctypes.c_ulonglong * 16)()
 rh._raw.rhccq_debug_upd_stamps.argtypes = [ctypes.c_void_p]
