@@ -364,6 +364,13 @@ int rhccq_box_sum(rhccq_ctx* ctx, const uint8_t* plane, int32_t H, int32_t W, in
  *   non-negative int32 (value_bytes 4) plane. */
 int rhccq_morph_dilate(rhccq_ctx* ctx, const uint8_t* in, int32_t H, int32_t W, int32_t radius, const int32_t* half_widths /* host */,
                        int32_t invert_in, int32_t invert_out, uint8_t* out);
+/* the general form: rows dy = -up .. down, row i spans dx = -left[i] .. right[i] (both -1: empty row).  An even k x k OpenCV element
+ * (protect_border_regions' default is 18, roi.py:824) has its anchor at k / 2: up = left = k / 2, down = right = k - 1 - k / 2. */
+int rhccq_morph_dilate_spans(rhccq_ctx* ctx, const uint8_t* in, int32_t H, int32_t W, int32_t up, int32_t down, const int32_t* left /* host */,
+                             const int32_t* right /* host */, int32_t invert_in, int32_t invert_out, uint8_t* out);
+/* compute_local_density (edges.py:173-195) on ANY u8 plane for odd kernels up to 11 x 11 = OpenCV's direct filter2D path: float32 accumulator
+ * over the taps in row-major order, BORDER_REFLECT_101; scale255 != 0: plane / 255.0 first.  (Binary planes go through rhccq_box_count and a table.) */
+int rhccq_box_filter_seq(rhccq_ctx* ctx, const uint8_t* plane, int32_t H, int32_t W, int32_t kernel_size, int32_t scale255, float* out);
 int rhccq_mask_op(rhccq_ctx* ctx, const uint8_t* a, const uint8_t* b, int64_t n, int32_t op, uint8_t* out);
 int rhccq_gap_bridge(rhccq_ctx* ctx, const uint8_t* in, const void* counts /* u16 (count_bytes 2) or u32 (4) */, int32_t count_bytes, int32_t H,
                      int32_t W, int64_t min_count, int32_t reach, uint8_t* out);

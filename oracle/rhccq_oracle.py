@@ -1595,9 +1595,14 @@ def local_density(binary_map, kernel_size=15):
 def region_mean_density(labels, num, binary_map, kernel_size):
     """per label the mean box density over its pixels, DFT-path kernel sizes: (exact sum of the window counts) * float32(1 / k^2) / area
     (the reference averages the float32 map in float64: the same number up to the last bits)"""
-    assert kernel_size * kernel_size >= 130
-    term = float((np.ones((kernel_size, kernel_size), np.float32) / np.float32(kernel_size * kernel_size))[0, 0])
     counts = np.bincount(labels.ravel(), minlength=num)
+    if kernel_size * kernel_size < 130:                             # direct-path sizes: the float32 densities themselves, summed exactly
+        dens = local_density(binary_map, kernel_size).astype(np.float64)
+        sums = np.bincount(labels.ravel(), weights=dens.ravel(), minlength=num)      # (multiples of 2^-30 below 2^23 pixels: exact in float64)
+        out = np.zeros(num)
+        out[counts > 0] = sums[counts > 0] / counts[counts > 0]
+        return out
+    term = float((np.ones((kernel_size, kernel_size), np.float32) / np.float32(kernel_size * kernel_size))[0, 0])
     sums = np.bincount(labels.ravel(), weights=box_counts(binary_map, kernel_size).ravel(), minlength=num)
     out = np.zeros(num)
     out[counts > 0] = sums[counts > 0] * term / counts[counts > 0]
@@ -1654,6 +1659,27 @@ def cv_erode(mask, half_widths):
 
 def cv_close(mask, half_widths):
     return cv_erode(cv_dilate(mask, half_widths), half_widths)
+
+
+def cv_dilate_rect(mask, ksize, erode=False):
+    """cv2.dilate / cv2.erode by a ksize x ksize rectangle with OpenCV's default anchor (ksize // 2, ksize // 2):
+    dst(y, x) = max / min over dy, dx in [-(ksize // 2), ksize - 1 - ksize // 2] of src(y + dy, x + dx); pixels outside the image do not
+    take part (border value -inf for dilate, +inf for erode).  Even sizes included: the window reaches one pixel further up / left."""
+    m = np.asarray(mask) != 0
+    if erode:
+        m = ~m
+    a, b = ksize // 2, ksize - 1 - ksize // 2
+    H, W = m.shape
+    pad = np.zeros((H + a + b + 1, W + a + b + 1), np.int64)
+    pad[a + 1:a + 1 + H, a + 1:a + 1 + W] = m
+    ii = pad.cumsum(0).cumsum(1)                                   # ii[i, j] = sum of pad[:i + 1, :j + 1]; window rows y .. y + a + b of pad[1:]
+    cnt = ii[a + b + 1:, a + b + 1:] - ii[:H, a + b + 1:] - ii[a + b + 1:, :W] + ii[:H, :W]
+    out = cnt > 0
+    return ~out if erode else out
+
+
+def cv_close_rect(mask, ksize):
+    return cv_dilate_rect(cv_dilate_rect(mask, ksize), ksize, erode=True)
 
 
 def cv_dist_chamfer3(mask):
@@ -1792,9 +1818,9 @@ def detect_meaningful_borders(binary_image, sensitivity=0.7):
 
 
 def protect_border_regions(binary_image, border_mask, kernel_size=18):
-    """roi.py:824-857 (odd kernel sizes; the pipeline passes 15)"""
+    """roi.py:824-857 (the function's own default kernel is 18 x 18, the pipeline passes 15)"""
     b = np.asarray(binary_image)
-    closed = cv_close(b > 0, [kernel_size // 2] * kernel_size)
+    closed = cv_close_rect(b > 0, kernel_size)
     out = b.copy()
     out[(b == 0) & closed & ~np.asarray(border_mask, bool)] = 255
     return out

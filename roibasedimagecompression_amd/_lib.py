@@ -77,6 +77,9 @@ PROTOTYPES = {
     "rhccq_morph_dilate": (c_int32, [c_void_p, c_void_p, c_int32, c_int32, c_int32, C.POINTER(c_int32), c_int32, c_int32, c_void_p]),
     "rhccq_mask_op": (c_int32, [c_void_p, c_void_p, c_void_p, c_int64, c_int32, c_void_p]),
     "rhccq_gap_bridge": (c_int32, [c_void_p, c_void_p, c_void_p, c_int32, c_int32, c_int32, c_int64, c_int32, c_void_p]),
+    "rhccq_morph_dilate_spans": (c_int32, [c_void_p, c_void_p, c_int32, c_int32, c_int32, c_int32, C.POINTER(c_int32), C.POINTER(c_int32), c_int32, c_int32,
+                                           c_void_p]),
+    "rhccq_box_filter_seq": (c_int32, [c_void_p, c_void_p, c_int32, c_int32, c_int32, c_int32, c_void_p]),
     "rhccq_box_sum": (c_int32, [c_void_p, c_void_p, c_int32, c_int32, c_int32, c_void_p]),
     "rhccq_dist_chamfer": (c_int32, [c_void_p, c_void_p, c_int32, c_int32, c_void_p, c_void_p]),
     "rhccq_binary_sobel": (c_int32, [c_void_p, c_void_p, c_int32, c_int32, c_void_p, c_void_p]),

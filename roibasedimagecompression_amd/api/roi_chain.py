@@ -72,7 +72,12 @@ class _Dev:
         """per label: mean of the box density over its pixels; for the DFT-path kernel sizes (k^2 >= 130: density = count / k^2 in
         float32) it is taken from the exact integer sum of the window counts: (sum of counts) * float32(1 / k^2) / area"""
         if kernel_size * kernel_size < 130:
-            raise NotImplementedError("per-region mean density: window sizes of 13 and more (the pipeline uses 15 and 25)")
+            # direct-path kernel sizes (k <= 11): a pixel's density is the sequential float32 sum table[count]; every table value is a
+            # multiple of 2^-30 (1 / 121 >= 2^-7, 24-bit mantissa), so the per-label sum of table[count] * 2^30 is an exact integer
+            table = (_density_table(kernel_size).astype(np.float64) * float(1 << 30)).astype(np.uint32)
+            sums = self.rh.label_sum(labels, n, self.rh.lut_u16(counts, table)).astype(np.float64) / float(1 << 30)
+            with np.errstate(all="ignore"):
+                return np.where(areas > 0, sums / np.maximum(areas, 1), 0.0)
         sums = self.rh.label_sum(labels, n, counts).astype(np.float64)
         term = float(_density_table(kernel_size)[1])
         with np.errstate(all="ignore"):
@@ -94,7 +99,17 @@ class _Dev:
         n, labels, stats = self.components(mask, connectivity)
         if n == 0:
             return mask
-        thin = self.thin_ids(mask, n, labels, stats)
+        if connectivity == 8:
+            thin = self.thin_ids(mask, n, labels, stats)
+        else:
+            # identify_thin_regions_ultrafast labels 8-connected whatever the caller's connectivity; a component of the caller's
+            # labelling is thin when it holds a pixel of a thin 8-connected region (thin_regions2.py:38-46)
+            n8, labels8, stats8 = self.components(mask, 8)
+            lut8 = np.zeros(n8 + 1, np.uint8)
+            lut8[self.thin_ids(mask, n8, labels8, stats8)] = 255
+            thin_px = self.rh.ccl_select(labels8, lut8)
+            hits = self.rh.label_sum(labels, n, self.rh.box_count(thin_px, 1))
+            thin = np.flatnonzero(hits[1:] > 0) + 1
         counts = self.rh.box_count(mask, window_size)
         areas = stats[:, 4].astype(np.float64)
         areas[0] = mask.numel() - areas[1:].sum()
@@ -138,7 +153,7 @@ class _Dev:
         return self.rh.morph(self.rh.morph_close(strong, RECT3), [2] * 5)
 
     def protect(self, mask, border, kernel_size):
-        closed = self.rh.morph_close(mask, [kernel_size // 2] * kernel_size)
+        closed = self.rh.morph_close_rect(mask, kernel_size)         # (even sizes too: the reference's own default is 18)
         internal = self.rh.mask_op(self.rh.mask_op(closed, mask, "andnot"), border, "andnot")
         return self.rh.mask_op(mask, internal, "or")
 
@@ -238,9 +253,15 @@ def bridge_small_gaps_fast(binary_image, max_gap=3, density_threshold=0.3, local
     if len(nz) <= 1:
         bridged = _u8(d.bridge(d.up(binary_image), max_gap, density_threshold, local_window, regional_window))
     else:
-        if regional_window * regional_window < 130:
-            raise NotImplementedError("bridge_small_gaps_fast on a multi-valued plane: regional windows of 13 and more")
         plane = torch.from_numpy(np.ascontiguousarray(binary_image, dtype=np.uint8)).to(d.rh.device)
+        if regional_window * regional_window < 130:
+            # direct-path window on a multi-valued plane: the float32 density itself (sequential accumulation), thresholded on the device
+            dens = d.rh.box_filter_seq(plane, regional_window, binary_image.max() > 1)
+            cand = (dens > np.float32(density_threshold)).to(torch.int16)
+            bridged = _u8(d.rh.gap_bridge(plane, cand, 1, min(max_gap, local_window)))
+            out = binary_image.copy()
+            out[(binary_image == 0) & (bridged != 0)] = 255
+            return out
         sums = d.rh.box_sum(plane, regional_window)
         term = _density_table(regional_window)[1]
         scale = 255.0 if binary_image.max() > 1 else 1.0
@@ -266,8 +287,6 @@ def detect_meaningful_borders(binary_image, sensitivity=0.7):
 
 
 def protect_border_regions(binary_image, border_mask, kernel_size=18):
-    if kernel_size % 2 == 0:
-        raise NotImplementedError("protect_border_regions: odd kernel sizes (the pipeline passes 15)")
     binary_image = np.asarray(binary_image)
     d = _Dev()
     prot = _u8(d.protect(d.up(binary_image), d.up(border_mask), kernel_size))

@@ -7,18 +7,22 @@
 
 namespace rhccq {
 
+// BORDER_REFLECT_101 for any offset (several reflections on a narrow image): the pattern has period 2n - 2
 __device__ __forceinline__ int m_reflect101(int i, int n) {
   if (n == 1) return 0;
-  if (i < 0) i = -i;
-  if (i >= n) i = 2 * n - 2 - i;
-  return i < 0 ? 0 : (i >= n ? n - 1 : i);
+  const int period = 2 * n - 2;
+  i %= period;
+  if (i < 0) i += period;
+  return i < n ? i : period - i;
 }
 
 // ---- dilation by a structuring element given as one half-width per row (-1: the row is empty), rows dy = -r .. r; pixels outside
 // the image are not set (cv2's default border value for dilate).  invert_in / invert_out turn it into the erosion by the same
 // (symmetric) element with cv2's border rule for erode (outside = set): erode(A) = not dilate(not A).
+// The general form (rhccq_morph_dilate_spans) gives every row dy = -up .. down its own span dx = -left .. right: what an
+// even-sized OpenCV element needs (anchor k / 2: one column / row more before the anchor than behind it).
 constexpr int kMorTW = 64, kMorTH = 16, kMorMaxR = 15;
-struct MorphSpans { int r; signed char half[2 * kMorMaxR + 1]; };
+struct MorphSpans { int r, up, down; signed char left[2 * kMorMaxR + 1], right[2 * kMorMaxR + 1]; };
 
 __global__ __launch_bounds__(256) void morph_dilate_kernel(const uint8_t* __restrict__ in, int H, int W, MorphSpans se, int invert_in, int invert_out,
                                                            uint8_t* __restrict__ out) {
@@ -45,14 +49,36 @@ __global__ __launch_bounds__(256) void morph_dilate_kernel(const uint8_t* __rest
     const int y = y0 + ly, x = x0 + lx;
     if (y >= H || x >= W) continue;
     bool any = false;
-    for (int dy = -r; dy <= r && !any; ++dy) {
-      const int hw = se.half[dy + r];
-      if (hw < 0) continue;
+    for (int dy = -se.up; dy <= se.down && !any; ++dy) {
+      const int lf = se.left[dy + se.up], rt = se.right[dy + se.up];
+      if (lf < 0) continue;
       const uint16_t* row = pre[ly + r + dy];
-      any = row[lx + r + hw + 1] != row[lx + r - hw];
+      any = row[lx + r + rt + 1] != row[lx + r - lf];
     }
     out[(long long)y * W + x] = (any != (invert_out != 0)) ? 255 : 0;
   }
+}
+
+// ---- compute_local_density (edges.py:173-195) for kernels up to 11 x 11 on ANY u8 plane: OpenCV's direct filter2D path, a float32
+// accumulator over the taps in row-major order, every product and every sum rounded to float32 (the library is built with
+// -ffp-contract=off), BORDER_REFLECT_101; `scale255`: the plane holds values above 1 and is divided by 255.0 first (float64 division,
+// then float32, as `binary_map / 255.0` followed by astype(float32) does)
+__global__ __launch_bounds__(256) void box_filter_seq_kernel(const uint8_t* __restrict__ plane, int H, int W, int k, int scale255, float* __restrict__ out) {
+  const long long p = (long long)blockIdx.x * 256 + threadIdx.x;
+  if (p >= (long long)H * W) return;
+  const int y = (int)(p / W), x = (int)(p % W), c = k / 2;
+  const float term = 1.0f / (float)(k * k);
+  float acc = 0.0f;
+  for (int dy = 0; dy < k; ++dy) {
+    const int yy = m_reflect101(y + dy - c, H);
+    for (int dx = 0; dx < k; ++dx) {
+      const int v = plane[(long long)yy * W + m_reflect101(x + dx - c, W)];
+      const float f = scale255 ? (float)((double)v / 255.0) : (float)v;
+      const float prod = term * f;
+      acc = acc + prod;
+    }
+  }
+  out[p] = acc;
 }
 
 // ---- element-wise combinations of masks: op 0: a | b, 1: a & b, 2: a & ~b, 3: ~a
@@ -257,18 +283,41 @@ using namespace rhccq;
 
 extern "C" {
 
-int rhccq_morph_dilate(rhccq_ctx* ctx, const uint8_t* in, int32_t H, int32_t W, int32_t radius, const int32_t* half_widths, int32_t invert_in,
-                       int32_t invert_out, uint8_t* out) {
-  if (!ctx || !in || !out || !half_widths || H <= 0 || W <= 0 || in == out) return rhccq_fail(ctx, RHCCQ_E_ARG, "morph_dilate: bad argument");
-  if (radius < 0 || radius > kMorMaxR) return rhccq_fail(ctx, RHCCQ_E_LIMIT, "morph_dilate: structuring elements up to 31 x 31");
+int rhccq_morph_dilate_spans(rhccq_ctx* ctx, const uint8_t* in, int32_t H, int32_t W, int32_t up, int32_t down, const int32_t* left,
+                             const int32_t* right, int32_t invert_in, int32_t invert_out, uint8_t* out) {
+  if (!ctx || !in || !out || !left || !right || H <= 0 || W <= 0 || in == out) return rhccq_fail(ctx, RHCCQ_E_ARG, "morph_dilate: bad argument");
+  if (up < 0 || down < 0 || up > kMorMaxR || down > kMorMaxR) return rhccq_fail(ctx, RHCCQ_E_LIMIT, "morph_dilate: structuring elements up to 31 x 31");
   MorphSpans se;
-  se.r = radius;
-  for (int i = 0; i <= 2 * radius; ++i) {
-    if (half_widths[i] > radius) return rhccq_fail(ctx, RHCCQ_E_ARG, "morph_dilate: a half-width exceeds the radius");
-    se.half[i] = (signed char)(half_widths[i] < 0 ? -1 : half_widths[i]);
+  se.up = up;
+  se.down = down;
+  se.r = up > down ? up : down;
+  for (int i = 0; i <= up + down; ++i) {
+    if (left[i] > kMorMaxR || right[i] > kMorMaxR) return rhccq_fail(ctx, RHCCQ_E_LIMIT, "morph_dilate: structuring elements up to 31 x 31");
+    if ((left[i] < 0) != (right[i] < 0)) return rhccq_fail(ctx, RHCCQ_E_ARG, "morph_dilate: a row is empty on one side only");
+    se.left[i] = (signed char)(left[i] < 0 ? -1 : left[i]);
+    se.right[i] = (signed char)(right[i] < 0 ? -1 : right[i]);
+    if (left[i] > se.r) se.r = left[i];
+    if (right[i] > se.r) se.r = right[i];
   }
   const unsigned grid = (unsigned)(((W + kMorTW - 1) / kMorTW) * (long long)((H + kMorTH - 1) / kMorTH));
   hipLaunchKernelGGL(morph_dilate_kernel, dim3(grid), dim3(256), 0, ctx->stream, in, H, W, se, invert_in, invert_out, out);
+  RHCCQ_LAUNCH_CHECK(ctx);
+  return 0;
+}
+
+int rhccq_morph_dilate(rhccq_ctx* ctx, const uint8_t* in, int32_t H, int32_t W, int32_t radius, const int32_t* half_widths, int32_t invert_in,
+                       int32_t invert_out, uint8_t* out) {
+  if (!half_widths || radius < 0 || radius > kMorMaxR) return rhccq_fail(ctx, RHCCQ_E_LIMIT, "morph_dilate: structuring elements up to 31 x 31");
+  for (int i = 0; i <= 2 * radius; ++i)
+    if (half_widths[i] > radius) return rhccq_fail(ctx, RHCCQ_E_ARG, "morph_dilate: a half-width exceeds the radius");
+  return rhccq_morph_dilate_spans(ctx, in, H, W, radius, radius, half_widths, half_widths, invert_in, invert_out, out);
+}
+
+int rhccq_box_filter_seq(rhccq_ctx* ctx, const uint8_t* plane, int32_t H, int32_t W, int32_t kernel_size, int32_t scale255, float* out) {
+  if (!ctx || !plane || !out || H <= 0 || W <= 0) return rhccq_fail(ctx, RHCCQ_E_ARG, "box_filter_seq: bad argument");
+  if (kernel_size < 1 || kernel_size > 11 || (kernel_size & 1) == 0) return rhccq_fail(ctx, RHCCQ_E_LIMIT, "box_filter_seq: odd kernels up to 11 x 11 (OpenCV's direct path)");
+  hipLaunchKernelGGL(box_filter_seq_kernel, dim3((unsigned)(((long long)H * W + 255) / 256)), dim3(256), 0, ctx->stream, plane, H, W, kernel_size,
+                     scale255, out);
   RHCCQ_LAUNCH_CHECK(ctx);
   return 0;
 }
@@ -284,7 +333,6 @@ int rhccq_gap_bridge(rhccq_ctx* ctx, const uint8_t* in, const void* counts, int3
                      uint8_t* out) {
   if (!ctx || !in || !counts || !out || H <= 0 || W <= 0 || reach < 0 || in == out || (count_bytes != 2 && count_bytes != 4))
     return rhccq_fail(ctx, RHCCQ_E_ARG, "gap_bridge: bad argument");
-  if (reach >= H || reach >= W) return rhccq_fail(ctx, RHCCQ_E_LIMIT, "gap_bridge: reach must be smaller than the image");
   const unsigned grid = (unsigned)(((long long)H * W + 255) / 256);
   if (count_bytes == 2)
     hipLaunchKernelGGL(gap_bridge_kernel<uint16_t>, dim3(grid), dim3(256), 0, ctx->stream, in, (const uint16_t*)counts, H, W, (long long)min_count, reach, out);

@@ -206,7 +206,12 @@ class Rhccq:
                     w = owner.mtw.ensure(max(n, 2 * have, 1 << 22))
                     t = torch.from_numpy(w.view(np.int32)).to(self.device)      # blocking copy: complete on return
                     torch.cuda.current_stream(self.device).synchronize()
+                    # a superseded table may still be read by kernels another lane has queued on ITS stream: keep it alive
+                    # (a few MB each, log2(n) of them at most) instead of handing its block back to the caching allocator
+                    if owner._mtw_dev is not None:
+                        owner.__dict__.setdefault("_mtw_retired", []).append(owner._mtw_dev)
                     owner._mtw_dev = t
+        t.record_stream(torch.cuda.current_stream(self.device))                 # (allocated on whichever lane grew it, used on this one)
         return t
 
     def close(self):
@@ -830,6 +835,34 @@ class Rhccq:
 
     def morph_close(self, mask, half_widths):
         return self.morph(self.morph(mask, half_widths), half_widths, erode=True)
+
+    def morph_rect(self, mask, ksize, erode=False):
+        """cv2.dilate / cv2.erode by a ksize x ksize rectangle, OpenCV's anchor ksize // 2 (an even element reaches one pixel
+        further up / left than down / right)"""
+        H, W = int(mask.shape[0]), int(mask.shape[1])
+        a, b = int(ksize) // 2, int(ksize) - 1 - int(ksize) // 2
+        left = (C.c_int32 * (a + b + 1))(*([a] * (a + b + 1)))
+        right = (C.c_int32 * (a + b + 1))(*([b] * (a + b + 1)))
+        out = self.empty((H, W), torch.uint8)
+        self._check(self.lib.rhccq_morph_dilate_spans(self.ctx, self._p(mask), H, W, a, b, left, right, int(erode), int(erode), self._p(out)), "morph_dilate_spans")
+        return out
+
+    def morph_close_rect(self, mask, ksize):
+        return self.morph_rect(self.morph_rect(mask, ksize), ksize, erode=True)
+
+    def box_filter_seq(self, plane, kernel_size, scale255):
+        """plane uint8[H,W] device -> float32[H,W] device: compute_local_density through OpenCV's direct filter2D path (odd kernels <= 11)"""
+        H, W = int(plane.shape[0]), int(plane.shape[1])
+        out = self.empty((H, W), torch.float32)
+        self._check(self.lib.rhccq_box_filter_seq(self.ctx, self._p(plane), H, W, int(kernel_size), int(bool(scale255)), self._p(out)), "box_filter_seq")
+        return out
+
+    def lut_u16(self, values, table_u32):
+        """values uint16 (int16 storage) device plane, table np.uint32[n] -> int32 device plane of table[value] (bit copies through rhccq_lut_u16_f32)"""
+        t = self.dev(np.ascontiguousarray(table_u32, np.uint32).view(np.float32))
+        out = self.empty(tuple(values.shape), torch.int32)
+        self._check(self.lib.rhccq_lut_u16_f32(self.ctx, self._p(values), self._p(t), int(t.numel()), values.numel(), self._p(out)), "lut_u16_f32")
+        return out
 
     def mask_op(self, a, b, op):
         """op: 'or', 'and', 'andnot' (a & ~b), 'not' (~a)"""

@@ -1,5 +1,6 @@
 """The reference's Python interface (encoder.compression.*, decoder.uncompression.*) served by the HIP
 path, checked against the oracle and the reference's golden outputs.  GPU only."""
+import json
 import os
 
 import numpy as np
@@ -7,6 +8,9 @@ import pytest
 
 pytestmark = pytest.mark.gpu
 G = os.path.join(os.path.dirname(__file__), "golden")
+
+
+STABLE = json.load(open(os.path.join(G, "g_stability.json")))["cases"]      # tests/golden/make_stability.py
 
 
 def arrs(seg):
@@ -31,8 +35,12 @@ def test_unique_and_cluster_palette_functions():
         p1, i1 = arrs(o)
         assert np.array_equal(p1, npal) and np.array_equal(i1, nidx), (i, q)          # HIP path == oracle
         assert o["compressed_colors"] == len(npal)
-        exact += np.array_equal(p1, g[f"pal{i}"]) and np.array_equal(i1, g[f"idx{i}"])  # == the reference itself
-    assert exact == 22                                        # the Tier-A count of test_oracle_golden.py::test_g4_cluster_palette
+        same = np.array_equal(p1, g[f"pal{i}"]) and np.array_equal(i1, g[f"idx{i}"])       # == the reference itself (Tier A)
+        same_px = same or (len(p1) == len(g[f"pal{i}"]) and np.array_equal(p1[i1], g[f"pal{i}"][g[f"idx{i}"]]))   # ... up to the palette order (A')
+        # the HIP path is bit-identical to the reference on EVERY case the reference itself reproduces across hosts (g_stability.json)
+        assert same_px or not STABLE[f"g4/{i}"]["reference_stable_pixels"], (i, q)
+        exact += same
+    assert exact >= 22
     black = get_all_unique_colors(np.zeros((4, 4, 3), np.uint8), (0, 0))
     assert cluster_palette_colors_parallel(20, black, eps=102.4, min_samples=1, max_colors_per_cluster=1) is black
     assert cluster_palette_colors_parallel(20, black, eps=102.4, min_samples=2, max_colors_per_cluster=1) is black
@@ -366,5 +374,8 @@ def test_dbscan_with_noise_points_g13():
         p1, i1 = arrs(o)
         assert np.array_equal(p1, npal) and np.array_equal(i1, nidx), (i, q, ms)                        # HIP path == oracle
         assert o["clustering_params"]["min_samples"] == ms
-        exact += np.array_equal(p1, g[f"pal{i}"]) and np.array_equal(i1, g[f"idx{i}"])
-    assert exact == 8                                          # the Tier-A count of test_oracle_golden.py::test_g13_dbscan_with_noise_points
+        same = np.array_equal(p1, g[f"pal{i}"]) and np.array_equal(i1, g[f"idx{i}"])
+        same_px = same or (len(p1) == len(g[f"pal{i}"]) and np.array_equal(p1[i1], g[f"pal{i}"][g[f"idx{i}"]]))
+        assert same_px or not STABLE[f"g13/{i}"]["reference_stable_pixels"], (i, q, ms)     # Tier B only where the reference is not reproducible
+        exact += same
+    assert exact >= 8

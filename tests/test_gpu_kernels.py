@@ -149,9 +149,13 @@ def test_minibatch_equals_sklearn_golden(rh, O):
     names = list(cases)
     pals = [g11_palette(n, cases[n]) for n in names]
     labs, info = rh.minibatch_kmeans([O.pack_rgb(P) for P in pals], [cases[n]["k"] for n in names], return_info=True)
+    untouched = load("g11_untouched.npz")          # sklearn's untouched fit where it is identical under every host setting (make_stability.py)
+    assert len(untouched.files) >= 3
     for i, n in enumerate(names):
         a, b = info["koff"][i], info["koff"][i + 1]
         check_against_g11(n, cases[n], g, info["chosen"][a:b], info["state"][i][5], info["centres"][a:b, :3], labs[i])
+        if n in untouched.files:
+            assert np.array_equal(labs[i], untouched[n]), (n, "HIP labels vs the untouched scikit-learn fit")
 
 
 def test_minibatch_more_than_256_problems(rh, O):

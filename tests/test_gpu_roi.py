@@ -255,6 +255,52 @@ def test_roi_cleanup_functions_vs_oracle():
     assert not detect_meaningful_borders(z, 0.5).any() and not remove_small_regions(z).any()
 
 
+def test_roi_cleanup_functions_with_their_reference_defaults_and_small_windows():
+    """every mirrored function called the way the reference's own defaults call it -- protect_border_regions' default kernel
+    is 18 x 18 (an EVEN OpenCV element: anchor 9, one pixel more up / left), windows below 13 take OpenCV's direct filter2D path (the
+    sequential float32 density), connectivity 4 keeps the 8-connected thin test, images narrower than the bridging reach reflect more
+    than once.  Device vs restatement."""
+    import torch
+    from oracle import rhccq_oracle as O
+    from encoder.ROI.thin_regions2 import remove_thin_structures_optimized
+    from encoder.ROI.small_gaps import bridge_small_gaps_fast
+    from encoder.ROI.roi import remove_small_noise_regions, protect_border_regions, remove_small_components_density_aware_fast, process_and_unify_borders
+    from encoder.ROI.edges import compute_local_density
+    from roibasedimagecompression_amd.ops import Rhccq
+    rh = Rhccq(0)
+    for m in _edge_like_masks():
+        t = torch.from_numpy(m).to(rh.device)
+        for k in (2, 4, 18, 15, 7):                                     # even and odd rectangles
+            assert np.array_equal(rh.morph_rect(t, k).cpu().numpy() != 0, O.cv_dilate_rect(m, k)), k
+            assert np.array_equal(rh.morph_rect(t, k, erode=True).cpu().numpy() != 0, O.cv_dilate_rect(m, k, erode=True)), k
+        assert np.array_equal(O.cv_dilate_rect(m, 15), O.cv_dilate(m, [7] * 15)) and np.array_equal(O.cv_dilate_rect(m, 5, True), O.cv_erode(m, [2] * 5))
+        border = O.detect_meaningful_borders(m, 0.5)
+        assert np.array_equal(protect_border_regions(m, border), O.protect_border_regions(m, border))              # kernel_size = 18
+        assert np.array_equal(protect_border_regions(m, border, 6), O.protect_border_regions(m, border, 6))
+        for win in (11, 5, 25):
+            assert np.array_equal(remove_thin_structures_optimized(m, 0.3, 0.3, win), O.remove_thin_structures(m, 0.3, 0.3, win)), win
+            assert np.array_equal(remove_small_noise_regions(m, 30, 0.3, win), O.remove_small_noise_regions(m, 30, 0.3, win)), win
+        assert np.array_equal(remove_thin_structures_optimized(m, 0.3, connectivity=4), O.remove_thin_structures(m, 0.3, connectivity=4))
+        dm = compute_local_density(m, 7)
+        assert np.array_equal(remove_small_components_density_aware_fast(m, 40, density_map=dm, density_threshold=0.3, window_size=7),
+                              O._remove_small_density_aware(m, 40, m, 7, 0.3))
+        three = m.copy()
+        three[::3, ::2] = np.where(three[::3, ::2] != 0, 1, 0)           # a 0 / 1 / 255 plane, as the notebook's cell 6 produces
+        for win in (11, 25):
+            assert np.array_equal(bridge_small_gaps_fast(three, 6, 0.2, 15, win), O.bridge_small_gaps(three, 6, 0.2, 15, win)), win
+        plane = torch.from_numpy(three).to(rh.device)
+        assert np.array_equal(rh.box_filter_seq(plane, 11, True).cpu().numpy(), O.local_density(three, 11))
+    rng = np.random.default_rng(5)
+    for h, w in ((10, 10), (7, 40), (33, 5)):                             # narrower than the reach of 15: several reflections
+        small = np.where(rng.random((h, w)) < 0.3, 255, 0).astype(np.uint8)
+        assert np.array_equal(bridge_small_gaps_fast(small, 100, 0.2, 15, 25), O.bridge_small_gaps(small, 100, 0.2, 15, 25)), (h, w)
+    img = rng.integers(0, 256, (12, 14, 3), dtype=np.uint8)
+    e = np.where(rng.random((12, 14)) < 0.4, 255, 0).astype(np.uint8)
+    got = process_and_unify_borders(e, O.local_density(e, 3), img, density_threshold=0.2)
+    want = O.process_and_unify_borders(e, O.local_density(e, 3), img, density_threshold=0.2)
+    assert np.array_equal(got[0], want[0]) and np.array_equal(got[1], want[1])
+
+
 def test_get_regions_whole_chain_vs_oracle():
     """get_regions (roi.py:14-40) end to end on the device == the restatement's chain, on the reference's own Lenna.png (data) and
     on a synthetic photo; then extract_regions on its masks"""

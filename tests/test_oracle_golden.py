@@ -57,6 +57,28 @@ def partition_equal(a, b):
     return True
 
 
+def stability(key):
+    """tests/golden/g_stability.json (make_stability.py): did the REFERENCE itself give one and the same result for this fixture case
+    under four host settings (OpenBLAS core type x numpy SIMD dispatch)?  `pixels`: up to the palette order, which the reference
+    takes from thread completion (clustering.py:458)."""
+    c = json.load(open(os.path.join(G, "g_stability.json")))["cases"][key]
+    return {"exact": c["reference_stable"], "pixels": c["reference_stable_pixels"], "genuine": c.get("default_equals_fixture_pixels", True)}
+
+
+def test_stability_table_covers_every_kmeans_fixture_case():
+    """every case of the k-means fixtures has a stability record, the default-host run of the reference reproduces every committed
+    fixture (up to the palette order), and the table names WHICH cases the reference is not reproducible on"""
+    cases = json.load(open(os.path.join(G, "g_stability.json")))["cases"]
+    want = {"g4": int(load("g4_cluster.npz")["n"]), "g9": int(load("g9_kmeans_split.npz")["n"]), "g13": int(load("g13_dbscan_min_samples.npz")["n"]),
+            "g10": 2, "g6": 15, "g11": 8}
+    for fam, n in want.items():
+        assert sum(k.startswith(fam + "/") for k in cases) == n, fam
+    assert all(c.get("default_equals_fixture_pixels", True) for c in cases.values())
+    unstable = {fam: sorted(k.split("/", 1)[1] for k, c in cases.items() if k.startswith(fam + "/") and not c["reference_stable_pixels"]) for fam in want}
+    assert sorted(unstable["g9"], key=int) == ["6", "11"]
+    assert sorted(unstable["g4"], key=int) == [str(v) for v in (2, 3, 4, 8, 9, 10, 14, 15, 16, 27, 28, 33, 34)]
+
+
 def test_g9_kmeans_split_partition_rate():
     """KMeans split (Tier A when the partition reproduces).  The restatement follows sklearn's
     algorithm with exact-integer k-means++ and KM64 Lloyd; it must reproduce the reference's
@@ -75,10 +97,11 @@ def test_g9_kmeans_split_partition_rate():
         report.append((str(g[f"name{i}"]), mc, bool(ok), float((mine == lab).mean())))
         assert max(len(s) for s in subs) <= max(mc, 2)
         assert len(subs) == lab.max() + 1 or not ok
+        # bit-exact wherever the reference itself is reproducible across hosts (g_stability.json); the others (k = n = 146 on an
+        # already quantised palette, k = 27 on a 6-level lattice: k-means++ potentials that tie exactly) are only reported
+        assert ok or not stability(f"g9/{i}")["exact"], report[-1]
     print(report)
-    # 11 of 13 identical; the two others (k = n = 146 on an already quantised palette, k = 27 on a 6-level lattice) are
-    # cases where k-means++ candidate potentials tie exactly (diagnosed against sklearn's own picks)
-    assert same == 11 and total == 13, report
+    assert total == 13 and same >= 11, report
 
 
 def psnr(a, b):
@@ -111,6 +134,8 @@ def test_g4_cluster_palette():
             tiers["A'"] += 1
             continue
         tiers["B"] += 1
+        # Tier B ONLY where the reference itself is not reproducible across hosts (tests/golden/make_stability.py)
+        assert not stability(f"g4/{i}")["pixels"], ("Tier B on a case the reference reproduces on every host", i, q)
         assert q >= 40, (i, q)                                  # every level-1 preset of the pipeline (q = 10, 20) is Tier A
         assert abs(len(npal) - len(gp)) <= 0.05 * len(gp), (i, q, len(npal), len(gp))      # observed: <= 4.8 %
         ref = psnr(gp[gi], img.reshape(-1, 3))
@@ -120,9 +145,9 @@ def test_g4_cluster_palette():
     # the observed split (sklearn 1.7.2 / numpy 2.2.6 fixtures): the B cases are KMeans splits whose k-means++ potentials tie
     # exactly in integer arithmetic (q >= 40: many small clusters on lattice-like palettes); sklearn's pick there follows the
     # summation order of OpenBLAS' dgemv for the host CPU
-    assert tiers == {"A": 22, "A'": 5, "B": 9}, tiers
+    # (observed with these fixtures: 22 A + 5 A' + 9 B; the 9 lie inside the 13 cases the reference itself does not reproduce)
     assert low_q_exact == 12
-    assert tiers["A"] + tiers["A'"] >= 18
+    assert tiers["A"] + tiers["A'"] >= 23, tiers
 
 
 def test_g13_dbscan_with_noise_points():
@@ -152,11 +177,12 @@ def test_g13_dbscan_with_noise_points():
         else:
             # (the oversize-cluster KMeans split with exactly tied k-means++ potentials, as in G4; the 8-step lattice crop ties most)
             tiers["B"] += 1
+            assert not stability(f"g13/{i}")["pixels"], ("Tier B on a case the reference reproduces on every host", i, q, ms)
             assert abs(len(npal) - len(gp)) <= 0.10 * len(gp), (i, q, ms, len(npal), len(gp))
             assert abs(psnr(gp[gi], img.reshape(-1, 3)) - psnr(npal[nidx], img.reshape(-1, 3))) < 0.5, (i, q, ms)
     print("g13 tiers", tiers, "cases with noise", noise_cases, "exact without a split", exact_without_split)
     assert noise_cases == 14 and exact_without_split == 5       # every case that involves no KMeans split is bit-identical (the raise above)
-    assert tiers == {"A": 8, "A'": 6, "B": 10}, tiers
+    assert tiers["A"] + tiers["A'"] >= 12, tiers                # (observed: 8 A + 6 A' + 10 B, every B inside the reference's own unstable set)
 
 
 def test_g10_minibatch_reference_function_bit_exact():
@@ -232,6 +258,14 @@ def test_g11_minibatch_equals_sklearn(name):
         check_against_g11(name, case, g, info2["picks"], info2["n_steps"], info2["centers"], lab2)
     if case["k"] < 500:
         assert case["default"]["equals_stable"], "below the cap the reference's own fit is the stable one"
+    # sklearn's UNTOUCHED fit (no forced argsort order), wherever it is the same under all four host settings of
+    # make_stability.py: its labels themselves (g11_untouched.npz) must come out of the restatement
+    untouched = load("g11_untouched.npz")
+    if name in untouched.files:
+        assert stability(f"g11/{name}")["exact"]
+        assert np.array_equal(lab, untouched[name]), (name, "labels of the untouched scikit-learn fit")
+    else:
+        assert not stability(f"g11/{name}")["exact"], "an ISA-stable untouched fit must be recorded and compared"
 
 
 def comps_from(g, name):
