@@ -19,11 +19,13 @@ namespace rhccq {
 constexpr int kM2Bins = 2 * 1020 * 1020 + 1;   // gx^2 + gy^2 of a 3x3 Sobel on 8-bit data
 constexpr int kM2Lds = 8192;
 
+// BORDER_REFLECT_101 for any offset (a window wider than the image reflects more than once): period 2n - 2
 __device__ __forceinline__ int reflect101(int i, int n) {
   if (n == 1) return 0;
-  if (i < 0) i = -i;
-  if (i >= n) i = 2 * n - 2 - i;
-  return i;
+  const int period = 2 * n - 2;
+  i %= period;
+  if (i < 0) i += period;
+  return i < n ? i : period - i;
 }
 __device__ __forceinline__ int clampi(int i, int n) { return i < 0 ? 0 : (i >= n ? n - 1 : i); }
 
@@ -283,7 +285,6 @@ static int box_launch(rhccq_ctx* ctx, const uint8_t* mask, int32_t H, int32_t W,
   if (!ctx || !mask || !out || H <= 0 || W <= 0) return rhccq_fail(ctx, RHCCQ_E_ARG, "box_count: bad argument");
   if (kernel_size < 1 || kernel_size > 2 * kBoxMaxR + 1 || !(kernel_size & 1)) return rhccq_fail(ctx, RHCCQ_E_LIMIT, "box_count: odd kernel sizes 1..31");
   const int r = kernel_size / 2;
-  if (r >= H || r >= W) return rhccq_fail(ctx, RHCCQ_E_LIMIT, "box_count: window radius must be smaller than the image");
   const unsigned grid = (unsigned)(((W + kBoxTW - 1) / kBoxTW) * (long long)((H + kBoxTH - 1) / kBoxTH));
   if (sum) hipLaunchKernelGGL((box_count_kernel<true, uint32_t>), dim3(grid), dim3(256), 0, ctx->stream, mask, H, W, r, (uint32_t*)out);
   else hipLaunchKernelGGL((box_count_kernel<false, uint16_t>), dim3(grid), dim3(256), 0, ctx->stream, mask, H, W, r, (uint16_t*)out);

@@ -1384,16 +1384,32 @@ __device__ __forceinline__ void mbk_inertia_block(const MbkP& P, double* st, lon
   const long long n = P.n;
   const int bs = (int)min((long long)1000, n);
   const long long n_steps_max = (100 * n) / bs;
-  for (int i = lane; i < kBatch; i += 64) s_per[i] = i < bs ? pper_p[i] : 0.0;    // rows beyond the batch: + 0.0 changes nothing
-  __builtin_amdgcn_s_waitcnt(0);
-  __builtin_amdgcn_wave_barrier();
-  if (lane != 0) return;
-  double inertia = 0.0;
-  for (int b = 0; b < kBatch; b += 8) {
-    const double4 u = *reinterpret_cast<const double4*>(&s_per[b]), v = *reinterpret_cast<const double4*>(&s_per[b + 4]);
-    inertia = inertia + u.x; inertia = inertia + u.y; inertia = inertia + u.z; inertia = inertia + u.w;
-    inertia = inertia + v.x; inertia = inertia + v.y; inertia = inertia + v.z; inertia = inertia + v.w;
+  // The sum must visit the rows in batch order, one rounding per addition (sklearn's _inertia_dense), but nothing says ONE lane
+  // has to hold all of them: lane l keeps rows 16 l .. 16 l + 15 in registers and the running sum walks the lanes -- every turn all
+  // lanes add their 16 rows to the sum so far, the lane whose turn it is has the true value, a readlane hands it on.  Same 1 024
+  // dependent additions in the same order, no LDS round trip between them (a single lane re-reading LDS every 8 additions took
+  // 12 us, and the E-step kernel this chain rides in lasted as long as the chain: 14 us of a 30 us step).
+  double v[16];
+  {
+    const double4* src = reinterpret_cast<const double4*>(pper_p + 16 * lane);
+#pragma unroll
+    for (int q = 0; q < 4; ++q) {
+      const double4 u = src[q];
+      v[4 * q] = u.x; v[4 * q + 1] = u.y; v[4 * q + 2] = u.z; v[4 * q + 3] = u.w;
+    }
+#pragma unroll
+    for (int j = 0; j < 16; ++j) v[j] = 16 * lane + j < bs ? v[j] : 0.0;     // rows beyond the batch: + 0.0 changes nothing
   }
+  (void)s_per;
+  double inertia = 0.0;
+  for (int t = 0; t < 64; ++t) {
+    double x = inertia;
+#pragma unroll
+    for (int j = 0; j < 16; ++j) x = x + v[j];
+    const unsigned long long bits = (unsigned long long)__double_as_longlong(x);
+    inertia = __longlong_as_double((long long)readlane64(bits, t));
+  }
+  if (lane != 0) return;
   st[5] = (double)(step + 1);
   double stop = 0.0;
   const double binert = inertia / (double)bs;
