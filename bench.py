@@ -1,7 +1,7 @@
 #!/usr/bin/env python3
 """bench.py -- Mpixels/s of the RHCCQ encoder hot path on MI355X (BASELINE.json metric).
 
-A "step" = one pass of the hot path over one batch of synthetic input resident in HBM.  Three workloads (--mode):
+A "step" = one pass of the hot path over one batch of synthetic input resident in HBM.  Four workloads (--mode):
 
   frame   (default; BASELINE.json configs[1]) one 3840x2160 RGB frame per GPU: per-segment unique colours ->
           three-level palette clustering (rhccq.ipynb:978-1039) -> final palette + index map, followed by the
@@ -9,13 +9,15 @@ A "step" = one pass of the hot path over one batch of synthetic input resident i
           but the reference does not contain; the extension is inside the timed region so that no
           named work is skipped, its share is reported in `stages_ms`.  Frames are independent: every rank encodes its
           own frame, no data-path collective; value = pixels of all ranks / max-over-ranks time ("weak").
+  batch   (configs[2]) a batch of 64 1920x1080 frames per GPU through FrameEncoder.encode_batch (one batched clustering call per
+          level for all frames), two quality tiers (20, 10); value = pixels of all ranks / time ("weak").
   tiled   (configs[3]) ONE 7680x4320 frame cut into one tile per GPU (2x4 at 8 GPUs), pixels stay tile-local, palettes
           are exchanged: 1 all-gather (segment bitmaps + stats) + up to 3 small MIN all-reduces over RCCL
           (parallel.TiledFrameEncoder); value = frame pixels / max-over-ranks time ("strong").
   stream  (configs[4]) a stream of 4K frames per GPU through stream.StreamEncoder (batches in flight on host threads
           with their own HIP streams), 16x16 DCT extension, two quality tiers; value = pixels of all ranks / time ("weak").
 
-    python bench.py [--gpus N] [--steps K] [--warmup W] [--mode frame|tiled|stream]
+    python bench.py [--gpus N] [--steps K] [--warmup W] [--mode frame|batch|tiled|stream]
 
 With --gpus N > 1 and no torch.distributed environment the script starts the N ranks itself (torch.distributed.run on
 127.0.0.1) BEFORE anything touches a GPU, and exits with their code; the driver's own launch line
@@ -46,7 +48,7 @@ def parse():
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=3)
     ap.add_argument("--warmup", type=int, default=2)
-    ap.add_argument("--mode", choices=["frame", "tiled", "stream"], default="frame")
+    ap.add_argument("--mode", choices=["frame", "batch", "tiled", "stream"], default="frame")
     ap.add_argument("--height", type=int, default=None)
     ap.add_argument("--width", type=int, default=None)
     ap.add_argument("--quality", type=int, default=20, help="ROI quality tier (configs[1]: the only tier)")
@@ -61,11 +63,32 @@ def parse():
     return ap.parse_args()
 
 
+def visible_gpus():
+    """GPUs this process would see, counted WITHOUT touching HIP (the parent must stay GPU-free: it only starts the ranks): KFD
+    topology nodes with SIMDs, cut by HIP_VISIBLE_DEVICES / ROCR_VISIBLE_DEVICES.  None when the topology cannot be read (then the
+    ranks themselves report a missing device)."""
+    import glob
+    n = 0
+    paths = glob.glob("/sys/class/kfd/kfd/topology/nodes/*/properties")
+    if not paths:
+        return None
+    for path in paths:
+        try:
+            props = dict(ln.split(None, 1) for ln in open(path).read().splitlines() if " " in ln)
+            n += int(props.get("simd_count", "0")) > 0
+        except Exception:
+            return None
+    for var in ("HIP_VISIBLE_DEVICES", "ROCR_VISIBLE_DEVICES", "CUDA_VISIBLE_DEVICES"):
+        v = os.environ.get(var)
+        if v is not None:
+            n = min(n, len([x for x in v.split(",") if x.strip() != ""]))
+    return n
+
+
 def self_launch(args):
     """--gpus N without a torch.distributed environment: start the N ranks (before any GPU call) and relay their exit code"""
-    import torch
-    have = torch.cuda.device_count()                      # does not initialise the GPU on this image
-    if have < args.gpus:
+    have = visible_gpus()
+    if have is not None and have < args.gpus:
         sys.stderr.write(f"bench.py: --gpus {args.gpus} but only {have} device(s) are visible\n")
         sys.exit(2)
     s = socket.socket()
@@ -143,16 +166,17 @@ def hbm_probe(rh, rgb, specs, iters=5):
     algo_bytes = H * W * (3 + 4 * len(specs))       # RGB + one int32 label per class, read once
     # HBM traffic per launch from the PMC passes kept under profiles/ (separate FETCH_SIZE / WRITE_SIZE runs of
     # this command; FETCH_SIZE doubled as MI355X_MICROARCH.md prescribes for wide coalesced reads on gfx950)
-    traffic = None
-    for name in ("r02_pmc_fetch_write_kb.json", "r01_pmc_fetch_write_kb.json"):
+    traffic, source = None, None
+    for name in ("r03_pmc_fetch_write_kb.json", "r02_pmc_fetch_write_kb.json", "r01_pmc_fetch_write_kb.json"):
         pmc = os.path.join(ROOT, "profiles", name)
         if os.path.exists(pmc) and H * W == 3840 * 2160:
             rec = json.load(open(pmc)).get("void rhccq::job_scan_kernel<true>")
             if rec:
                 traffic = (2 * rec["FETCH_SIZE"]["mean"] + rec["WRITE_SIZE"]["mean"]) * 1024
+                source = f"profiles/{name}: separate rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE passes of this command (NOT measured in this run)"
                 break
     return {"bound": "hbm", "kernel": "job_scan_kernel<true>", "achieved": algo_bytes / t / 1e9, "peak": HBM_PEAK_GBS,
-            "unit": "GB/s", "frac": algo_bytes / t / 1e9 / HBM_PEAK_GBS, "traffic": traffic,
+            "unit": "GB/s", "frac": algo_bytes / t / 1e9 / HBM_PEAK_GBS, "traffic": traffic, "traffic_source": source,
             "algorithmic_bytes_per_launch": algo_bytes, "avg_launch_s": t, "launches": iters,
             "share_of_step_gpu_time": "< 0.1 %: the per-pixel passes (scan, index, remap) are ~0.9 ms of the step"}
 
@@ -181,12 +205,13 @@ def chain_probe(rh, enc, rgb, specs, ms_per_step):
     pairs = sum((k - 1) * (2 + int(math.log(k))) * max(3 * k, 3000) for k in ks)
     ops = 8.0 * pairs
     sec = t["init_ms"] * 1e-3
-    return {"bound": "valu-latency", "kernel": "mbk_init2_kernel", "launch_ms": t["init_ms"], "problems": len(ks), "picks_longest_chain": max(ks),
+    gen3 = max(max(3 * k, 3000) for k in ks) <= 98304
+    return {"bound": "valu-latency", "kernel": "mbk_init3_kernel" if gen3 else "mbk_init2_kernel", "launch_ms": t["init_ms"], "problems": len(ks), "picks_longest_chain": max(ks),
             "us_per_pick": t["init_ms"] * 1e3 / max(ks), "share_of_step": t["init_ms"] / ms_per_step,
             "brute_force_pair_evaluations": pairs, "achieved": ops / sec / 1e12, "peak": VALU_PEAK_TOPS, "unit": "Tops/s (brute-force equivalent)",
             "frac": ops / sec / 1e12 / VALU_PEAK_TOPS, "cus_occupied": len(ks), "cus": N_CUS,
-            "note": "one workgroup per problem; the chain cannot leave its CU: the per-pick time (search -> enumerate -> evaluate -> commit, "
-                    "4 barriers, 2 L2 round trips) sets the step, not throughput"}
+            "note": "one workgroup per problem; the chain cannot leave its CU: the per-pick time (candidate search + box descent -> evaluate -> "
+                    "commit, 3 barriers, 2 L2 round trips) sets the step, not throughput"}
 
 
 def pixel_probe(rh, rgb, iters=10):
@@ -329,6 +354,21 @@ def cpu_baseline(img, lab_roi, lab_non, size, qs):
                                                 "N = 148 279 colours, k = 2 966 (BASELINE.md section 3); 0.0060 Mpixels/s for its 64-segment notebook path"}}
 
 
+def carried_cpu_baseline():
+    for name in ("r03_bench4k.json", "r02_bench4k.json"):
+        path = os.path.join(ROOT, "profiles", name)
+        if os.path.exists(path):
+            try:
+                cb = json.load(open(path)).get("cpu_baseline")
+            except Exception:
+                cb = None
+            if cb:
+                cb = dict(cb)
+                cb["carried_from"] = f"profiles/{name}: the N = 1 run of configs[1] on an MI355X box (the CPU leg is not re-timed at N > 1)"
+                return cb
+    return None
+
+
 # ---- main -----------------------------------------------------------------------------------------------------------
 def main():
     args = parse()
@@ -362,13 +402,16 @@ def main():
     Rhccq.scan_events = []          # class-wide: the lanes of the stream regime own their own contexts
     rh = Rhccq(local)
     mode = args.mode
-    H = args.height or (4320 if mode == "tiled" else 2160)
-    W = args.width or (7680 if mode == "tiled" else 3840)
+    batch_mode = mode == "batch"                          # configs[2]: the frame path with 64 1080p frames per step, tiers (20, 10)
+    if batch_mode:
+        mode = "frame"
+    H = args.height or (4320 if mode == "tiled" else (1080 if batch_mode else 2160))
+    W = args.width or (7680 if mode == "tiled" else (1920 if batch_mode else 3840))
     block = args.block or (16 if mode == "stream" else 8)
     q_roi = args.quality
-    q_bg = args.quality_bg if args.quality_bg is not None else (args.quality if mode == "frame" else 10)
+    q_bg = args.quality_bg if args.quality_bg is not None else (args.quality if (mode == "frame" and not batch_mode) else 10)
     # stream regime: measured 458 Mpx/s at 3 lanes x 16 frames, 570 at 5 x 24, 574 at 6 x 32, 605 at 8 x 32 (3.5 s per step)
-    B = args.frames_per_step or (24 if mode == "stream" else 1)
+    B = args.frames_per_step or (24 if mode == "stream" else (64 if batch_mode else 1))
     L = args.lanes or (5 if mode == "stream" else 1)
 
     def barrier():
@@ -449,6 +492,7 @@ def main():
             one_step(rh, enc, rgb, specs, roi_mask, block, stage_acc=stages, extra=extra)
         px = H * W * args.steps * world * B
         workload = ((f"configs[1]: single {W}x{H} RGB synthetic 'photo' frame per GPU (seed 1234+rank, sigma={args.sigma}), " if B == 1 else
+                     ("configs[2]: " if batch_mode else "") +
                      f"batch of {B} {W}x{H} RGB synthetic 'photo' frames per GPU per step (seeds 1234+rank*{B}+i, sigma={args.sigma}), ")
                     + (f"one quality tier q={q_roi} (levels {q_roi}/{min(2 * q_roi, 100)}/{min(4 * q_roi, 100)}), " if q_roi == q_bg else f"quality tiers ({q_roi},{q_bg}), ")
                     + f"2 segments per class, ROI ellipse 35 % + 3 px overlap; {block}x{block} DCT + two-tier quantisation extension in the timed region")
@@ -460,19 +504,21 @@ def main():
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
         dt = float(t.item())
     line = {
-        "metric": "Mpixels/s encoded (ROI cluster + DCT/quant) at 4K RGB" if mode != "tiled" else "Mpixels/s encoded (ROI cluster + DCT/quant), one 8K RGB frame tiled over the GPUs",
+        "metric": ("Mpixels/s encoded (ROI cluster + DCT/quant) at 4K RGB" if not batch_mode else "Mpixels/s encoded (ROI cluster + DCT/quant), batches of 1080p RGB frames") if mode != "tiled" else "Mpixels/s encoded (ROI cluster + DCT/quant), one 8K RGB frame tiled over the GPUs",
         "value": px / dt / 1e6, "unit": "Mpixels/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
         "ms_per_step": dt / args.steps * 1e3, "higher_is_better": True, "scaling": scaling, "vs_baseline": None,
         "dtype": "u8 keys / int32 exact k-means++ / f64 Lloyd+mini-batch", "data": "synthetic" + (" (REHEARSAL: ranks share one GPU)" if rehearsal else ""),
-        "config": {"workload": workload, "mode": mode, "frames_per_step_per_gpu": B * L if mode == "stream" else B, "lanes": L, "parallelism": par},
+        "config": {"workload": workload, "mode": args.mode, "frames_per_step_per_gpu": B * L if mode == "stream" else B, "lanes": L, "parallelism": par},
     }
     if rank == 0:
         if stages:
             line["stages_ms"] = {k: round(v * 1e3, 3) for k, v in stages.items()}
+            if getattr(enc, "class_timings", None):        # the two class pipelines run side by side: their own stage clocks
+                line["stages_ms"]["per_class"] = {str(ci): {k: round(v * 1e3, 3) for k, v in tm.items()} for ci, tm in sorted(enc.class_timings.items())}
         line["final_colours"] = int(len(out["palette"]))
         line["unique_colours_per_segment"] = [int(v) for v in out["n_unique"]]
         probes = not args.no_probes and world == 1 and mode == "frame" and B == 1
-        roof = hbm_probe(rh, rgb, specs) if mode != "tiled" or world == 1 else None
+        roof = hbm_probe(rh, rgb, specs)                  # per rank: this rank's frame (its tile in tiled mode)
         if probes:
             dom = chain_probe(rh, enc, rgb, specs, dt / args.steps * 1e3)
             if roof is not None and dom is not None:
@@ -481,10 +527,11 @@ def main():
             line["pixel_neighbour_pass_extension"] = pixel_probe(rh, rgb)
             line["roi_stage_upstream"] = roi_stage_probe(rh, img)
         line["roofline"] = roof
-        if args.cpu_sample and world == 1 and mode == "frame":
+        if args.cpu_sample and world == 1:
             line["cpu_baseline"] = cpu_baseline(img, lr, ln, min(args.cpu_sample, H, W), (q_roi, q_bg))
         else:
-            line["cpu_baseline"] = None
+            # N > 1: the CPU leg is timed at N = 1 only (one bounded sample per box); carry the N = 1 figure of record along
+            line["cpu_baseline"] = carried_cpu_baseline()
         print(json.dumps(line), flush=True)
     if world > 1:
         dist.barrier()

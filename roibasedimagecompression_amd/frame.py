@@ -48,6 +48,10 @@ class ClassSpec:
         self.n_seg = len(self.seg_region)
 
 
+class _TableOverflow(Exception):
+    pass
+
+
 class _Comp:
     """A component of the hierarchy in palette space."""
     __slots__ = ("keys", "fp", "top_left", "shape", "maps", "merged")
@@ -184,22 +188,23 @@ class FrameEncoder:
 
     # ---- the three levels as (collect jobs) / (apply results) pairs, so that the palettes of several frames
     # can share one batched clustering launch per level (encode_batch) ---------------------------------------
-    def level1_jobs(self, S):
-        """Clustering jobs of every segment palette of the frame (subregions.py:426-449)."""
+    def level1_jobs(self, S, only_class=None):
+        """Clustering jobs of every segment palette of the frame (subregions.py:426-449); `only_class`: of one class."""
         classes, pal_off = S["classes"], S["pal_off"]
         jobs, job_ids = [], []
         # palettes of >= 10 000 colours stay in HBM (MiniBatch branch); the small ones (DBSCAN branch) are
         # brought to the host in ONE copy
         nblk = S["has_black"].astype(np.int64)
-        big = S["present"] & (S["P"] - nblk >= 10000)
-        small_ids = np.nonzero(S["present"] & ~big)[0]
+        present = S["present"] if only_class is None else (S["present"] & (S["job_class"] == only_class))
+        big = present & (S["P"] - nblk >= 10000)
+        small_ids = np.nonzero(present & ~big)[0]
         host_keys = {}
         if len(small_ids):
             lo, hi = int(pal_off[small_ids[0]]), int(pal_off[small_ids[-1] + 1])
             chunk = S["keys_dev"][lo:hi].cpu().numpy().view(np.uint32)
             for j in small_ids:
                 host_keys[int(j)] = chunk[pal_off[j] - lo:pal_off[j + 1] - lo]
-        for j in np.nonzero(S["present"])[0]:
+        for j in np.nonzero(present)[0]:
             q = classes[S["job_class"][j]].quality
             eps, _, mc = clustering_params(int(S["P"][j]), q)
             jb = {"quality": q, "eps": eps, "mc": mc}
@@ -335,6 +340,125 @@ class FrameEncoder:
             result["levels"] = levels
         return result
 
+    # ---- levels 1 and 2 of the region classes side by side ------------------------------------------------------
+    # Nothing of a class's level 1 -> merge -> level 2 chain depends on the other class (regions.py:9-70 is called once per
+    # class, rhccq.ipynb:1001-1013); only quantize_image (level 3) needs both.  On a 4K frame one class is usually done long
+    # before the other (its k-means++ chains are shorter, or the other class holds a straggling mini-batch problem), so each
+    # class runs as a pipeline of its own -- host thread, HIP stream, sibling context -- and its merge bookkeeping and level 2
+    # disappear behind the slower class's level 1.
+    PIPELINE_CLASSES = True       # (the tiled multi-GPU encoder turns it off: its collectives must stay in one order on every rank)
+
+    def _class_pipeline(self, S, ci, rhc, table_base, table_room, lut1, fp_all):
+        """level 1 -> merge per region -> merge per class -> level 2 of class `ci` on context `rhc` (current stream: its own)"""
+        classes, pal_off, job_base = S["classes"], S["pal_off"], S["job_base"]
+        r0, r1, c0, c1 = S["crop"]
+        tm, t_prev = {}, time.perf_counter()
+
+        def mark(name):
+            nonlocal t_prev
+            t = time.perf_counter()
+            tm[name] = tm.get(name, 0.0) + (t - t_prev)
+            t_prev = t
+        jobs, job_ids = self.level1_jobs(S, only_class=ci)
+        res = cluster_palettes(rhc, jobs)
+        mark("level1_cluster")
+        # entries of this class's clustered level-1 palettes live at table_base[ci] + ...: a slice of the frame-wide tables
+        # (lut1 values, first positions, lut2) fixed BEFORE the clustering from an upper bound of the palette sizes
+        new_off = table_base + np.concatenate([[0], np.cumsum([len(nk) for nk, _, _ in res])]).astype(np.int64)
+        if int(new_off[-1]) - table_base > table_room:
+            raise _TableOverflow()                               # (k-means splits blew a palette past its bound: the caller goes serial)
+        for i, (j, (nk, mp, info)) in enumerate(zip(job_ids, res)):
+            if mp is None:
+                lut1[pal_off[j]:pal_off[j + 1]] = info["mapping_dev"] + int(new_off[i])
+            else:
+                lut1[pal_off[j]:pal_off[j + 1]] = rhc.dev((new_off[i] + mp).astype(np.int32))
+        k1_off = {int(j): (int(new_off[i]), int(new_off[i + 1])) for i, j in enumerate(job_ids)}
+        # first raster position of every clustered entry of THIS class: one pass over the class's label map
+        rhc.job_index(S["rgb"], S["labels"][ci:ci + 1], S["job_base"][ci:ci + 1], S["bitmaps"], S["prefix"], S["d_pal_off"], S["fix_key"],
+                      want_idx=False, first_pos=fp_all, fp_lut=lut1)
+        lo, hi = int(new_off[0]), int(new_off[-1])
+        fp_new = fp_all[lo:hi].cpu().numpy().astype(np.int64) if hi > lo else np.zeros(0, np.int64)
+        mark("first_positions")
+        seg_comp = {}
+        for i, (j, (nk, mp, info)) in enumerate(zip(job_ids, res)):
+            seg_comp[j] = _Comp(nk, fp_new[new_off[i] - lo:new_off[i + 1] - lo], (int(r0[j]), int(c0[j])),
+                                (int(r1[j] - r0[j] + 1), int(c1[j] - c0[j] + 1)), {int(j): np.arange(len(nk), dtype=np.int32)}, False)
+        cls = classes[ci]
+        regs = []
+        for r in range(len(cls.region_bbox)):
+            segs = [seg_comp[j] for j in range(job_base[ci], job_base[ci + 1]) if S["job_region"][j] == r and j in seg_comp]
+            regs.append(_merge(segs, tuple(int(v) for v in cls.region_bbox[r])) if segs else None)
+        live = [r for r in regs if r is not None]
+        q2 = min(cls.quality * 2, 100)
+        comp3 = None
+        if live:                                                                              # rhccq.ipynb:1009-1013
+            comp = _merge(live, (0, 0, S["H"], S["W"]))
+            mark("merge")
+            eps, _, mc = clustering_params(len(comp.keys), q2)
+            (res2,) = cluster_palettes(rhc, [{"keys": comp.keys, "quality": q2, "eps": eps, "mc": mc}])
+            mark("level2_cluster")
+            (comp3,) = self.level2_finish([(ci, comp, q2)], [res2])
+            mark("level2_finish")
+        self.class_timings[ci] = tm
+        return k1_off, regs, comp3, q2
+
+    def _encode_pipelined(self, S):
+        import threading
+        rh = self.rh
+        classes = S["classes"]
+        nblk = S["has_black"].astype(np.int64)
+        # upper bound of every job's clustered palette: ceil(N q / 1000) clusters (+ black) in the MiniBatch branch, the palette
+        # itself otherwise
+        bound = np.zeros(S["n_jobs"], np.int64)
+        for j in np.nonzero(S["present"])[0]:
+            n_col = int(S["P"][j] - nblk[j])
+            q = classes[S["job_class"][j]].quality
+            bound[j] = min(int(S["P"][j]), 2 * (-(-n_col * q // 1000) + int(nblk[j])) + 64) if n_col >= 10000 else int(S["P"][j])
+        base = [int(bound[:S["job_base"][ci]].sum()) for ci in range(len(classes))]
+        room = [int(bound[S["job_base"][ci]:S["job_base"][ci + 1]].sum()) for ci in range(len(classes))]
+        total = int(bound.sum())
+        lut1 = torch.zeros((max(S["total"], 1),), dtype=torch.int32, device=rh.device)
+        fp_all = torch.full((max(total, 1),), INT_MAX, dtype=torch.int32, device=rh.device)
+        here = torch.cuda.current_stream(rh.device)
+        ready = torch.cuda.Event()
+        ready.record(here)
+        out, errors = [None] * len(classes), []
+        self.class_timings = {}
+
+        def run(ci):
+            try:
+                torch.cuda.set_device(rh.device)
+                stream, rhc = rh._lane(("class", ci))
+                with torch.cuda.stream(stream):
+                    stream.wait_event(ready)
+                    out[ci] = self._class_pipeline(S, ci, rhc, base[ci], room[ci], lut1, fp_all)
+                    done = torch.cuda.Event()
+                    done.record(stream)
+                    out[ci] += (done,)
+            except BaseException as e:                        # surfaced to the caller below
+                errors.append(e)
+
+        threads = [threading.Thread(target=run, args=(ci,), name=f"rhccq-class{ci}") for ci in range(len(classes))]
+        for t in threads:
+            t.start()
+        for t in threads:
+            t.join()
+        if errors:
+            torch.cuda.synchronize(rh.device)                     # (the other class may still be writing the shared tables)
+            raise errors[0]
+        S["lut1"], S["k1_off"], S["k1_total"] = lut1, {}, total
+        per_class, comps3, q2s = [], [], []
+        for k1_off, regs, comp3, q2, done in out:
+            here.wait_event(done)
+            S["k1_off"].update(k1_off)
+            per_class.append(regs)
+            q2s.append(q2)
+            if comp3 is not None:
+                comps3.append(comp3)
+        for t in (lut1, fp_all):
+            t.record_stream(here)
+        return per_class, comps3, q2s
+
     def encode(self, rgb, classes, want_levels=False, profile=False):
         """rgb: uint8[H,W,3] device tensor; classes: [ClassSpec] in precedence order (ROI first).
         Returns dict(palette uint8[K,3], indices (device tensor [H,W], dtype by max index),
@@ -342,6 +466,20 @@ class FrameEncoder:
         rh = self.rh
         self.timings = {}
         S = self.prepare(rgb, classes)
+        if self.PIPELINE_CLASSES and not profile and len(classes) > 1 and all(S["present"][S["job_class"] == ci].any() for ci in range(len(classes))):
+            t0 = time.perf_counter()
+            try:
+                per_class, comps3, q2s = self._encode_pipelined(S)
+            except _TableOverflow:
+                per_class = None
+            if per_class is not None:
+                self._t("levels_1_2_per_class", t0)
+                levels = {"level1": per_class, "level2": comps3} if want_levels else None
+                t0 = time.perf_counter()
+                m3c, q3, job3 = self.level3_job(S, comps3, q2s)
+                (res3,) = cluster_palettes(rh, [job3])
+                self._t("level3", t0)
+                return self.finish(S, comps3, m3c, q3, res3, want_levels, levels, profile)
         per_class = self.level1(S)
         t0 = time.perf_counter()
         lvl2, q2s, jobs2 = self.level2_jobs(S, per_class)

@@ -192,6 +192,11 @@ class Rhccq:
     def set_option(self, option, value):
         """rhccq_ctx_set_int: thresholds between equivalent kernel paths (include/rhccq.h)"""
         self._check(self.lib.rhccq_ctx_set_int(self.ctx, int(option), int(value)), "ctx_set_int")
+        # the sibling contexts of pipelined calls (one per lane / per class) follow: an option set on the context a caller holds
+        # must reach the kernels wherever they are launched from
+        self.__dict__.setdefault("_options", {})[int(option)] = int(value)
+        for _, ln in self.__dict__.get("_lanes", {}).values():
+            ln.set_option(option, value)
 
     def _mt_words_dev(self, n):
         """at least the first n raw MT19937 words on the device (uploaded once, regrown geometrically; the lanes of a
@@ -442,7 +447,9 @@ class Rhccq:
             stream = torch.cuda.Stream(self.device)
             with torch.cuda.stream(stream):
                 rh = Rhccq(self.device.index)
-            rh.mtw, rh._parent = self.mtw, self
+            rh.mtw, rh._parent = self.mtw, getattr(self, "_parent", None) or self      # (the root context owns the MT19937 word table)
+            for opt, val in self.__dict__.get("_options", {}).items():
+                rh.set_option(opt, val)
             lanes[i] = (stream, rh)
         return lanes[i]
 

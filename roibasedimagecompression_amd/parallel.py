@@ -70,6 +70,8 @@ class TiledFrameEncoder(FrameEncoder):
     differs (exchange after the scan, global positions); levels 1-3 are inherited unchanged and run
     redundantly on every rank."""
 
+    PIPELINE_CLASSES = False     # the collectives of the two classes must come in one order on every rank: classes one after the other
+
     def __init__(self, rh, frame_shape, tile, group=None):
         super().__init__(rh)
         self.frame_shape = tuple(frame_shape)
