@@ -66,6 +66,7 @@ PROTOTYPES = {
     "rhccq_ccl_work_bytes": (c_int64, [c_int32, c_int32, c_int32]),
     "rhccq_ccl": (c_int32, [c_void_p, c_void_p, c_int32, c_int32, c_int32, c_int32, c_void_p, c_int64, c_int32, c_void_p, c_void_p, c_void_p]),
     "rhccq_ccl_select": (c_int32, [c_void_p, c_void_p, c_void_p, c_int64, c_void_p]),
+    "rhccq_ccl_keys": (c_int32, [c_void_p, c_void_p, c_int32, c_int32, c_int32, c_int32, c_int32, c_int32, c_int32, c_int32, c_void_p]),
     "rhccq_roi_buffer": (c_int32, [c_void_p, c_void_p, c_void_p, c_int32, c_int32, c_int32, c_void_p, c_void_p, c_void_p, c_void_p]),
     "rhccq_edges_m2_bins": (c_int64, []),
     "rhccq_edges_gray": (c_int32, [c_void_p, c_void_p, c_int64, c_void_p, c_void_p]),

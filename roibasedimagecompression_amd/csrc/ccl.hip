@@ -327,6 +327,22 @@ __global__ __launch_bounds__(256) void ccl_relabel_kernel(const int32_t* __restr
 }
 
 // out[p] = lut[labels[p]] (u8): keeps / drops whole components (every "remove regions whose statistic ..." step of encoder/ROI/*)
+// ---- tile-parallel labelling (parallel.tiled_ccl): the ordering key of every component of a TILE in FRAME coordinates, i.e. the
+// smallest key among its pixels -- numbering 0 (8-connectivity): the 2x2 block in block-raster order, (y / 2) * ceil(Wf / 2) + x / 2;
+// numbering 1 (and 4-connectivity): the pixel in raster order, y * Wf + x.  Only the first pixel of every horizontal run asks for the
+// atomic (one per run and row instead of one per pixel: a solid blob would serialise millions of atomics on one word).
+__global__ __launch_bounds__(256) void ccl_keys_kernel(const int32_t* __restrict__ labels, int H, int W, int y0, int x0, int Wf, int block_keys,
+                                                       uint32_t* __restrict__ keys) {
+  const long long p = (long long)blockIdx.x * 256 + threadIdx.x;
+  if (p >= (long long)H * W) return;
+  const int y = (int)(p / W), x = (int)(p % W);
+  const int l = labels[p];
+  if (l <= 0 || (x > 0 && labels[p - 1] == l)) return;
+  const long long gy = y0 + y, gx = x0 + x;
+  const unsigned key = block_keys ? (unsigned)((gy >> 1) * ((Wf + 1) >> 1) + (gx >> 1)) : (unsigned)(gy * Wf + gx);
+  atomicMin(&keys[l], key);
+}
+
 __global__ __launch_bounds__(256) void ccl_select_kernel(const int32_t* __restrict__ labels, const uint8_t* __restrict__ lut, long long n,
                                                          uint8_t* __restrict__ out) {
   const long long p = (long long)blockIdx.x * 256 + threadIdx.x;
@@ -468,6 +484,20 @@ int rhccq_ccl(rhccq_ctx* ctx, const uint8_t* mask, int32_t H, int32_t W, int32_t
   hipLaunchKernelGGL(ccl_scan_blocks_kernel, dim3(1), dim3(1024), 0, ctx->stream, blocksum, L.n_blocks);
   hipLaunchKernelGGL(ccl_rank_kernel, dim3(cgrid), dim3(256), 0, ctx->stream, raw, count, cap, keybits, wordrank, blocksum, rank, stats);
   hipLaunchKernelGGL(ccl_relabel_kernel, dim3(pgrid), dim3(256), 0, ctx->stream, parent, cid, rank, count, cap, n, labels);
+  RHCCQ_LAUNCH_CHECK(ctx);
+  return 0;
+}
+
+int rhccq_ccl_keys(rhccq_ctx* ctx, const int32_t* labels, int32_t H, int32_t W, int32_t y0, int32_t x0, int32_t frame_w, int32_t numbering,
+                   int32_t connectivity, int32_t n_labels, uint32_t* keys) {
+  if (!ctx || !labels || !keys || H <= 0 || W <= 0 || y0 < 0 || x0 < 0 || frame_w < x0 + W || n_labels < 0 || (numbering != 0 && numbering != 1) ||
+      (connectivity != 4 && connectivity != 8))
+    return rhccq_fail(ctx, RHCCQ_E_ARG, "ccl_keys: bad argument");
+  const int block_keys = (numbering == 0 && connectivity == 8) ? 1 : 0;
+  if (block_keys && ((y0 | x0) & 1)) return rhccq_fail(ctx, RHCCQ_E_ARG, "ccl_keys: block keys need a tile origin with even coordinates");
+  RHCCQ_HIP(ctx, hipMemsetAsync(keys, 0xff, sizeof(uint32_t) * ((size_t)n_labels + 1), ctx->stream));
+  hipLaunchKernelGGL(ccl_keys_kernel, dim3((unsigned)(((long long)H * W + 255) / 256)), dim3(256), 0, ctx->stream, labels, H, W, y0, x0, frame_w,
+                     block_keys, keys);
   RHCCQ_LAUNCH_CHECK(ctx);
   return 0;
 }

@@ -744,6 +744,14 @@ class Rhccq:
             return n, labels, None
         return n, labels, (stats[:n + 1].cpu().numpy() if host_stats else stats)   # host_stats=False: the device tensor [cap + 1][5]
 
+    def ccl_keys(self, labels, n, y0, x0, frame_w, connectivity=8, numbering="opencv"):
+        """-> np.uint32[n + 1]: the ordering key (frame coordinates) of every component of a tile labelled by ccl(); see rhccq_ccl_keys"""
+        H, W = int(labels.shape[0]), int(labels.shape[1])
+        keys = self.empty((n + 1,), torch.int32)
+        self._check(self.lib.rhccq_ccl_keys(self.ctx, self._p(labels), H, W, int(y0), int(x0), int(frame_w), {"opencv": 0, "raster": 1}[numbering],
+                                            int(connectivity), int(n), self._p(keys)), "ccl_keys")
+        return keys.cpu().numpy().view(np.uint32)
+
     def ccl_select(self, labels, lut):
         """labels int32[H,W] device, lut uint8[n + 1] (numpy, or a device tensor) -> uint8[H,W] device = lut[labels]"""
         out = self.empty(tuple(labels.shape), torch.uint8)

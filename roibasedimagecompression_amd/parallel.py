@@ -22,7 +22,7 @@ import torch.distributed as dist
 from .frame import FrameEncoder, _Comp, _merge, _scatter_min          # noqa: F401
 from .ops import INT_MAX
 
-__all__ = ["shard_frames", "all_gather_stack", "all_reduce_min_", "TiledFrameEncoder", "tile_grid"]
+__all__ = ["shard_frames", "all_gather_stack", "all_reduce_min_", "TiledFrameEncoder", "tile_grid", "tiled_ccl", "stitch_tiles"]
 
 
 def shard_frames(n_frames, rank, world):
@@ -176,3 +176,140 @@ class TiledFrameEncoder(FrameEncoder):
         """tiles: [(r0, c0, h, w)] of every rank, rank order."""
         self._origins = np.array([[t[0], t[1]] for t in tiles], dtype=np.int64)
         return self
+
+
+# ---- connected components of a tiled mask: the seam stitch (SURVEY 8e, last bullet; BASELINE.json north_star) ------------------
+# Region extraction of the ROI stage labels a frame-sized mask (cv2.connectedComponentsWithStats in the reference,
+# encoder/ROI/roi.py:285-360).  Tile-parallel: every rank labels ITS tile (csrc/ccl.hip), then ONE all-gather moves, per tile, the
+# labels along its four borders and its component table (ordering key, bounding box, area per component; the payload length goes
+# round in a 4-byte all-gather first).  Every rank then runs the same union-find over the label pairs that face each other across
+# a seam (8-connectivity: also diagonally, across tile corners too), numbers the merged components exactly as the single-GPU kernel
+# does -- by the smallest ordering key of their parts -- and rewrites its own tile through a look-up table.  Pixels never leave
+# their tile; labels, numbering and statistics equal rhccq_ccl on the whole mask (tests/test_gpu_tiled.py).
+def stitch_tiles(tiles, frame_shape, parts, connectivity=8):
+    """tiles: [(r0, c0, h, w)] rank order; parts[r] = dict(n, top, bottom, left, right (int arrays: the tile's border labels),
+    stats int[n + 1][5] (cv2 column order, tile coordinates), keys uint[n + 1] (frame coordinates)).  Pure numpy, identical on every
+    rank.  -> (n_global, [lut_r: int32[n_r + 1] local -> global label], stats int32[n_global + 1][5])"""
+    from scipy.sparse import coo_matrix
+    from scipy.sparse.csgraph import connected_components
+    H, W = frame_shape
+    ns = np.array([int(p["n"]) for p in parts], np.int64)
+    base = np.concatenate([[0], np.cumsum(ns)])
+    N = int(base[-1])
+
+    def gid(r, lab):                                            # node of (rank, local label >= 1); -1 for background
+        lab = np.asarray(lab, np.int64)
+        return np.where(lab > 0, base[r] + lab - 1, -1)
+    ea, eb = [], []
+    steps = (-1, 0, 1) if connectivity == 8 else (0,)
+
+    def seam(a, b):                                             # two facing lines of node ids (frame-long, -1 = nothing there)
+        for d in steps:
+            if d == 0:
+                x, y = a, b
+            elif d == 1:
+                x, y = a[:-1], b[1:]
+            else:
+                x, y = a[1:], b[:-1]
+            m = (x >= 0) & (y >= 0)
+            ea.append(x[m])
+            eb.append(y[m])
+    for y in sorted({t[0] for t in tiles if t[0] > 0}):         # horizontal seams: the frame-wide rows y - 1 (above) and y (below)
+        above, below = np.full(W, -1, np.int64), np.full(W, -1, np.int64)
+        for r, (r0, c0, h, w) in enumerate(tiles):
+            if r0 + h == y:
+                above[c0:c0 + w] = gid(r, parts[r]["bottom"])
+            if r0 == y:
+                below[c0:c0 + w] = gid(r, parts[r]["top"])
+        seam(above, below)
+    for x in sorted({t[1] for t in tiles if t[1] > 0}):         # vertical seams: the frame-high columns x - 1 and x
+        lcol, rcol = np.full(H, -1, np.int64), np.full(H, -1, np.int64)
+        for r, (r0, c0, h, w) in enumerate(tiles):
+            if c0 + w == x:
+                lcol[r0:r0 + h] = gid(r, parts[r]["right"])
+            if c0 == x:
+                rcol[r0:r0 + h] = gid(r, parts[r]["left"])
+        seam(lcol, rcol)
+    if N == 0:
+        comp = np.zeros(0, np.int64)
+        n_comp = 0
+    else:
+        ea = np.concatenate(ea) if ea else np.zeros(0, np.int64)
+        eb = np.concatenate(eb) if eb else np.zeros(0, np.int64)
+        g = coo_matrix((np.ones(len(ea), np.int8), (ea, eb)), shape=(N, N))
+        n_comp, comp = connected_components(g, directed=False)
+    # component tables in frame coordinates
+    key = np.concatenate([np.asarray(p["keys"], np.int64)[1:int(p["n"]) + 1] for p in parts]) if N else np.zeros(0, np.int64)
+    st = [np.asarray(p["stats"], np.int64).reshape(-1, 5) for p in parts]
+    L = np.concatenate([s_[1:n + 1, 0] + t[1] for s_, n, t in zip(st, ns, tiles)]) if N else np.zeros(0, np.int64)
+    T = np.concatenate([s_[1:n + 1, 1] + t[0] for s_, n, t in zip(st, ns, tiles)]) if N else np.zeros(0, np.int64)
+    R = L + (np.concatenate([s_[1:n + 1, 2] for s_, n in zip(st, ns)]) if N else 0)
+    B = T + (np.concatenate([s_[1:n + 1, 3] for s_, n in zip(st, ns)]) if N else 0)
+    A = np.concatenate([s_[1:n + 1, 4] for s_, n in zip(st, ns)]) if N else np.zeros(0, np.int64)
+    big = np.iinfo(np.int64).max
+    ckey, cL, cT = np.full(n_comp, big), np.full(n_comp, big), np.full(n_comp, big)
+    cR, cB, cA = np.zeros(n_comp, np.int64), np.zeros(n_comp, np.int64), np.zeros(n_comp, np.int64)
+    np.minimum.at(ckey, comp, key)
+    np.minimum.at(cL, comp, L)
+    np.minimum.at(cT, comp, T)
+    np.maximum.at(cR, comp, R)
+    np.maximum.at(cB, comp, B)
+    np.add.at(cA, comp, A)
+    order = np.argsort(ckey, kind="stable")                     # keys are unique: a component's first block / pixel is its own
+    label_of = np.empty(n_comp, np.int64)
+    label_of[order] = np.arange(1, n_comp + 1)
+    luts = []
+    for r in range(len(parts)):
+        lut = np.zeros(int(ns[r]) + 1, np.int32)
+        lut[1:] = label_of[comp[base[r]:base[r + 1]]]
+        luts.append(lut)
+    stats = np.zeros((n_comp + 1, 5), np.int32)
+    stats[1:, 0], stats[1:, 1] = cL[order], cT[order]
+    stats[1:, 2], stats[1:, 3], stats[1:, 4] = (cR - cL)[order], (cB - cT)[order], cA[order]
+    # the background row: the union of the tiles' background boxes
+    bg = [(s_[0], t) for s_, t in zip(st, tiles) if s_[0, 4] > 0]
+    if bg:
+        l0 = min(s0[0] + t[1] for s0, t in bg)
+        t0 = min(s0[1] + t[0] for s0, t in bg)
+        r1 = max(s0[0] + s0[2] + t[1] for s0, t in bg)
+        b1 = max(s0[1] + s0[3] + t[0] for s0, t in bg)
+        stats[0] = (l0, t0, r1 - l0, b1 - t0, sum(int(s0[4]) for s0, _ in bg))
+    return n_comp, luts, stats
+
+
+def tiled_ccl(rh, mask_tile, tile, frame_shape, tiles, group=None, connectivity=8, numbering="opencv"):
+    """Connected components of a frame-sized mask, one tile per rank.  mask_tile: this rank's tile (device u8 / bool [h, w]);
+    tile = (r0, c0, h, w) of this rank, tiles = every rank's, rank order (parallel.tile_grid; even origins for OpenCV's 8-connectivity
+    numbering).  -> (n, labels of this tile (device int32[h, w], FRAME-wide numbering), stats np.int32[n + 1][5] as rhccq_ccl gives
+    for the whole mask): identical to labelling the whole mask on one GPU."""
+    world = dist.get_world_size(group) if dist.is_initialized() else 1
+    rank = dist.get_rank(group) if dist.is_initialized() else 0
+    r0, c0, h, w = tile
+    H, W = frame_shape
+    n, lab, st = rh.ccl(mask_tile, connectivity, numbering=numbering)
+    keys = rh.ccl_keys(lab, n, r0, c0, W, connectivity, numbering)
+    strips = torch.cat([lab[0, :], lab[-1, :], lab[:, 0], lab[:, -1]]).to(torch.int64)
+    payload = torch.cat([torch.tensor([n, h, w], dtype=torch.int64, device=rh.device), strips,
+                         torch.from_numpy(st.astype(np.int64).reshape(-1)).to(rh.device), torch.from_numpy(keys.astype(np.int64)).to(rh.device)])
+    if world > 1:
+        lens = all_gather_stack(torch.tensor([payload.numel()], dtype=torch.int64, device=rh.device), group).reshape(-1)
+        m = int(lens.max().item())
+        padded = torch.zeros((m,), dtype=torch.int64, device=rh.device)
+        padded[:payload.numel()] = payload
+        allp = all_gather_stack(padded, group).cpu().numpy()       # THE seam all-gather
+    else:
+        allp = payload.cpu().numpy()[None]
+    parts = []
+    for r in range(world):
+        p = allp[r]
+        nr, hr, wr = int(p[0]), int(p[1]), int(p[2])
+        o = 3
+        top, bottom = p[o:o + wr], p[o + wr:o + 2 * wr]
+        left, right = p[o + 2 * wr:o + 2 * wr + hr], p[o + 2 * wr + hr:o + 2 * wr + 2 * hr]
+        o += 2 * wr + 2 * hr
+        stats_r = p[o:o + 5 * (nr + 1)].reshape(nr + 1, 5)
+        o += 5 * (nr + 1)
+        parts.append({"n": nr, "top": top, "bottom": bottom, "left": left, "right": right, "stats": stats_r, "keys": p[o:o + nr + 1]})
+    n_glob, luts, stats = stitch_tiles(tiles, (H, W), parts, connectivity)
+    out = rh.remap(lab.reshape(-1), rh.dev(luts[rank])).reshape(h, w)
+    return n_glob, out, stats

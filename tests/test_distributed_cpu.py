@@ -93,3 +93,95 @@ def test_tile_grid_covers_frame():
         cov[r0:r0 + h, c0:c0 + w] += 1
     assert (cov == 1).all()
     assert tile_grid(4320, 7680, 2, 4)[0] == (0, 0, 2160, 1920)
+
+
+def _tile_parts(m, tiles, conn, numbering, W):
+    """numpy stand-in for the per-tile device passes of parallel.tiled_ccl (rhccq_ccl + rhccq_ccl_keys, covered by the GPU tests)"""
+    from oracle import rhccq_oracle as O
+    parts = []
+    for (r0, c0, h, w) in tiles:
+        n, lab, st = O.cv_connected_components_with_stats(m[r0:r0 + h, c0:c0 + w], conn, numbering)
+        n -= 1
+        keys = np.full(n + 1, 2 ** 32 - 1, np.int64)
+        ys, xs = np.nonzero(lab)
+        block_keys = numbering == "opencv" and conn == 8
+        k = (((ys + r0) >> 1) * ((W + 1) >> 1) + ((xs + c0) >> 1)) if block_keys else ((ys + r0) * W + xs + c0)
+        np.minimum.at(keys, lab[ys, xs], k)
+        parts.append({"n": n, "top": lab[0], "bottom": lab[-1], "left": lab[:, 0], "right": lab[:, -1], "stats": st, "keys": keys, "lab": lab})
+    return parts
+
+
+def test_seam_stitch_of_tile_labels_equals_whole_mask_labelling():
+    """parallel.stitch_tiles (the host half of the tile-parallel connected components: union-find over the label pairs facing each
+    other across tile seams, numbering by the smallest ordering key, statistics): for 1x3, 2x2, 2x4 and 4x4 tilings, 4- and
+    8-connectivity, raster and OpenCV numbering, the stitched labels / numbering / statistics equal labelling the whole mask."""
+    from oracle import rhccq_oracle as O
+    from roibasedimagecompression_amd.parallel import stitch_tiles, tile_grid
+    rng = np.random.default_rng(3)
+    checked = 0
+    for (H, W, rows, cols, dens) in ((40, 60, 2, 2, 0.45), (33, 50, 1, 3, 0.6), (64, 64, 2, 4, 0.3), (16, 16, 4, 4, 0.55), (20, 30, 1, 1, 0.5),
+                                      (48, 80, 2, 4, 0.0), (48, 80, 2, 4, 1.0)):
+        for conn in (4, 8):
+            for numbering in ("raster", "opencv"):
+                m = rng.random((H, W)) < dens
+                tiles = tile_grid(H, W, rows, cols)
+                if numbering == "opencv" and conn == 8 and any((t[0] | t[1]) & 1 for t in tiles):
+                    continue                                   # block keys need even tile origins (rhccq_ccl_keys refuses the others)
+                num, want, wstats = O.cv_connected_components_with_stats(m, conn, numbering)
+                parts = _tile_parts(m, tiles, conn, numbering, W)
+                ng, luts, stats = stitch_tiles(tiles, (H, W), parts, conn)
+                full = np.zeros((H, W), np.int64)
+                for (r0, c0, h, w), p, lut in zip(tiles, parts, luts):
+                    full[r0:r0 + h, c0:c0 + w] = lut[p["lab"]]
+                assert ng + 1 == num and np.array_equal(full, want) and np.array_equal(stats[1:], wstats[1:]), (H, W, rows, cols, conn, numbering)
+                if (~m).any():
+                    assert np.array_equal(stats[0], wstats[0])
+                checked += 1
+    assert checked >= 20
+
+
+def _ccl_worker(rank, world, port, ret):
+    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port))
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    try:
+        from roibasedimagecompression_amd.parallel import all_gather_stack, stitch_tiles, tile_grid
+        H, W = 48, 70
+        m = np.random.default_rng(8).random((H, W)) < 0.5
+        tiles = tile_grid(H, W, 1, world)
+        p = _tile_parts(m, tiles, 8, "raster", W)[rank]       # this rank's tile only
+        payload = np.concatenate([[p["n"], tiles[rank][2], tiles[rank][3]], p["top"], p["bottom"], p["left"], p["right"],
+                                  p["stats"].reshape(-1), p["keys"]]).astype(np.int64)
+        lens = all_gather_stack(torch.tensor([len(payload)], dtype=torch.int64)).reshape(-1)
+        padded = torch.zeros(int(lens.max()), dtype=torch.int64)
+        padded[:len(payload)] = torch.from_numpy(payload)
+        allp = all_gather_stack(padded).numpy()                # the seam all-gather, as parallel.tiled_ccl issues it
+        parts = []
+        for r in range(world):
+            q = allp[r]
+            n, h, w = int(q[0]), int(q[1]), int(q[2])
+            o = 3
+            top, bottom, left, right = q[o:o + w], q[o + w:o + 2 * w], q[o + 2 * w:o + 2 * w + h], q[o + 2 * w + h:o + 2 * w + 2 * h]
+            o += 2 * w + 2 * h
+            parts.append({"n": n, "top": top, "bottom": bottom, "left": left, "right": right, "stats": q[o:o + 5 * (n + 1)].reshape(n + 1, 5),
+                          "keys": q[o + 5 * (n + 1):o + 6 * (n + 1)]})
+        ng, luts, stats = stitch_tiles(tiles, (H, W), parts, 8)
+        ret[rank] = (ng, luts[rank][p["lab"]], stats, tiles[rank])
+    finally:
+        dist.destroy_process_group()
+
+
+def test_tiled_connected_components_two_ranks_gloo():
+    """the exchange of parallel.tiled_ccl over a real process group (world 2, gloo): both ranks end with the same component count and
+    statistics, and their relabelled tiles tile the whole-mask labelling"""
+    from oracle import rhccq_oracle as O
+    ret = mp.Manager().dict()
+    mp.spawn(_ccl_worker, args=(2, _free_port(), ret), nprocs=2, join=True)
+    H, W = 48, 70
+    m = np.random.default_rng(8).random((H, W)) < 0.5
+    num, want, wstats = O.cv_connected_components_with_stats(m, 8, "raster")
+    full = np.zeros((H, W), np.int64)
+    for rank in (0, 1):
+        ng, lab, stats, (r0, c0, h, w) = ret[rank]
+        assert ng + 1 == num and np.array_equal(stats, wstats)
+        full[r0:r0 + h, c0:c0 + w] = lab
+    assert np.array_equal(full, want)
