@@ -200,17 +200,25 @@ def enhanced_slic_with_texture(image, mask, n_segments=100, compactness=10):
     return segments, np.zeros((h, w), np.float64)
 
 
+def segment_dropped_by_find_contours(segment_mask):
+    """slic.py:188-193: skimage.measure.find_contours(segment_mask, level=0.5) is empty iff the mask is constant over a box of at
+    least 2 x 2 -- no crossing of the level between neighbouring pixels -- and the reference then appends nothing for the segment"""
+    rows, cols = segment_mask.shape
+    return rows >= 2 and cols >= 2 and bool(segment_mask.all())
+
+
 def extract_slic_segment_boundaries(roi_segments, bbox_mask):
     """slic.py:143-214: one dict per segment id present inside the mask.  Downstream (subregions.py:315-317) only reads
     `segment_id`; `boundary_coords` here are the segment's border pixels (a pixel with a 4-neighbour outside the segment) in
-    raster order instead of scikit-image's marching-squares contour, and -- deliberate deviation -- a segment whose mask
-    fills the whole region box is kept (the reference drops it because find_contours finds no level crossing)."""
+    raster order instead of scikit-image's marching-squares contour.  The reference's drop rule is kept: find_contours(mask, 0.5)
+    returns nothing for a mask without a level crossing, i.e. a CONSTANT mask, so a segment that fills its whole region box
+    (at least 2 x 2) is silently skipped (slic.py:188-193); boxes thinner than 2 pixels take the point-boundary branch instead."""
     out = []
     ids = np.unique(roi_segments)
     for seg_id in ids[ids != 0]:
         m = (roi_segments == seg_id) & bbox_mask
         area = int(m.sum())
-        if area == 0:
+        if area == 0 or segment_dropped_by_find_contours(m):
             continue
         p = np.pad(m, 1)
         inner = p[:-2, 1:-1] & p[2:, 1:-1] & p[1:-1, :-2] & p[1:-1, 2:]

@@ -11,6 +11,7 @@ import numpy as np
 from ..frame import ClassSpec, FrameEncoder
 from ..ops import default_context, unpack_rgb
 from ..segment import IndexList
+from .slic import segment_dropped_by_find_contours
 
 log = logging.getLogger("rhccq")
 
@@ -46,6 +47,9 @@ def _comp_to_dict(enc, S, comp, quality):
             "clustering_params": {"quality": quality, "min_samples": 1}}
 
 
+last_stats = {}        # diagnostics of the most recent call: regions, SLIC segments encoded / dropped (tools/notebook_flow.py reads it)
+
+
 def subregion_quantization(image_rgb, subregions, quality=10, subregion_type=None, debug=False, segmenter=None):
     """Returns, per region, the list the reference appends (subregions.py:634-679): [merged dict] when the
     region has several segments, [component dict] for one, [] for none.
@@ -60,7 +64,7 @@ def subregion_quantization(image_rgb, subregions, quality=10, subregion_type=Non
     # included, to the non-ROI list, roi.py:76-84); the reference treats every region on its own, so an overlapping region
     # goes to the first layer in which its pixels are still free
     layers = []
-    nxt = 0
+    nxt = dropped = 0
     for ri, region in enumerate(subregions):
         minr, minc, maxr, maxc = (int(v) for v in region["bbox"])
         mask = np.asarray(region["bbox_mask"], dtype=bool)
@@ -79,10 +83,14 @@ def subregion_quantization(image_rgb, subregions, quality=10, subregion_type=Non
             m = (seg == sid) & mask
             if not m.any():
                 continue
+            if segment_dropped_by_find_contours(m):                     # (slic.py:188-193: a segment that fills its box yields no contour)
+                dropped += 1
+                continue
             nxt += 1
             layer["n"] += 1
             view[m] = layer["n"]
             layer["seg_region"].append(local)
+    last_stats.update(regions=len(subregions), segments=nxt, segments_dropped=dropped, layers=len([l for l in layers if l["n"]]))
     if nxt == 0:
         return [[] for _ in subregions]
     layers = [l for l in layers if l["n"]]

@@ -21,8 +21,11 @@ def notebook_flow(image_rgb, roi_quality=20, nonroi_quality=10, out_path=None):
     roi_regions, nonroi_regions = extract_regions(image_rgb, roi_mask, nonroi_mask)
     t["roi_stage"] = time.perf_counter() - t0
     t0 = time.perf_counter()
+    from roibasedimagecompression_amd.api import subregions as _sub
     roi_components = subregion_quantization(image_rgb, roi_regions, quality=roi_quality, subregion_type="ROI", debug=False)
+    seg_roi = dict(_sub.last_stats)
     nonroi_components = subregion_quantization(image_rgb, nonroi_regions, quality=nonroi_quality, subregion_type="nonROI", debug=False)
+    seg_non = dict(_sub.last_stats)
     t["level1"] = time.perf_counter() - t0
     t0 = time.perf_counter()
     H, W = image_rgb.shape[:2]
@@ -41,13 +44,15 @@ def notebook_flow(image_rgb, roi_quality=20, nonroi_quality=10, out_path=None):
     if out_path:
         save_compressed(pkg, out_path)
     return final, pkg, {"region_map_roi_fraction": float(region_map.mean()), "roi_regions": len(roi_regions), "nonroi_regions": len(nonroi_regions),
-                        "seconds": {k: round(v, 3) for k, v in t.items()}}
+                        "roi_segments": seg_roi.get("segments", 0), "nonroi_segments": seg_non.get("segments", 0),
+                        "segments_dropped": seg_roi.get("segments_dropped", 0) + seg_non.get("segments_dropped", 0),
+                        "edge_fraction": float((unified > 0).mean()), "seconds": {k: round(v, 3) for k, v in t.items()}}
 
 
-def report(png, artefact, out_path):
+def report(png, artefact, out_path, roi_quality=20, nonroi_quality=10):
     from decoder.uncompression.uncompression import load_compressed, lossless_decompress, decompress_color_quantization
     img = np.asarray(Image.open(png).convert("RGB"), dtype=np.uint8)
-    final, pkg, info = notebook_flow(img, out_path=out_path)
+    final, pkg, info = notebook_flow(img, roi_quality, nonroi_quality, out_path=out_path)
     rec = np.asarray(decompress_color_quantization(lossless_decompress(load_compressed(out_path)))["image"])
 
     def stats(a):
@@ -57,6 +62,40 @@ def report(png, artefact, out_path):
     return {"image": os.path.basename(png), "this_build": dict(stats(rec), bytes=os.path.getsize(out_path)),
             "reference_artefact": dict(stats(ref), bytes=os.path.getsize(artefact)), **info}
 
+
+def all_pairs():
+    g = os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "tests", "golden")
+    return [("Lenna", os.path.join(g, "Lenna.png"), os.path.join(g, "Lenna_compressed_20_10.rhccq"))] + \
+           [(f"kodak_{i}", os.path.join(g, f"kodak_{i}.png"), os.path.join(g, f"compressed_{i}.rhccq")) for i in range(1, 25)]
+
+
+if __name__ == "__main__" and len(sys.argv) > 1 and sys.argv[1] == "--all":
+    # every (image, artefact) pair the reference ships for the (20, 10) preset -> one JSON table (profiles/r03_script_flow.json)
+    import json
+    os.makedirs("gpurun_out", exist_ok=True)
+    table = {}
+    for name, png, art in all_pairs():
+        table[name] = report(png, art, os.path.join("gpurun_out", "flow_" + name + ".rhccq"))
+        print(name, table[name], flush=True)
+    json.dump(table, open(sys.argv[2] if len(sys.argv) > 2 else "gpurun_out/script_flow_all.json", "w"), indent=1)
+    sys.exit(0)
+
+if __name__ == "__main__" and len(sys.argv) > 1 and sys.argv[1] == "--infer":
+    # the artefacts under images/rhccq/ were written with OTHER settings the reference does not record: try presets
+    import json
+    g = os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "tests", "golden")
+    os.makedirs("gpurun_out", exist_ok=True)
+    table = {}
+    for i in (1, 5):
+        for qr, qn in ((100, 100), (95, 95), (90, 90), (100, 50), (80, 80)):
+            try:
+                r = report(os.path.join(g, f"kodak_{i}.png"), os.path.join(g, f"other_settings_compressed_{i}.rhccq"), os.path.join("gpurun_out", "infer.rhccq"), qr, qn)
+                table[f"kodak_{i}@({qr},{qn})"] = {"this_build": r["this_build"], "artefact": r["reference_artefact"]}
+            except Exception as e:                          # (q = 100 divides by zero nowhere, but be safe)
+                table[f"kodak_{i}@({qr},{qn})"] = {"error": repr(e)}
+            print(f"kodak_{i}@({qr},{qn})", table[f"kodak_{i}@({qr},{qn})"], flush=True)
+    json.dump(table, open("gpurun_out/script_flow_infer.json", "w"), indent=1)
+    sys.exit(0)
 
 if __name__ == "__main__":
     g = os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "tests", "golden")
