@@ -126,11 +126,15 @@ class FrameEncoder:
     def first_positions(self, S, fp_lut, n_entries):
         """int64[n_entries]: first frame-raster position of every entry fp_lut maps (job, rank) to
         (INT_MAX where an entry has no pixel).  The tiled (multi-GPU) encoder overrides this."""
+        return self.first_positions_dev(S, fp_lut, n_entries).cpu().numpy().astype(np.int64)
+
+    def first_positions_dev(self, S, fp_lut, n_entries):
+        """the same as a device tensor (int32[n_entries], positions in THIS encoder's pixel raster)"""
         rh = self.rh
         fp = torch.full((max(n_entries, 1),), INT_MAX, dtype=torch.int32, device=rh.device)
         rh.job_index(S["rgb"], S["labels"], S["job_base"][:-1], S["bitmaps"], S["prefix"], S["d_pal_off"], S["fix_key"],
                      want_idx=False, first_pos=fp, fp_lut=fp_lut)
-        return fp[:n_entries].cpu().numpy().astype(np.int64)
+        return fp[:n_entries]
 
     # ------------------------------------------------------------------------------------------
     def prepare(self, rgb, classes):

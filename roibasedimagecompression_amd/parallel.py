@@ -164,9 +164,11 @@ class TiledFrameEncoder(FrameEncoder):
     def first_positions(self, S, fp_lut, n_entries):
         """tile-local first positions -> frame raster positions -> MIN over ranks: the only other exchange of
         the tiled path, the size of the clustered palettes (a few 10^4 int64 per segment at 4K)."""
-        local = super().first_positions(S, fp_lut, n_entries)
-        t = torch.from_numpy(self._global_pos(local)).to(self.rh.device)
-        return all_reduce_min_(t, self.group).cpu().numpy().astype(np.int64)
+        p = self.first_positions_dev(S, fp_lut, n_entries).to(torch.int64)      # stays on the device up to the collective (RCCL reduces it in place)
+        r0, c0, h, w = self.tile
+        W = self.frame_shape[1]
+        g = torch.where(p >= INT_MAX, torch.full_like(p, INT_MAX), (torch.div(p, w, rounding_mode="floor") + r0) * W + (p % w + c0))
+        return all_reduce_min_(g, self.group).cpu().numpy().astype(np.int64)
 
     @property
     def tile_origins(self):
