@@ -31,7 +31,7 @@ constexpr int kG3MaxSup = kG3MaxLeaves / 16;            // 384
 constexpr int kG3MaxDsum = kG3MaxSamples / 64;          // 64-draw sums: 1 536
 constexpr int kG3MaxTop = kG3MaxDsum / 64;              // 4 096-draw sums: 24
 constexpr int kG3MaxItems = 4096;                       // (candidate, leaf) items per pick
-constexpr int kG3WList = 128;                           // hit supers one candidate keeps (beyond: brute-force pick)
+constexpr int kG3WList = kG3MaxSup;                     // hit supers one candidate keeps: room for all of them (u16 entries, 12 KB for 16 candidates)
 constexpr int kG3Touch = 512;
 constexpr int kG3Keep = 3;                              // evaluation instruction streams (16 items each) a wave keeps in registers
 
@@ -44,6 +44,11 @@ struct G3Shared {
   uint2 ck[kTMaxI];                                     // candidate colour, its squared norm
   int n_items, overflow, n_touch2[2];
 };
+
+// number of set bits of a ballot below this lane: v_mbcnt_lo / _hi (2 instructions; popcount of the masked halves takes 4)
+__device__ __forceinline__ int g3_rank_in(unsigned long long m) {
+  return (int)__builtin_amdgcn_mbcnt_hi((unsigned)(m >> 32), __builtin_amdgcn_mbcnt_lo((unsigned)m, 0u));
+}
 
 __device__ __forceinline__ unsigned dpp_quad_sum(unsigned v) {
   v += (unsigned)__builtin_amdgcn_update_dpp(0, (int)v, 0xB1, 0xF, 0xF, true);    // quad_perm [1,0,3,2]
@@ -106,7 +111,7 @@ __global__ __launch_bounds__(kG3Threads) void mbk_init3_kernel(const uint32_t* _
   __shared__ uint32_t dsum[kG3MaxDsum];                  // per 64 consecutive draws: sum of closest
   __shared__ uint32_t dtop[kG3MaxTop];                   // per 4 096 consecutive draws
   __shared__ uint32_t items[kG3MaxItems];
-  __shared__ uint32_t wlist[kTMaxI * kG3WList];          // per candidate: the supers it may improve
+  __shared__ uint16_t wlist[kTMaxI * kG3WList];          // per candidate: the supers it may improve
   __shared__ int s_touch[2 * kG3Touch];
   const MbkP P = probs[blockIdx.x];
   const int tid = threadIdx.x, lane = tid & 63;
@@ -170,7 +175,6 @@ __global__ __launch_bounds__(kG3Threads) void mbk_init3_kernel(const uint32_t* _
   if (tid < kTMaxI) sh.delta[tid] = 0;
   if (tid < T && k > 1) sh.R[tid] = (unsigned long long)ceil(rand[P.rand_off + tid] * (double)psum);
   __syncthreads();
-  const unsigned long long below = (1ull << lane) - 1ull;
 #ifdef RHCCQ_STAMPS
   unsigned long long _acc[16] = {0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0};
   unsigned long long _last = clock64();
@@ -255,20 +259,18 @@ __global__ __launch_bounds__(kG3Threads) void mbk_init3_kernel(const uint32_t* _
         }
       }
       WSPLIT(5);
-      uint32_t* wl = wlist + t * kG3WList;
+      uint16_t* wl = wlist + t * kG3WList;
       int n_sup = 0;
 #pragma unroll
       for (int r = 0; r < kG3MaxSup / 64; ++r) {
-        const int pos = n_sup + __popcll(ms[r] & below);
-        if (hsv[r] && pos < kG3WList) wl[pos] = (uint32_t)(r * 64 + lane);
+        if (hsv[r]) wl[n_sup + g3_rank_in(ms[r])] = (uint16_t)(r * 64 + lane);
         n_sup += __popcll(ms[r]);
       }
       WSPLIT(6);
 #ifdef RHCCQ_STAMPS
       if (t == 0) { _acc[13] += (unsigned long long)n_sup; _acc[14] += (unsigned long long)((n_sup + 15) >> 4); }
 #endif
-      if (n_sup > kG3WList) { if (lane == 0) sh.overflow = 1; }
-      else {
+      {
         // the leaves of the hit supers: four supers per round (one row of lanes each), four independent rounds per batch
         for (int h0 = 0; h0 < n_sup; h0 += 16) {
           int bq[4];
@@ -277,7 +279,7 @@ __global__ __launch_bounds__(kG3Threads) void mbk_init3_kernel(const uint32_t* _
           uint32_t sq[4];
           uint4 be[4];
 #pragma unroll
-          for (int q = 0; q < 4; ++q) sq[q] = wl[min(h0 + 4 * q + rq, kG3WList - 1)];
+          for (int q = 0; q < 4; ++q) sq[q] = wl[min(h0 + 4 * q + rq, kG3WList - 1)];      // (entries beyond n_sup: stale, masked below)
           __builtin_amdgcn_sched_barrier(0);
 #pragma unroll
           for (int q = 0; q < 4; ++q) {
@@ -302,7 +304,7 @@ __global__ __launch_bounds__(kG3Threads) void mbk_init3_kernel(const uint32_t* _
             else {
 #pragma unroll
               for (int q = 0; q < 4; ++q) {
-                if (hb[q]) items[base + __popcll(mb[q] & below)] = ((uint32_t)t << 24) | (uint32_t)bq[q];
+                if (hb[q]) items[base + g3_rank_in(mb[q])] = ((uint32_t)t << 24) | (uint32_t)bq[q];
                 base += __popcll(mb[q]);
               }
             }
