@@ -50,6 +50,8 @@ const char* rhccq_last_error(const rhccq_ctx* ctx);
  *                              16 samples) up to 98 304 init samples, second generation (blocks of 64) up to 262 144, first
  *                              generation beyond; 1: the first-generation chain always; 2: the second generation whenever its
  *                              tables fit (same picks everywhere; the older chains serve larger problems and as cross-checks);
+ *   RHCCQ_OPT_INIT_CANDS_PER_WAVE  third-generation chain: how many of a pick's candidates ONE search wave finds and descends for,
+ *                              as interleaved dependency chains of one instruction stream (1, 2 or 3; same picks);
  *   RHCCQ_OPT_INIT_SHARDS      workgroups (CUs) per problem of the second-generation chain: 1 (default) = one; 2 / 4 / 8 =
  *                              up to that many, each owning a range of the draws, when every shard keeps >= 4096 init
  *                              samples and at most 64 workgroups result (they wait for each other inside the launch, so
@@ -59,6 +61,7 @@ const char* rhccq_last_error(const rhccq_ctx* ctx);
 #define RHCCQ_OPT_INIT_MAX_ITEMS 2
 #define RHCCQ_OPT_INIT_KERNEL 3
 #define RHCCQ_OPT_INIT_SHARDS 4
+#define RHCCQ_OPT_INIT_CANDS_PER_WAVE 5
 int rhccq_ctx_set_int(rhccq_ctx* ctx, int32_t option, int64_t value);
 int rhccq_sync(rhccq_ctx* ctx);                 /* hipStreamSynchronize on the context stream */
 void* rhccq_stream(rhccq_ctx* ctx);             /* the hipStream_t in use */

@@ -100,6 +100,7 @@ __device__ __forceinline__ void g3_commit_quad(bool on, int b, uint32_t ck, int 
   }
 }
 
+template <int kCW>          // candidates per search wave: 1 (one wave each), 2 or 3
 __global__ __launch_bounds__(kG3Threads) void mbk_init3_kernel(const uint32_t* __restrict__ keys, const MbkP* __restrict__ probs,
                                                                const int32_t* __restrict__ init_idx, const int32_t* __restrict__ perm,
                                                                const double* __restrict__ rand, double* __restrict__ centres,
@@ -117,6 +118,7 @@ __global__ __launch_bounds__(kG3Threads) void mbk_init3_kernel(const uint32_t* _
   const int tid = threadIdx.x, lane = tid & 63;
   const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);     // wave-uniform BY CONSTRUCTION: loops and branches on it stay scalar
   const int n = (int)P.init_n, k = (int)P.k, T = P.T;
+  const int NW = (T + kCW - 1) / kCW;                             // search waves
   const int nd = (n + 63) >> 6, np = nd << 6;                     // 64-draw blocks; padded sample count
   const int nb = np >> 4, nsb = (nb + 15) >> 4, ntop = (nd + 63) >> 6;
   uint2* samp = reinterpret_cast<uint2*>(scratch + scratch_off[blockIdx.x]);
@@ -193,55 +195,91 @@ __global__ __launch_bounds__(kG3Threads) void mbk_init3_kernel(const uint32_t* _
     const int* touch_r = s_touch + (((c - 1) & 1) ? kG3Touch : 0);
     const int n_touched = min(sh.n_touch2[(c - 1) & 1], kG3Touch);
     // ================= phase 1: waves t < T -- candidate t, the supers and the leaves it may improve ================
-    if (wave < T) {
+    if (wave < NW) {
+      // Search wave w finds candidates w, w + NW, ... (kCW of them, the last wave possibly fewer): kCW independent dependency chains
+      // in ONE instruction stream.  A chain of this phase is latency bound (~11 cycles per instruction with three such waves per
+      // SIMD, the youngest of them starved by the issue arbiter until the older ones stall); interleaved in one wave the chains fill
+      // each other's bubbles, and whatever does not depend on the candidate (the top-level scan, every super's box) is loaded once.
       // np.searchsorted(cumsum(closest), r, 'left') in DRAW order; cum and the target R = ceil(r) are exact integers
-      const int t = wave;
-      const unsigned long long rv = sh.R[t];
-      const unsigned long long R = ((unsigned long long)(unsigned)__builtin_amdgcn_readfirstlane((int)(rv >> 32)) << 32) |
-                                   (unsigned)__builtin_amdgcn_readfirstlane((int)(unsigned)rv);
-      int cand = R == 0 ? 0 : n - 1;                      // R = 0: position 0; a target beyond the total (cannot happen): the last
-      uint32_t ck = 0;
-      bool found = false;
-      if (R != 0) {
+      int tc[kCW];
+      bool on[kCW];
+      unsigned long long R[kCW];
+#pragma unroll
+      for (int c2 = 0; c2 < kCW; ++c2) {
+        tc[c2] = wave + c2 * NW;
+        on[c2] = tc[c2] < T;
+        const unsigned long long rv = sh.R[min(tc[c2], T - 1)];
+        R[c2] = ((unsigned long long)(unsigned)__builtin_amdgcn_readfirstlane((int)(rv >> 32)) << 32) |
+                (unsigned)__builtin_amdgcn_readfirstlane((int)(unsigned)rv);
+      }
+      int cand[kCW], l1[kCW], bh[kCW];
+      uint32_t ck[kCW];
+      bool found[kCW];
+      unsigned rr[kCW], rr3[kCW];
+      {
         const unsigned v = lane < ntop ? dtop[lane] : 0u;
         const unsigned long long inc = wave_incscan_limbs(v);
         const unsigned long long exc = inc - v;
-        const unsigned long long m1 = __ballot(v > 0 && exc < R && R <= inc);
-        if (m1) {
-          const int l1 = __ffsll((long long)m1) - 1;
-          const unsigned rr = (unsigned)(R - readlane64(exc, l1));             // <= the 4 096-draw sum
-          const int d2 = l1 * 64 + lane;
-          const unsigned v2 = d2 < nd ? dsum[d2] : 0u;
-          const unsigned inc2 = wave_incscan_u32(v2);
-          const unsigned long long m2 = __ballot(v2 > 0 && (inc2 - v2) < rr && rr <= inc2);
-          if (m2) {
-            const int l2 = __ffsll((long long)m2) - 1;
-            const int bh = l1 * 64 + l2;
-            const unsigned rr3 = rr - (unsigned)__builtin_amdgcn_readlane((int)(inc2 - v2), l2);   // <= the block's sum
-            const int i = (bh << 6) + lane;
-            const uint2 sv = dsamp[i];
-            const unsigned inc3 = wave_incscan_u32(i < n ? sv.y : 0u);          // 64 x 195075 fits 32 bits
-            const unsigned long long m3 = __ballot(i < n && inc3 >= rr3);
-            const int l3 = m3 ? __ffsll((long long)m3) - 1 : min(63, n - 1 - (bh << 6));
-            cand = (bh << 6) + l3;
-            ck = (uint32_t)__builtin_amdgcn_readlane((int)sv.x, l3);
-            found = true;
-          }
+#pragma unroll
+        for (int c2 = 0; c2 < kCW; ++c2) {
+          const unsigned long long m1 = __ballot(v > 0 && exc < R[c2] && R[c2] <= inc);
+          found[c2] = m1 != 0ull;
+          l1[c2] = found[c2] ? __ffsll((long long)m1) - 1 : 0;
+          rr[c2] = (unsigned)(R[c2] - readlane64(exc, l1[c2]));             // <= the 4 096-draw sum
         }
       }
-      if (!found) ck = dsamp[cand].x;
-      WSPLIT(4);
-      const CandP cp = cand_pairs(ck);
-      if (lane == 0) {
-        sh.cand[t] = cand;
-        sh.ck[t] = make_uint2(ck, norm2_key(ck));
+      {
+        unsigned v2[kCW];
+#pragma unroll
+        for (int c2 = 0; c2 < kCW; ++c2) v2[c2] = dsum[min(l1[c2] * 64 + lane, nd - 1)];
+        __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+        for (int c2 = 0; c2 < kCW; ++c2) {
+          const unsigned w2 = l1[c2] * 64 + lane < nd ? v2[c2] : 0u;
+          const unsigned inc2 = wave_incscan_u32(w2);
+          const unsigned long long m2 = __ballot(w2 > 0 && (inc2 - w2) < rr[c2] && rr[c2] <= inc2);
+          found[c2] = found[c2] && m2 != 0ull;
+          const int l2 = m2 ? __ffsll((long long)m2) - 1 : 0;
+          bh[c2] = l1[c2] * 64 + l2;
+          rr3[c2] = rr[c2] - (unsigned)__builtin_amdgcn_readlane((int)(inc2 - w2), l2);   // <= the block's sum
+        }
       }
-      // every super, 64 per round; the rounds are independent of each other (one LDS round trip for all).  The maxima may be
-      // mid-refresh by the idle waves: a stale, larger maximum is conservative
-      // (loads unconditional, indices clamped, all of them issued before the first test -- sched_barrier: left alone the compiler
-      // waits for each entry before it asks for the next, six LDS round trips instead of one)
-      unsigned long long ms[kG3MaxSup / 64];
-      bool hsv[kG3MaxSup / 64];
+      {
+        uint2 sv[kCW];
+#pragma unroll
+        for (int c2 = 0; c2 < kCW; ++c2) sv[c2] = dsamp[min((bh[c2] << 6) + lane, np - 1)];
+        __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+        for (int c2 = 0; c2 < kCW; ++c2) {
+          const int i = (bh[c2] << 6) + lane;
+          const unsigned inc3 = wave_incscan_u32(i < n ? sv[c2].y : 0u);          // 64 x 195075 fits 32 bits
+          const unsigned long long m3 = __ballot(i < n && inc3 >= rr3[c2]);
+          const int l3 = m3 ? __ffsll((long long)m3) - 1 : min(63, n - 1 - (bh[c2] << 6));
+          // R = 0: position 0; a target beyond the total (cannot happen): the last sample
+          cand[c2] = found[c2] ? (bh[c2] << 6) + l3 : (R[c2] == 0 ? 0 : n - 1);
+          ck[c2] = (uint32_t)__builtin_amdgcn_readlane((int)sv[c2].x, l3);
+        }
+      }
+#pragma unroll
+      for (int c2 = 0; c2 < kCW; ++c2)
+        if (!found[c2]) ck[c2] = dsamp[cand[c2]].x;          // (wave-uniform, rare)
+      WSPLIT(4);
+      CandP cp[kCW];
+#pragma unroll
+      for (int c2 = 0; c2 < kCW; ++c2) {
+        cp[c2] = cand_pairs(ck[c2]);
+        if (lane == 0 && on[c2]) {
+          sh.cand[tc[c2]] = cand[c2];
+          sh.ck[tc[c2]] = make_uint2(ck[c2], norm2_key(ck[c2]));
+        }
+      }
+      // every super, 64 per round, against the wave's candidates; the rounds are independent of each other (one LDS round trip for
+      // all: loads unconditional, indices clamped, all of them issued before the first test -- sched_barrier: left alone the
+      // compiler waits for each entry before it asks for the next).  The maxima may be mid-refresh by the idle waves: a stale,
+      // larger maximum is conservative.  Hits go to the candidate's own list.
+      int n_sup[kCW];
+#pragma unroll
+      for (int c2 = 0; c2 < kCW; ++c2) n_sup[c2] = 0;
       {
         uint4 se[kG3MaxSup / 64];
         const int nr = nsb > 128 ? kG3MaxSup / 64 : 2;      // (wave-uniform; the unrolled rounds beyond it cost a scalar branch)
@@ -253,45 +291,92 @@ __global__ __launch_bounds__(kG3Threads) void mbk_init3_kernel(const uint32_t* _
         __builtin_amdgcn_sched_barrier(0);
 #pragma unroll
         for (int r = 0; r < kG3MaxSup / 64; ++r) {
-          const unsigned d2 = box_dist2(cp, se[r].x, se[r].y, se[r].z);
-          hsv[r] = (bool)((int)(d2 < se[r].w) & (int)(r * 64 + lane < nsb));      // (no short circuit)
-          ms[r] = __ballot(hsv[r]);
+#pragma unroll
+          for (int c2 = 0; c2 < kCW; ++c2) {
+            const unsigned d2 = box_dist2(cp[c2], se[r].x, se[r].y, se[r].z);
+            const bool h = (bool)((int)(d2 < se[r].w) & (int)(r * 64 + lane < nsb) & (int)on[c2]);      // (no short circuit)
+            const unsigned long long m = __ballot(h);
+            if (h) wlist[tc[c2] * kG3WList + n_sup[c2] + g3_rank_in(m)] = (uint16_t)(r * 64 + lane);
+            n_sup[c2] += __popcll(m);
+          }
         }
       }
       WSPLIT(5);
-      uint16_t* wl = wlist + t * kG3WList;
-      int n_sup = 0;
-#pragma unroll
-      for (int r = 0; r < kG3MaxSup / 64; ++r) {
-        if (hsv[r]) wl[n_sup + g3_rank_in(ms[r])] = (uint16_t)(r * 64 + lane);
-        n_sup += __popcll(ms[r]);
-      }
-      WSPLIT(6);
 #ifdef RHCCQ_STAMPS
-      if (t == 0) { _acc[13] += (unsigned long long)n_sup; _acc[14] += (unsigned long long)((n_sup + 15) >> 4); }
+      if (wave == 0) { _acc[13] += (unsigned long long)n_sup[0]; _acc[14] += (unsigned long long)((n_sup[0] + 15) >> 4); }
 #endif
+      // the leaves of the hit supers: four supers per round (one row of lanes each), four independent rounds per batch; the FIRST
+      // batch of every candidate of the wave in one straight line (one atomic for all of them), further batches (one candidate in
+      // six has more than 16 hit supers) candidate by candidate
       {
-        // the leaves of the hit supers: four supers per round (one row of lanes each), four independent rounds per batch
-        for (int h0 = 0; h0 < n_sup; h0 += 16) {
+        int bq[kCW][4];
+        bool hb[kCW][4];
+        unsigned long long mb[kCW][4];
+        uint32_t sq[kCW][4];
+        uint4 be[kCW][4];
+#pragma unroll
+        for (int c2 = 0; c2 < kCW; ++c2)
+#pragma unroll
+          for (int q = 0; q < 4; ++q) sq[c2][q] = wlist[min(tc[c2], kTMaxI - 1) * kG3WList + 4 * q + rq];      // (entries beyond n_sup: stale, masked below)
+        __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+        for (int c2 = 0; c2 < kCW; ++c2)
+#pragma unroll
+          for (int q = 0; q < 4; ++q) {
+            const int b = (int)sq[c2][q] * 16 + rj;
+            bq[c2][q] = ((int)(4 * q + rq < n_sup[c2]) & (int)(b < nb)) ? b : -1;
+            be[c2][q] = blk[max(bq[c2][q], 0)];
+          }
+        __builtin_amdgcn_sched_barrier(0);
+        int total = 0;
+#pragma unroll
+        for (int c2 = 0; c2 < kCW; ++c2)
+#pragma unroll
+          for (int q = 0; q < 4; ++q) {
+            const unsigned d2 = box_dist2(cp[c2], be[c2][q].x, be[c2][q].y, be[c2][q].z);
+            hb[c2][q] = (bool)((int)(d2 < be[c2][q].w) & (int)(bq[c2][q] >= 0));
+            mb[c2][q] = __ballot(hb[c2][q]);
+            total += __popcll(mb[c2][q]);
+          }
+        if (total) {
+          int base = 0;
+          if (lane == 0) base = atomicAdd(&sh.n_items, total);
+          base = __builtin_amdgcn_readfirstlane(base);
+          if (base + total > max_items) { if (lane == 0) sh.overflow = 1; }
+          else {
+#pragma unroll
+            for (int c2 = 0; c2 < kCW; ++c2)
+#pragma unroll
+              for (int q = 0; q < 4; ++q) {
+                if (hb[c2][q]) items[base + g3_rank_in(mb[c2][q])] = ((uint32_t)tc[c2] << 24) | (uint32_t)bq[c2][q];
+                base += __popcll(mb[c2][q]);
+              }
+          }
+        }
+      }
+#pragma unroll
+      for (int c2 = 0; c2 < kCW; ++c2) {
+        const uint16_t* wl = wlist + min(tc[c2], kTMaxI - 1) * kG3WList;
+        for (int h0 = 16; h0 < n_sup[c2]; h0 += 16) {
           int bq[4];
           bool hb[4];
           unsigned long long mb[4];
           uint32_t sq[4];
           uint4 be[4];
 #pragma unroll
-          for (int q = 0; q < 4; ++q) sq[q] = wl[min(h0 + 4 * q + rq, kG3WList - 1)];      // (entries beyond n_sup: stale, masked below)
+          for (int q = 0; q < 4; ++q) sq[q] = wl[min(h0 + 4 * q + rq, kG3WList - 1)];
           __builtin_amdgcn_sched_barrier(0);
 #pragma unroll
           for (int q = 0; q < 4; ++q) {
             const int b = (int)sq[q] * 16 + rj;
-            bq[q] = ((int)(h0 + 4 * q + rq < n_sup) & (int)(b < nb)) ? b : -1;
+            bq[q] = ((int)(h0 + 4 * q + rq < n_sup[c2]) & (int)(b < nb)) ? b : -1;
             be[q] = blk[max(bq[q], 0)];
           }
           __builtin_amdgcn_sched_barrier(0);
           int total = 0;
 #pragma unroll
           for (int q = 0; q < 4; ++q) {
-            const unsigned d2 = box_dist2(cp, be[q].x, be[q].y, be[q].z);
+            const unsigned d2 = box_dist2(cp[c2], be[q].x, be[q].y, be[q].z);
             hb[q] = (bool)((int)(d2 < be[q].w) & (int)(bq[q] >= 0));
             mb[q] = __ballot(hb[q]);
             total += __popcll(mb[q]);
@@ -304,7 +389,7 @@ __global__ __launch_bounds__(kG3Threads) void mbk_init3_kernel(const uint32_t* _
             else {
 #pragma unroll
               for (int q = 0; q < 4; ++q) {
-                if (hb[q]) items[base + g3_rank_in(mb[q])] = ((uint32_t)t << 24) | (uint32_t)bq[q];
+                if (hb[q]) items[base + g3_rank_in(mb[q])] = ((uint32_t)tc[c2] << 24) | (uint32_t)bq[q];
                 base += __popcll(mb[q]);
               }
             }
@@ -313,7 +398,7 @@ __global__ __launch_bounds__(kG3Threads) void mbk_init3_kernel(const uint32_t* _
       }
     } else {
       // the other waves refresh the super maxima the previous winner touched
-      for (int i = tid - T * 64; i < n_touched * 16; i += kG3Threads - T * 64) {
+      for (int i = tid - NW * 64; i < n_touched * 16; i += kG3Threads - NW * 64) {
         const int sb = touch_r[i >> 4], b = sb * 16 + (i & 15);
         unsigned m = b < nb ? blk[b].w : 0u;
         m = dpp_row_max(m);

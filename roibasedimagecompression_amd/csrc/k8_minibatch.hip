@@ -2586,9 +2586,19 @@ int rhccq_mbk_init(rhccq_ctx* ctx, const uint32_t* keys, const rhccq_mbk_problem
   if (int e = put(ctx, dof, ho, 8 * (size_t)n_wg)) return e;
   if (nshard > 1) RHCCQ_HIP(ctx, hipMemsetAsync(xch, 0, xbytes, ctx->stream));
   RHCCQ_HIP(ctx, hipStreamSynchronize(ctx->stream));
-  if (gen3)
-    hipLaunchKernelGGL(mbk_init3_kernel, dim3(n_prob), dim3(kG3Threads), 0, ctx->stream, keys, dp, init_idx, perm, rand, centres, chosen, dscr, dof,
-                       max_items < kG3MaxItems ? max_items : kG3MaxItems);
+  if (gen3) {
+    const int mi = max_items < kG3MaxItems ? max_items : kG3MaxItems;
+    int cw = ctx->opt_init_cands_per_wave;
+    bool t16 = false;                                      // (more than 12 trials cannot occur below 98 304 samples; a fourth candidate per wave is not built)
+    for (int i = 0; i < n_prob; ++i) t16 = t16 || probs[i].T > 12;
+    if (t16) cw = 1;
+    if (cw == 3)
+      hipLaunchKernelGGL(mbk_init3_kernel<3>, dim3(n_prob), dim3(kG3Threads), 0, ctx->stream, keys, dp, init_idx, perm, rand, centres, chosen, dscr, dof, mi);
+    else if (cw == 2)
+      hipLaunchKernelGGL(mbk_init3_kernel<2>, dim3(n_prob), dim3(kG3Threads), 0, ctx->stream, keys, dp, init_idx, perm, rand, centres, chosen, dscr, dof, mi);
+    else
+      hipLaunchKernelGGL(mbk_init3_kernel<1>, dim3(n_prob), dim3(kG3Threads), 0, ctx->stream, keys, dp, init_idx, perm, rand, centres, chosen, dscr, dof, mi);
+  }
   else if (nshard > 1)
     hipLaunchKernelGGL(mbk_init2_kernel<true>, dim3(n_wg), dim3(kJThreads), 0, ctx->stream, keys, dp, init_idx, perm, rand, centres, chosen, dscr,
                        dof, max_items < kJMaxItems ? max_items : kJMaxItems, nshard, xch);

@@ -219,7 +219,8 @@ def test_dct_quant_extension(rh, O, block):
     assert np.array_equal(q.cpu().numpy(), oq)
 
 
-@pytest.mark.parametrize("path", ["default", "tiny_work_list", "small_work_list", "second_generation", "second_generation_tiny_work_list",
+@pytest.mark.parametrize("path", ["default", "tiny_work_list", "small_work_list", "one_candidate_per_wave", "two_candidates_per_wave", "three_candidates_per_wave",
+                                  "three_candidates_per_wave_small_work_list", "second_generation", "second_generation_tiny_work_list",
                                   "first_generation", "first_generation_tiny_work_list", "global_tables"])
 def test_minibatch_init_chain_many_cases(rh, O, path):
     """The k-means++ chains (mbk_init3_kernel: leaves of 16 samples under three box levels, 64-ary candidate search, quad
@@ -234,8 +235,11 @@ def test_minibatch_init_chain_many_cases(rh, O, path):
         rh.set_option(rh.OPT_INIT_LDS_BLOCKS, 8)
     if path.endswith("tiny_work_list"):
         rh.set_option(rh.OPT_INIT_MAX_ITEMS, 24)
-    if path == "small_work_list":
+    if path.endswith("small_work_list"):
         rh.set_option(rh.OPT_INIT_MAX_ITEMS, 200)
+    cw = {"one": 1, "two": 2, "three": 3}.get(path.split("_")[0])
+    if cw:
+        rh.set_option(rh.OPT_INIT_CANDS_PER_WAVE, cw)
     if path.startswith("first_generation"):
         rh.set_option(rh.OPT_INIT_KERNEL, 1)
     if path.startswith("second_generation"):
@@ -246,6 +250,10 @@ def test_minibatch_init_chain_many_cases(rh, O, path):
         rh.set_option(rh.OPT_INIT_LDS_BLOCKS, 4096)
         rh.set_option(rh.OPT_INIT_MAX_ITEMS, 12288)
         rh.set_option(rh.OPT_INIT_KERNEL, 0)
+        rh.set_option(rh.OPT_INIT_CANDS_PER_WAVE, DEFAULT_CANDS_PER_WAVE)
+
+
+DEFAULT_CANDS_PER_WAVE = 1
 
 
 @pytest.mark.parametrize("shards", [2, 8])

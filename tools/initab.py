@@ -14,10 +14,12 @@ for n in (1506367, 1027775):
     pal = allp[:n]
     k = math.ceil(len(pal) * 0.2 / 10)
     for rep in range(2):
-        for gen in (2, 0):
+        for gen, cw in ((2, 1), (0, 1), (0, 2), (0, 3)):
             rh.set_option(rh.OPT_INIT_KERNEL, gen)
+            rh.set_option(rh.OPT_INIT_CANDS_PER_WAVE, cw)
             t = {}
             labs, info = rh.minibatch_kmeans([pal], [k], return_info=True, timing=t)
-            print("N", len(pal), "k", k, "generation", gen or 3, "init ms", round(t["init_ms"], 2), "us/pick", round(t["init_ms"] * 1e3 / k, 3),
-                  "picks crc", zlib.crc32(info["chosen"].tobytes()), flush=True)
+            print("N", len(pal), "k", k, "generation", gen or 3, "candidates per wave", cw, "init ms", round(t["init_ms"], 2), "us/pick",
+                  round(t["init_ms"] * 1e3 / k, 3), "picks crc", zlib.crc32(info["chosen"].tobytes()), flush=True)
 rh.set_option(rh.OPT_INIT_KERNEL, 0)
+rh.set_option(rh.OPT_INIT_CANDS_PER_WAVE, 1)
