@@ -115,6 +115,27 @@ int rhccq_bitmap_emit(rhccq_ctx* ctx, const uint32_t* bitmaps, int32_t n_jobs, c
 int rhccq_job_blackfix(rhccq_ctx* ctx, const uint8_t* rgb, int32_t H, int32_t W, int32_t n_class,
                        const int32_t* const* labels_host, const int32_t* job_base_host,
                        const uint8_t* job_needs_fix /* device u8[n_jobs] */, unsigned long long* best);
+/* ---- frames with very many segments: unique colours by one device sort instead of 6 MiB of bitmap tables per job.
+ * rhccq_job_stats: the statistics half of rhccq_job_scan alone (stats as there).
+ * rhccq_job_sort_unique: every masked pixel of every class becomes the key (job << 24 | colour) -- in-mask black recoloured by fix_key[job] when
+ *   that is non-zero, and one synthetic (job, colour 0) entry per job listed in black_jobs (crops that show background, all-black segments) --;
+ *   one radix sort + head flags + an exclusive scan give, per job in job order, its sorted distinct colours (np.unique order) in
+ *   keys_out[job_start[job] ...) (job_start[job] = -1: the job has no colour; *n_unique = their total) and, per (class, pixel), the rank of the
+ *   pixel's colour inside its job's palette in rankmap (int32[n_class][H*W], -1 where the pixel has no job).  tmp: rhccq_job_sort_unique_bytes
+ *   (n_class * H * W + n_black) bytes of device scratch; keys_out must hold that many entries.
+ * rhccq_job_index_ranked / rhccq_frame_remap_ranked: rhccq_job_index (first positions only) / rhccq_frame_remap reading the stored ranks. */
+int rhccq_job_stats(rhccq_ctx* ctx, const uint8_t* rgb, int32_t H, int32_t W, int32_t n_class, const int32_t* const* labels_host,
+                    const int32_t* job_base_host, int32_t* stats);
+int64_t rhccq_job_sort_unique_bytes(int64_t n_entries);
+int rhccq_job_sort_unique(rhccq_ctx* ctx, const uint8_t* rgb, int32_t H, int32_t W, int32_t n_class, const int32_t* const* labels_host,
+                          const int32_t* job_base_host, int32_t n_jobs, const uint32_t* fix_key /* device, may be NULL */,
+                          const int32_t* black_jobs /* device int32[n_black] */, int32_t n_black, void* tmp, int64_t tmp_bytes, int32_t* rankmap,
+                          uint32_t* keys_out, int32_t* job_start /* device int32[n_jobs] */, int32_t* n_unique /* device int32 */);
+int rhccq_job_index_ranked(rhccq_ctx* ctx, int32_t H, int32_t W, int32_t n_class, const int32_t* const* labels_host, const int32_t* job_base_host,
+                           const int32_t* rankmap, const int64_t* pal_off, int32_t* first_pos, const int32_t* fp_lut);
+int rhccq_frame_remap_ranked(rhccq_ctx* ctx, int32_t H, int32_t W, int32_t n_class, const int32_t* const* labels_host, const int32_t* job_base_host,
+                             const int32_t* rankmap, const int64_t* pal_off, const int32_t* lut, const int32_t* lut2, int32_t default_index, void* out,
+                             int32_t out_elem_bytes);
 /* per-pixel palette index (rank of the pixel's colour in its job's palette) and/or first raster
  * position of every palette entry.  fix_key[job] (device, may be NULL) = key that replaces in-mask
  * black pixels (0 = no fix).  idx_out (int32[n_class][H*W], may be NULL): -1 where the pixel has no

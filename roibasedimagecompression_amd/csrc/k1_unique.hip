@@ -12,6 +12,8 @@
 //   (word, prefix) = word_prefix[key >> 5];  prefix + popc(word & lower_mask)        (one 8-byte gather)
 // instead of storing a 4 B/pixel index map.  All per-pixel passes are HBM-streaming kernels:
 // 4 pixels per thread, 12 B of RGB as three dwords + one int4 of labels per class.
+#include <hipcub/hipcub.hpp>
+
 #include "rhccq_common.h"
 
 namespace rhccq {
@@ -149,7 +151,7 @@ __global__ __launch_bounds__(256) void job_scan_kernel(const uint8_t* __restrict
         if (!black || black_is_colour) {
           if (kBytes) {
             bytemaps[((size_t)job << 24) + key[i]] = 1;
-          } else {
+          } else if (bitmaps != nullptr) {                    // (NULL: statistics only, rhccq_job_stats)
             uint32_t* wptr = bitmaps + (size_t)job * RHCCQ_BITMAP_WORDS + (key[i] >> 5);
             const uint32_t bit = 1u << (key[i] & 31u);
             if ((*wptr & bit) == 0u) atomicOr(wptr, bit);   // bits are only ever set: a stale read costs one redundant atomic
@@ -277,6 +279,74 @@ __global__ __launch_bounds__(256) void job_blackfix_kernel(const uint8_t* __rest
   }
 }
 
+// ---- many-segment frames: unique colours by ONE device sort ------------------------------------------------------------------
+// The bitmap path keeps 6 MiB of tables per job (2 MiB bitmap + 4 MiB of (word, prefix) pairs): fine for the handful of segments a
+// 4K frame is cut into, 12 GB at 2 048 jobs, impossible for a fine grid.  Here every masked pixel of every class becomes one
+// 64-bit key (job << 24 | colour), one radix sort (rocPRIM through hipCUB) puts equal (job, colour) pairs next to each other in
+// (job, R, G, B) order = np.unique order per job, a head flag + exclusive scan numbers the distinct pairs, and every pixel's rank
+// inside its job's palette is STORED (int32 per pixel and class) instead of being recomputed from a bitmap.  Memory: 16 B per
+// (pixel, class) of scratch + 4 B of rank, whatever the number of jobs.
+__global__ __launch_bounds__(256) void sort_keys_kernel(const uint8_t* __restrict__ rgb, int H, int W, ClassArgs ca, const uint32_t* __restrict__ fix_key,
+                                                        const int32_t* __restrict__ black_jobs, int n_black, int invalid_shift,
+                                                        unsigned long long* __restrict__ keys, uint32_t* __restrict__ vals) {
+  const int64_t n_px = (int64_t)H * W;
+  const int64_t total = (int64_t)ca.n_class * n_px + n_black;
+  for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (int64_t)gridDim.x * blockDim.x) {
+    unsigned long long kv = 1ull << invalid_shift;         // sorts behind every real key
+    if (i >= (int64_t)ca.n_class * n_px) {
+      kv = (unsigned long long)black_jobs[i - (int64_t)ca.n_class * n_px] << 24;      // colour 0 of a job whose crop shows background
+    } else {
+      const int c = (int)(i / n_px);
+      const int64_t p = i - (int64_t)c * n_px;
+      const int32_t lab = ca.labels[c] ? ca.labels[c][p] : 1;
+      if (lab > 0) {
+        const int job = ca.job_base[c] + lab - 1;
+        uint32_t k = ((uint32_t)rgb[p * 3] << 16) | ((uint32_t)rgb[p * 3 + 1] << 8) | rgb[p * 3 + 2];
+        if (k == 0u && fix_key) k = fix_key[job];
+        kv = ((unsigned long long)job << 24) | k;
+      }
+    }
+    keys[i] = kv;
+    vals[i] = (uint32_t)i;
+  }
+}
+
+__global__ __launch_bounds__(256) void sort_heads_kernel(const unsigned long long* __restrict__ keys, int64_t total, int invalid_shift,
+                                                         uint32_t* __restrict__ heads) {
+  const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= total) return;
+  const unsigned long long k = keys[i];
+  heads[i] = ((k >> invalid_shift) == 0ull && (i == 0 || keys[i - 1] != k)) ? 1u : 0u;
+}
+
+// first element of every job: where its palette starts in the list of distinct (job, colour) pairs; the palette keys themselves
+__global__ __launch_bounds__(256) void sort_emit_kernel(const unsigned long long* __restrict__ keys, const uint32_t* __restrict__ heads,
+                                                        const uint32_t* __restrict__ uidx, int64_t total, int invalid_shift,
+                                                        int32_t* __restrict__ job_start, uint32_t* __restrict__ keys_out, int32_t* __restrict__ n_unique) {
+  const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= total) return;
+  const unsigned long long k = keys[i];
+  const bool valid = (k >> invalid_shift) == 0ull;
+  if (valid && heads[i]) {
+    keys_out[uidx[i]] = (uint32_t)(k & 0xffffffull);
+    if (i == 0 || (keys[i - 1] >> 24) != (k >> 24)) job_start[(int)(k >> 24)] = (int32_t)uidx[i];
+  }
+  if (i == total - 1) *n_unique = (int32_t)(uidx[i] + heads[i]);
+}
+
+__global__ __launch_bounds__(256) void sort_ranks_kernel(const unsigned long long* __restrict__ keys, const uint32_t* __restrict__ vals,
+                                                         const uint32_t* __restrict__ heads, const uint32_t* __restrict__ uidx, int64_t total,
+                                                         int64_t n_pixel_entries, int invalid_shift, const int32_t* __restrict__ job_start,
+                                                         int32_t* __restrict__ rankmap) {
+  const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= total) return;
+  const uint32_t v = vals[i];
+  if ((int64_t)v >= n_pixel_entries) return;               // a synthetic black entry: no pixel behind it
+  const unsigned long long k = keys[i];
+  if ((k >> invalid_shift) != 0ull) { rankmap[v] = -1; return; }
+  rankmap[v] = (int32_t)(uidx[i] + heads[i] - 1u) - job_start[(int)(k >> 24)];
+}
+
 // ---- rank lookup shared by K1d and K6 ----------------------------------------------------------
 __device__ __forceinline__ uint32_t rank_of(const uint32_t* __restrict__ word_prefix, int job, uint32_t key) {
   const uint2 wp = reinterpret_cast<const uint2*>(word_prefix)[(size_t)job * RHCCQ_BITMAP_WORDS + (key >> 5)];
@@ -287,7 +357,7 @@ __global__ __launch_bounds__(256) void job_index_kernel(const uint8_t* __restric
                                                         const uint32_t* __restrict__ bitmaps, const uint32_t* __restrict__ word_prefix,
                                                         const int64_t* __restrict__ pal_off, const uint32_t* __restrict__ fix_key,
                                                         int32_t* __restrict__ idx_out, int32_t* first_pos,
-                                                        const int32_t* __restrict__ fp_lut) {
+                                                        const int32_t* __restrict__ fp_lut, const int32_t* __restrict__ rankmap) {
   const int64_t n_px = (int64_t)H * W;
   const int64_t n_quads = (n_px + 3) >> 2;
   for (int64_t q = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; q < n_quads; q += (int64_t)gridDim.x * blockDim.x) {
@@ -303,9 +373,13 @@ __global__ __launch_bounds__(256) void job_index_kernel(const uint8_t* __restric
         res[i] = -1;
         if (lab[i] <= 0 || p0 + i >= n_px) continue;
         const int job = ca.job_base[c] + lab[i] - 1;
-        uint32_t k = key[i];
-        if (k == 0u && fix_key) k = fix_key[job];      // recoloured in-mask black (0 = keep black)
-        const uint32_t rk = rank_of(word_prefix, job, k);
+        uint32_t rk;
+        if (rankmap) rk = (uint32_t)rankmap[(size_t)c * n_px + p0 + i];        // many-segment frames: the rank was stored by the sort
+        else {
+          uint32_t k = key[i];
+          if (k == 0u && fix_key) k = fix_key[job];    // recoloured in-mask black (0 = keep black)
+          rk = rank_of(word_prefix, job, k);
+        }
         res[i] = (int32_t)rk;
         if (first_pos) {
           // fp_lut (optional) maps (job, rank) to an entry of a smaller table, e.g. the level-1 clustered
@@ -333,7 +407,7 @@ __global__ __launch_bounds__(256) void frame_remap_kernel(const uint8_t* __restr
                                                           const uint32_t* __restrict__ bitmaps, const uint32_t* __restrict__ word_prefix,
                                                           const int64_t* __restrict__ pal_off, const uint32_t* __restrict__ fix_key,
                                                           const int32_t* __restrict__ lut, const int32_t* __restrict__ lut2,
-                                                          int32_t default_index, OutT* __restrict__ out) {
+                                                          int32_t default_index, OutT* __restrict__ out, const int32_t* __restrict__ rankmap) {
   const int64_t n_px = (int64_t)H * W;
   const int64_t n_quads = (n_px + 3) >> 2;
   for (int64_t q = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; q < n_quads; q += (int64_t)gridDim.x * blockDim.x) {
@@ -349,9 +423,14 @@ __global__ __launch_bounds__(256) void frame_remap_kernel(const uint8_t* __restr
       for (int i = 0; i < 4; ++i) {
         if (res[i] >= 0 || lab[i] <= 0 || p0 + i >= n_px) continue;
         const int job = ca.job_base[c] + lab[i] - 1;
-        uint32_t k = key[i];
-        if (k == 0u && fix_key) k = fix_key[job];
-        int32_t v = lut[pal_off[job] + rank_of(word_prefix, job, k)];
+        uint32_t rk;
+        if (rankmap) rk = (uint32_t)rankmap[(size_t)c * n_px + p0 + i];
+        else {
+          uint32_t k = key[i];
+          if (k == 0u && fix_key) k = fix_key[job];
+          rk = rank_of(word_prefix, job, k);
+        }
+        int32_t v = lut[pal_off[job] + rk];
         if (lut2) v = lut2[v];                          // level-1 index -> composed levels 2/3 (small, cache resident)
         res[i] = v;
       }
@@ -506,10 +585,96 @@ int rhccq_job_index(rhccq_ctx* ctx, const uint8_t* rgb, int32_t H, int32_t W, in
   if (int e = make_class_args(ctx, n_class, labels_host, job_base_host, &ca)) return e;
   const int64_t quads = ((int64_t)H * W + 3) / 4;
   hipLaunchKernelGGL(job_index_kernel, dim3(stream_grid(quads, 256)), dim3(256), 0, ctx->stream, rgb, H, W, ca, bitmaps, word_prefix,
-                     pal_off, fix_key, idx_out, first_pos, fp_lut);
+                     pal_off, fix_key, idx_out, first_pos, fp_lut, (const int32_t*)nullptr);
   RHCCQ_LAUNCH_CHECK(ctx);
   return 0;
 }
+
+int rhccq_job_index_ranked(rhccq_ctx* ctx, int32_t H, int32_t W, int32_t n_class, const int32_t* const* labels_host, const int32_t* job_base_host,
+                           const int32_t* rankmap, const int64_t* pal_off, int32_t* first_pos, const int32_t* fp_lut) {
+  if (!ctx || !rankmap || !pal_off || !first_pos || H <= 0 || W <= 0 || (int64_t)H * W > INT32_MAX)
+    return rhccq_fail(ctx, RHCCQ_E_ARG, "job_index_ranked: bad argument");
+  ClassArgs ca;
+  if (int e = make_class_args(ctx, n_class, labels_host, job_base_host, &ca)) return e;
+  const int64_t quads = ((int64_t)H * W + 3) / 4;
+  // (the kernel reads no pixel colour on this path: rgb is only dereferenced by load4px, harmless on any mapped address -- pass the rank map)
+  hipLaunchKernelGGL(job_index_kernel, dim3(stream_grid(quads, 256)), dim3(256), 0, ctx->stream, (const uint8_t*)rankmap, H, W, ca, (const uint32_t*)nullptr,
+                     (const uint32_t*)nullptr, pal_off, (const uint32_t*)nullptr, (int32_t*)nullptr, first_pos, fp_lut, rankmap);
+  RHCCQ_LAUNCH_CHECK(ctx);
+  return 0;
+}
+
+int rhccq_job_stats(rhccq_ctx* ctx, const uint8_t* rgb, int32_t H, int32_t W, int32_t n_class, const int32_t* const* labels_host,
+                    const int32_t* job_base_host, int32_t* stats) {
+  if (!ctx || !rgb || !stats || H <= 0 || W <= 0) return rhccq_fail(ctx, RHCCQ_E_ARG, "job_stats: bad argument");
+  if (((uintptr_t)rgb & 3u) != 0) return rhccq_fail(ctx, RHCCQ_E_ARG, "job_stats: rgb must be 4-byte aligned");
+  ClassArgs ca;
+  if (int e = make_class_args(ctx, n_class, labels_host, job_base_host, &ca)) return e;
+  const int64_t quads = ((int64_t)H * W + 3) / 4;
+  int64_t g64 = (quads + 1023) / 1024;
+  if (g64 > 2048) g64 = 2048;
+  if (g64 < 1) g64 = 1;
+  hipLaunchKernelGGL(job_scan_kernel<false>, dim3((int)g64), dim3(256), 0, ctx->stream, rgb, H, W, ca, 0, (uint32_t*)nullptr, (uint8_t*)nullptr, stats);
+  RHCCQ_LAUNCH_CHECK(ctx);
+  return 0;
+}
+
+static inline size_t k1_align(size_t v) { return (v + 255) & ~(size_t)255; }
+
+int64_t rhccq_job_sort_unique_bytes(int64_t n_entries) {
+  if (n_entries <= 0) return 0;
+  // keys in / out (u64), values in / out (u32), heads + their scan (u32), hipCUB's own scratch (bounded by ~ the key array)
+  return (int64_t)(2 * k1_align(8 * (size_t)n_entries) + 4 * k1_align(4 * (size_t)n_entries) + k1_align(8 * (size_t)n_entries) + (16u << 20));
+}
+
+int rhccq_job_sort_unique(rhccq_ctx* ctx, const uint8_t* rgb, int32_t H, int32_t W, int32_t n_class, const int32_t* const* labels_host,
+                          const int32_t* job_base_host, int32_t n_jobs, const uint32_t* fix_key, const int32_t* black_jobs, int32_t n_black,
+                          void* tmp, int64_t tmp_bytes, int32_t* rankmap, uint32_t* keys_out, int32_t* job_start, int32_t* n_unique) {
+  if (!ctx || !rgb || !tmp || !rankmap || !keys_out || !job_start || !n_unique || H <= 0 || W <= 0 || n_jobs <= 0 || n_black < 0 || (n_black > 0 && !black_jobs))
+    return rhccq_fail(ctx, RHCCQ_E_ARG, "job_sort_unique: bad argument");
+  ClassArgs ca;
+  if (int e = make_class_args(ctx, n_class, labels_host, job_base_host, &ca)) return e;
+  const int64_t n_px = (int64_t)H * W, n_pix_entries = (int64_t)n_class * n_px, total = n_pix_entries + n_black;
+  if (total >= (1ll << 31)) return rhccq_fail(ctx, RHCCQ_E_LIMIT, "job_sort_unique: more than 2^31 (pixel, class) entries");
+  if (tmp_bytes < rhccq_job_sort_unique_bytes(total)) return rhccq_fail(ctx, RHCCQ_E_ARG, "job_sort_unique: tmp too small");
+  int jb = 1;
+  while ((1ll << jb) < n_jobs) ++jb;
+  const int invalid_shift = 24 + jb;                      // valid keys are < 2^(24 + jb)
+  char* base = (char*)tmp;
+  unsigned long long* k0 = (unsigned long long*)base; base += k1_align(8 * (size_t)total);
+  unsigned long long* k1 = (unsigned long long*)base; base += k1_align(8 * (size_t)total);
+  uint32_t* v0 = (uint32_t*)base; base += k1_align(4 * (size_t)total);
+  uint32_t* v1 = (uint32_t*)base; base += k1_align(4 * (size_t)total);
+  uint32_t* heads = (uint32_t*)base; base += k1_align(4 * (size_t)total);
+  uint32_t* uidx = (uint32_t*)base; base += k1_align(4 * (size_t)total);
+  void* cub_tmp = (void*)base;
+  size_t cub_avail = (size_t)tmp_bytes - (size_t)(base - (char*)tmp);
+  const unsigned grid = (unsigned)((total + 255) / 256);
+  hipLaunchKernelGGL(sort_keys_kernel, dim3(stream_grid(total, 256)), dim3(256), 0, ctx->stream, rgb, H, W, ca, fix_key, black_jobs, n_black, invalid_shift, k0, v0);
+  hipcub::DoubleBuffer<unsigned long long> kb(k0, k1);
+  hipcub::DoubleBuffer<uint32_t> vb(v0, v1);
+  size_t need = 0;
+  RHCCQ_HIP(ctx, hipcub::DeviceRadixSort::SortPairs(nullptr, need, kb, vb, (int)total, 0, invalid_shift + 1, ctx->stream));
+  if (need > cub_avail) return rhccq_fail(ctx, RHCCQ_E_LIMIT, "job_sort_unique: sort scratch exceeds tmp");
+  RHCCQ_HIP(ctx, hipcub::DeviceRadixSort::SortPairs(cub_tmp, need, kb, vb, (int)total, 0, invalid_shift + 1, ctx->stream));
+  const unsigned long long* ks = kb.Current();
+  const uint32_t* vs = vb.Current();
+  hipLaunchKernelGGL(sort_heads_kernel, dim3(grid), dim3(256), 0, ctx->stream, ks, total, invalid_shift, heads);
+  size_t need2 = 0;
+  RHCCQ_HIP(ctx, hipcub::DeviceScan::ExclusiveSum(nullptr, need2, heads, uidx, (int)total, ctx->stream));
+  if (need2 > cub_avail) return rhccq_fail(ctx, RHCCQ_E_LIMIT, "job_sort_unique: scan scratch exceeds tmp");
+  RHCCQ_HIP(ctx, hipcub::DeviceScan::ExclusiveSum(cub_tmp, need2, heads, uidx, (int)total, ctx->stream));
+  RHCCQ_HIP(ctx, hipMemsetAsync(job_start, 0xff, sizeof(int32_t) * (size_t)n_jobs, ctx->stream));       // -1: the job has no colour
+  hipLaunchKernelGGL(sort_emit_kernel, dim3(grid), dim3(256), 0, ctx->stream, ks, heads, uidx, total, invalid_shift, job_start, keys_out, n_unique);
+  hipLaunchKernelGGL(sort_ranks_kernel, dim3(grid), dim3(256), 0, ctx->stream, ks, vs, heads, uidx, total, n_pix_entries, invalid_shift, job_start, rankmap);
+  RHCCQ_LAUNCH_CHECK(ctx);
+  return 0;
+}
+
+static int frame_remap_impl(rhccq_ctx* ctx, const uint8_t* rgb, int32_t H, int32_t W, int32_t n_class,
+                            const int32_t* const* labels_host, const int32_t* job_base_host, const uint32_t* bitmaps,
+                            const uint32_t* word_prefix, const int64_t* pal_off, const uint32_t* fix_key, const int32_t* lut,
+                            const int32_t* lut2, int32_t default_index, void* out, int32_t out_elem_bytes, const int32_t* rankmap);
 
 int rhccq_frame_remap(rhccq_ctx* ctx, const uint8_t* rgb, int32_t H, int32_t W, int32_t n_class,
                       const int32_t* const* labels_host, const int32_t* job_base_host, const uint32_t* bitmaps,
@@ -517,14 +682,30 @@ int rhccq_frame_remap(rhccq_ctx* ctx, const uint8_t* rgb, int32_t H, int32_t W, 
                       const int32_t* lut2, int32_t default_index, void* out, int32_t out_elem_bytes) {
   if (!ctx || !rgb || !bitmaps || !word_prefix || !pal_off || !lut || !out || H <= 0 || W <= 0)
     return rhccq_fail(ctx, RHCCQ_E_ARG, "frame_remap: bad argument");
+  return frame_remap_impl(ctx, rgb, H, W, n_class, labels_host, job_base_host, bitmaps, word_prefix, pal_off, fix_key, lut, lut2, default_index, out,
+                          out_elem_bytes, nullptr);
+}
+
+int rhccq_frame_remap_ranked(rhccq_ctx* ctx, int32_t H, int32_t W, int32_t n_class, const int32_t* const* labels_host, const int32_t* job_base_host,
+                             const int32_t* rankmap, const int64_t* pal_off, const int32_t* lut, const int32_t* lut2, int32_t default_index, void* out,
+                             int32_t out_elem_bytes) {
+  if (!ctx || !rankmap || !pal_off || !lut || !out || H <= 0 || W <= 0) return rhccq_fail(ctx, RHCCQ_E_ARG, "frame_remap_ranked: bad argument");
+  return frame_remap_impl(ctx, (const uint8_t*)rankmap, H, W, n_class, labels_host, job_base_host, nullptr, nullptr, pal_off, nullptr, lut, lut2,
+                          default_index, out, out_elem_bytes, rankmap);
+}
+
+static int frame_remap_impl(rhccq_ctx* ctx, const uint8_t* rgb, int32_t H, int32_t W, int32_t n_class,
+                            const int32_t* const* labels_host, const int32_t* job_base_host, const uint32_t* bitmaps,
+                            const uint32_t* word_prefix, const int64_t* pal_off, const uint32_t* fix_key, const int32_t* lut,
+                            const int32_t* lut2, int32_t default_index, void* out, int32_t out_elem_bytes, const int32_t* rankmap) {
   ClassArgs ca;
   if (int e = make_class_args(ctx, n_class, labels_host, job_base_host, &ca)) return e;
   const int64_t quads = ((int64_t)H * W + 3) / 4;
   const dim3 grid(stream_grid(quads, 256)), block(256);
   switch (out_elem_bytes) {
-    case 1: hipLaunchKernelGGL(frame_remap_kernel<uint8_t>, grid, block, 0, ctx->stream, rgb, H, W, ca, bitmaps, word_prefix, pal_off, fix_key, lut, lut2, default_index, (uint8_t*)out); break;
-    case 2: hipLaunchKernelGGL(frame_remap_kernel<uint16_t>, grid, block, 0, ctx->stream, rgb, H, W, ca, bitmaps, word_prefix, pal_off, fix_key, lut, lut2, default_index, (uint16_t*)out); break;
-    case 4: hipLaunchKernelGGL(frame_remap_kernel<int32_t>, grid, block, 0, ctx->stream, rgb, H, W, ca, bitmaps, word_prefix, pal_off, fix_key, lut, lut2, default_index, (int32_t*)out); break;
+    case 1: hipLaunchKernelGGL(frame_remap_kernel<uint8_t>, grid, block, 0, ctx->stream, rgb, H, W, ca, bitmaps, word_prefix, pal_off, fix_key, lut, lut2, default_index, (uint8_t*)out, rankmap); break;
+    case 2: hipLaunchKernelGGL(frame_remap_kernel<uint16_t>, grid, block, 0, ctx->stream, rgb, H, W, ca, bitmaps, word_prefix, pal_off, fix_key, lut, lut2, default_index, (uint16_t*)out, rankmap); break;
+    case 4: hipLaunchKernelGGL(frame_remap_kernel<int32_t>, grid, block, 0, ctx->stream, rgb, H, W, ca, bitmaps, word_prefix, pal_off, fix_key, lut, lut2, default_index, (int32_t*)out, rankmap); break;
     default: return rhccq_fail(ctx, RHCCQ_E_ARG, "frame_remap: out_elem_bytes must be 1, 2 or 4");
   }
   RHCCQ_LAUNCH_CHECK(ctx);

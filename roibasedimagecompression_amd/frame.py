@@ -128,12 +128,30 @@ class FrameEncoder:
         (INT_MAX where an entry has no pixel).  The tiled (multi-GPU) encoder overrides this."""
         return self.first_positions_dev(S, fp_lut, n_entries).cpu().numpy().astype(np.int64)
 
+    SORT_UNIQUE_MIN_JOBS = 2048   # beyond: unique colours by a device sort (rhccq_job_sort_unique) instead of 6 MiB of bitmap tables per job
+
+    def _first_pos_pass(self, rh, S, fp, fp_lut, ci=None):
+        """one pass over the pixels (of class `ci`, or of all classes): atomicMin of the raster position into fp[fp_lut[(job, rank)]]"""
+        labels = S["labels"] if ci is None else S["labels"][ci:ci + 1]
+        job_base = S["job_base"][:-1] if ci is None else S["job_base"][ci:ci + 1]
+        if S.get("rankmap") is not None:
+            rm = S["rankmap"] if ci is None else S["rankmap"][ci:ci + 1]
+            rh.job_index_ranked(S["H"], S["W"], labels, job_base, rm, S["d_pal_off"], fp, fp_lut)
+        else:
+            rh.job_index(S["rgb"], labels, job_base, S["bitmaps"], S["prefix"], S["d_pal_off"], S["fix_key"], want_idx=False, first_pos=fp, fp_lut=fp_lut)
+
+    def _remap_pass(self, S, lut1, default_index, out_dtype, d_lut2):
+        rh = self.rh
+        if S.get("rankmap") is not None:
+            return rh.frame_remap_ranked(S["H"], S["W"], S["labels"], S["job_base"][:-1], S["rankmap"], S["d_pal_off"], lut1, default_index, out_dtype, lut2=d_lut2)
+        return rh.frame_remap(S["rgb"], S["labels"], S["job_base"][:-1], S["bitmaps"], S["prefix"], S["d_pal_off"], S["fix_key"], lut1, default_index,
+                              out_dtype, lut2=d_lut2)
+
     def first_positions_dev(self, S, fp_lut, n_entries):
         """the same as a device tensor (int32[n_entries], positions in THIS encoder's pixel raster)"""
         rh = self.rh
         fp = torch.full((max(n_entries, 1),), INT_MAX, dtype=torch.int32, device=rh.device)
-        rh.job_index(S["rgb"], S["labels"], S["job_base"][:-1], S["bitmaps"], S["prefix"], S["d_pal_off"], S["fix_key"],
-                     want_idx=False, first_pos=fp, fp_lut=fp_lut)
+        self._first_pos_pass(rh, S, fp, fp_lut)
         return fp[:n_entries]
 
     # ------------------------------------------------------------------------------------------
@@ -149,8 +167,14 @@ class FrameEncoder:
         if n_jobs == 0:
             raise ValueError("no segments")
         t0 = time.perf_counter()
-        bitmaps, stats = rh.new_job_state(n_jobs)
-        rh.job_scan(rgb, labels, job_base[:-1], bitmaps, stats, black_is_colour=False)
+        # frames cut into very many segments: 6 MiB of bitmap tables per job stops fitting; one device sort of (job, colour) keys
+        # bounds the memory by the pixel count instead (the rank of every pixel's colour is then STORED, not recomputed)
+        sort_path = n_jobs > self.SORT_UNIQUE_MIN_JOBS
+        if sort_path:
+            bitmaps, stats = None, rh.job_stats(rgb, labels, job_base[:-1], n_jobs)
+        else:
+            bitmaps, stats = rh.new_job_state(n_jobs)
+            rh.job_scan(rgb, labels, job_base[:-1], bitmaps, stats, black_is_colour=False)
         st = stats.cpu().numpy().astype(np.int64)
         self._t("scan", t0)
         t0 = time.perf_counter()
@@ -177,15 +201,23 @@ class FrameEncoder:
             fk = ((px[:, 0] << 16) | (px[:, 1] << 8) | px[:, 2]).astype(np.uint32)
             fk[~needs_fix] = 0
             fix_key = rh.dev(fk.view(np.int32))
-        rh.job_set_black(bitmaps, np.nonzero(has_bg | all_black)[0])
-        chunk, counts = rh.bitmap_count(bitmaps)
-        P = counts.cpu().numpy().astype(np.int64)
-        pal_off = np.concatenate([[0], np.cumsum(P)]).astype(np.int64)
-        d_pal_off = rh.dev(pal_off[:-1].copy())
-        total = int(pal_off[-1])
-        prefix, keys_dev = rh.bitmap_emit(bitmaps, chunk, d_pal_off, total)
+        rankmap = None
+        if sort_path:
+            P, keys_dev, rankmap = rh.job_sort_unique(rgb, labels, job_base[:-1], n_jobs, fix_key, np.nonzero(has_bg | all_black)[0])
+            pal_off = np.concatenate([[0], np.cumsum(P)]).astype(np.int64)
+            d_pal_off = rh.dev(pal_off[:-1].copy())
+            total = int(pal_off[-1])
+            prefix = None
+        else:
+            rh.job_set_black(bitmaps, np.nonzero(has_bg | all_black)[0])
+            chunk, counts = rh.bitmap_count(bitmaps)
+            P = counts.cpu().numpy().astype(np.int64)
+            pal_off = np.concatenate([[0], np.cumsum(P)]).astype(np.int64)
+            d_pal_off = rh.dev(pal_off[:-1].copy())
+            total = int(pal_off[-1])
+            prefix, keys_dev = rh.bitmap_emit(bitmaps, chunk, d_pal_off, total)
         self._t("unique", t0)
-        return {"H": H, "W": W, "rgb": rgb, "classes": classes, "labels": labels, "job_base": job_base, "n_jobs": n_jobs,
+        return {"H": H, "W": W, "rgb": rgb, "classes": classes, "labels": labels, "job_base": job_base, "n_jobs": n_jobs, "rankmap": rankmap,
                 "bitmaps": bitmaps, "prefix": prefix, "pal_off": pal_off, "d_pal_off": d_pal_off, "fix_key": fix_key,
                 "keys_dev": keys_dev, "has_black": has_bg | all_black, "P": P, "present": present, "job_class": job_class,
                 "job_region": job_region, "crop": (r0, r1, c0, c1), "total": total}
@@ -333,8 +365,7 @@ class FrameEncoder:
         d_lut2 = rh.dev(lut2)
         self._t("compose", t0)
         t0 = time.perf_counter()
-        out = rh.frame_remap(S["rgb"], S["labels"], S["job_base"][:-1], S["bitmaps"], S["prefix"], S["d_pal_off"], S["fix_key"], S["lut1"],
-                             default_index, out_dtype, lut2=d_lut2)
+        out = self._remap_pass(S, S["lut1"], default_index, out_dtype, d_lut2)
         self._t("remap", t0, sync=profile)
         result = {"palette": unpack_rgb(fk3), "indices": out, "indices_dtype": dtype_name,
                   "shape": (H, W) if multi else tuple(m3c.shape), "top_left": (0, 0) if multi else tuple(m3c.top_left),
@@ -378,8 +409,7 @@ class FrameEncoder:
                 lut1[pal_off[j]:pal_off[j + 1]] = rhc.dev((new_off[i] + mp).astype(np.int32))
         k1_off = {int(j): (int(new_off[i]), int(new_off[i + 1])) for i, j in enumerate(job_ids)}
         # first raster position of every clustered entry of THIS class: one pass over the class's label map
-        rhc.job_index(S["rgb"], S["labels"][ci:ci + 1], S["job_base"][ci:ci + 1], S["bitmaps"], S["prefix"], S["d_pal_off"], S["fix_key"],
-                      want_idx=False, first_pos=fp_all, fp_lut=lut1)
+        self._first_pos_pass(rhc, S, fp_all, lut1, ci)
         lo, hi = int(new_off[0]), int(new_off[-1])
         fp_new = fp_all[lo:hi].cpu().numpy().astype(np.int64) if hi > lo else np.zeros(0, np.int64)
         mark("first_positions")
@@ -541,8 +571,7 @@ class FrameEncoder:
         if not comp.merged:
             blk = np.nonzero(comp.keys == 0)[0]
             default = int(blk[0]) if len(blk) else 0
-        full = rh.frame_remap(S["rgb"], S["labels"], S["job_base"][:-1], S["bitmaps"], S["prefix"], S["d_pal_off"], S["fix_key"],
-                              S["lut1"], default, torch.int32, lut2=rh.dev(lut2))
+        full = self._remap_pass(S, S["lut1"], default, torch.int32, rh.dev(lut2))
         r, c = comp.top_left
         h, w = comp.shape
         return full[r:r + h, c:c + w].contiguous()

@@ -317,6 +317,49 @@ class Rhccq:
         self._check(self.lib.rhccq_job_blackfix(self.ctx, self._p(rgb), H, W, n, ptrs, bases, self._p(needs_fix), self._p(best)),
                     "job_blackfix")
 
+    # -- many-segment frames: unique colours by one device sort (rhccq_job_sort_unique) ------------------------------
+    def job_stats(self, rgb, labels, job_base, n_jobs):
+        H, W = rgb.shape[0], rgb.shape[1]
+        n, ptrs, bases = self._class_args(labels, job_base)
+        stats = torch.tensor([INT_MAX, -1, INT_MAX, -1, 0, 0], dtype=torch.int32, device=self.device).repeat(n_jobs, 1).contiguous()
+        self._check(self.lib.rhccq_job_stats(self.ctx, self._p(rgb), H, W, n, ptrs, bases, self._p(stats)), "job_stats")
+        return stats
+
+    def job_sort_unique(self, rgb, labels, job_base, n_jobs, fix_key, black_jobs):
+        """-> (P np.int64[n_jobs] palette sizes, keys int32[sum P] device (sorted per job, job order), rankmap int32[n_class, H*W] device)"""
+        H, W = int(rgb.shape[0]), int(rgb.shape[1])
+        n, ptrs, bases = self._class_args(labels, job_base)
+        bj = self.dev(np.asarray(black_jobs, dtype=np.int32)) if len(black_jobs) else None
+        total = n * H * W + len(black_jobs)
+        tb = int(self.lib.rhccq_job_sort_unique_bytes(total))
+        tmp = self.empty((tb,), torch.uint8)
+        rankmap = self.empty((n, H * W), torch.int32)
+        keys = self.empty((total,), torch.int32)
+        start = self.empty((n_jobs,), torch.int32)
+        nu = self.empty((1,), torch.int32)
+        self._check(self.lib.rhccq_job_sort_unique(self.ctx, self._p(rgb), H, W, n, ptrs, bases, int(n_jobs), self._p(fix_key), self._p(bj), len(black_jobs),
+                                                   self._p(tmp), tb, self._p(rankmap), self._p(keys), self._p(start), self._p(nu)), "job_sort_unique")
+        st = start.cpu().numpy().astype(np.int64)
+        n_unique = int(nu.cpu()[0])
+        # palette sizes: the distance to the next job that has colours
+        nxt = np.full(n_jobs + 1, n_unique, np.int64)
+        for j in range(n_jobs - 1, -1, -1):
+            nxt[j] = st[j] if st[j] >= 0 else nxt[j + 1]
+        P = np.where(st >= 0, nxt[1:] - st, 0).astype(np.int64)
+        return P, keys[:max(n_unique, 1)], rankmap
+
+    def job_index_ranked(self, H, W, labels, job_base, rankmap, pal_off, first_pos, fp_lut):
+        n, ptrs, bases = self._class_args(labels, job_base)
+        self._check(self.lib.rhccq_job_index_ranked(self.ctx, int(H), int(W), n, ptrs, bases, self._p(rankmap), self._p(pal_off), self._p(first_pos),
+                                                    self._p(fp_lut)), "job_index_ranked")
+
+    def frame_remap_ranked(self, H, W, labels, job_base, rankmap, pal_off, lut, default_index, out_dtype, lut2=None):
+        n, ptrs, bases = self._class_args(labels, job_base)
+        out = self.empty((int(H), int(W)), out_dtype)
+        self._check(self.lib.rhccq_frame_remap_ranked(self.ctx, int(H), int(W), n, ptrs, bases, self._p(rankmap), self._p(pal_off), self._p(lut), self._p(lut2),
+                                                      int(default_index), self._p(out), out.element_size()), "frame_remap_ranked")
+        return out
+
     def job_index(self, rgb, labels, job_base, bitmaps, prefix, pal_off, fix_key=None, want_idx=True, first_pos=None, fp_lut=None):
         H, W = rgb.shape[0], rgb.shape[1]
         n, ptrs, bases = self._class_args(labels, job_base)

@@ -222,3 +222,70 @@ def test_frame_fuzz_vs_oracle(rh, seed):
     assert np.array_equal(out["palette"], np.asarray(fin["palette"]).reshape(-1, 3)), (seed, H, W, tiles, q)
     assert np.array_equal(indices_np(out).reshape(-1), np.asarray(fin["indices"]).reshape(-1)), (seed, H, W, tiles, q)
     assert out["indices_dtype"] == fin["indices_dtype"]
+
+
+@pytest.mark.parametrize("seed", range(12))
+def test_sort_based_unique_path_equals_bitmap_path_and_oracle(rh, seed):
+    """Frames cut into very many segments take their unique colours from ONE device sort of (job, colour) keys and keep the rank of
+    every pixel's colour (rhccq_job_sort_unique, rhccq_job_index_ranked, rhccq_frame_remap_ranked) instead of 6 MiB of bitmap tables
+    per job.  Forced here on the fuzz generator's frames (black patches -> recoloured in-mask black and all-black segments, crops
+    that show background, one or two tiers, single class): palette and every index equal the bitmap path's and the oracle's."""
+    import torch
+    from oracle import rhccq_oracle as O
+    from roibasedimagecompression_amd import synth
+    from roibasedimagecompression_amd.frame import FrameEncoder
+    rng = np.random.default_rng(7000 + seed)
+    H, W = int(rng.integers(40, 150)), int(rng.integers(40, 170))
+    img = (synth.photo(H, W, 900 + seed, sigma=float(rng.choice([0.0, 2.0, 6.0]))) if rng.random() < 0.7 else synth.poster(H, W, 900 + seed)).copy()
+    for _ in range(int(rng.integers(1, 4))):
+        y0, x0 = int(rng.integers(0, H - 8)), int(rng.integers(0, W - 8))
+        img[y0:y0 + int(rng.integers(1, 8)), x0:x0 + int(rng.integers(1, 8))] = 0
+    tiles = (int(rng.integers(1, 7)), int(rng.integers(1, 7)))
+    (lr, nr, _), (ln, nn, _) = synth.frame_classes(H, W, tiles)
+    q = [int(rng.choice([10, 20, 50])), int(rng.choice([5, 10, 20]))]
+    labs = [lr, ln]
+    if seed % 5 == 4:
+        labs, q = [np.where((lr > 0) | (ln > 0), np.maximum(lr, ln), 0).astype(np.int32)], q[:1]
+    specs, oc = specs_from_labels(rh, labs, q)
+    rgb = torch.from_numpy(img).to(rh.device)
+    a = FrameEncoder(rh).encode(rgb, specs)
+    enc = FrameEncoder(rh)
+    enc.SORT_UNIQUE_MIN_JOBS = 0                             # every frame through the sort
+    b = enc.encode(rgb, specs)
+    assert np.array_equal(a["palette"], b["palette"]) and torch.equal(a["indices"], b["indices"]) and a["indices_dtype"] == b["indices_dtype"], (seed, tiles)
+    assert np.array_equal(a["n_unique"], b["n_unique"])
+    fin = O.encode_frame(img, oc, q)["final"]
+    assert np.array_equal(b["palette"], np.asarray(fin["palette"]).reshape(-1, 3)) and np.array_equal(indices_np(b).reshape(-1), np.asarray(fin["indices"]).reshape(-1))
+
+
+def test_fine_grid_4k_frame_through_the_sort_path(rh):
+    """A 3840x2160 frame cut into a 60 x 64 grid (thousands of jobs at 6 MiB of bitmap tables each; one 0.4 GB sort instead): the default
+    encoder switches to the sort path by itself; size-independent properties (determinism, indices inside the palette, every entry
+    used, PSNR) and, on a 1080p frame with 1 536 jobs where both paths fit comfortably, equality with the bitmap path."""
+    import torch
+    from roibasedimagecompression_amd import synth
+    from roibasedimagecompression_amd.frame import ClassSpec, FrameEncoder
+
+    def frame(H, W, seed, tiles):
+        img = synth.photo(H, W, seed)
+        (lr, nr, br), (ln, nn, bn) = synth.frame_classes(H, W, tiles)
+        specs = [ClassSpec(torch.from_numpy(lr).to(rh.device), np.zeros(nr, np.int64), [br], 20),
+                 ClassSpec(torch.from_numpy(ln).to(rh.device), np.zeros(nn, np.int64), [bn], 10)]
+        return img, torch.from_numpy(img).to(rh.device), specs
+    img, rgb, specs = frame(1080, 1920, 31, (24, 32))
+    assert sum(sp.n_seg for sp in specs) <= FrameEncoder.SORT_UNIQUE_MIN_JOBS
+    a = FrameEncoder(rh).encode(rgb, specs)
+    enc = FrameEncoder(rh)
+    enc.SORT_UNIQUE_MIN_JOBS = 0
+    b = enc.encode(rgb, specs)
+    assert np.array_equal(a["palette"], b["palette"]) and torch.equal(a["indices"], b["indices"])
+    img, rgb, specs = frame(2160, 3840, 32, (60, 64))
+    assert sum(sp.n_seg for sp in specs) > FrameEncoder.SORT_UNIQUE_MIN_JOBS
+    enc = FrameEncoder(rh)
+    o1 = enc.encode(rgb, specs)
+    o2 = enc.encode(rgb, specs)
+    assert np.array_equal(o1["palette"], o2["palette"]) and torch.equal(o1["indices"], o2["indices"])
+    pal, idx = np.asarray(o1["palette"]), indices_np(o1).reshape(2160, 3840)
+    assert idx.min() >= 0 and idx.max() < len(pal) and (np.bincount(idx.ravel(), minlength=len(pal))[1:] > 0).all()
+    err = pal[idx].astype(np.float64) - img
+    assert 10 * np.log10(255.0 ** 2 / np.mean(err ** 2)) > 26.0
