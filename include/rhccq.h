@@ -216,7 +216,7 @@ int rhccq_mbk_init(rhccq_ctx* ctx, const uint32_t* keys, const rhccq_mbk_problem
  * with the number of steps launched so far; all problems of a call sequence share the step index).  state:
  * double[n_prob][16] = {[0] ewa, [1] ewa_min, [2] no_improvement, [3] samples since the last reassignment, [4] why the
  * problem stopped (0 running, 1 converged, 2 out of steps, 3 word table exhausted -- fatal: size `words` so that it
- * cannot happen), [5] steps done, [6] have_ewa, [7] have_min, [8] zero-weight centres (initialise to k), [9] MT cursor
+ * cannot happen; 4 sharded chain hand-off lost; 5 overlapped schedule diverged), [5] steps done, [6] have_ewa, [7] have_min, [8] zero-weight centres (initialise to k), [9] MT cursor
  * = raw words consumed so far (initialise to the position behind the k-means++ uniforms), [10] first batch drawn, [11]
  * stop_at (steps done when it stopped, 0 while running), [12..14] the odd-step twins of [3], [8], [9] (a step reads the
  * slots of its parity and writes the other's; after s steps the current values sit in the slots of parity s & 1)};
@@ -236,6 +236,20 @@ int rhccq_mbk_steps(rhccq_ctx* ctx, const uint32_t* keys, const rhccq_mbk_proble
 #define RHCCQ_ESTEP_TILES 1
 #define RHCCQ_ESTEP_GRID 2
 int64_t rhccq_mbk_work_bytes(const rhccq_mbk_problem* probs_host, int32_t n_prob);
+/* The same steps for ONE problem (n_prob == 1) that has no zero-weight centre left (state[8] / [13] == 0), with the batch
+ * E-step of step t + 1 started BESIDE the update of step t: a step that does not reassign changes only the <= 1000 centres its
+ * batch touched, so the next batch is first compared with every untouched centre (same launch as the update) and then with
+ * the touched ones at their new values -- the same distances and the same first arg-min, off the chain of dependent
+ * launches (a 4K frame ends in one problem that runs all its ~2000 steps: sklearn MiniBatchKMeans.fit,
+ * clustering.py:207-218).  since0: "samples since the last reassignment" as step0 sees it (state[3] for an even step0,
+ * state[12] for an odd one): the host derives from it which steps reassign (those run the classic E-step); a device state
+ * that disagrees stops the problem with state[4] = 5.  *carry: in/out, 0 before the first call and after any rhccq_mbk_steps
+ * call; bit 0 = the batch of step0 + 1 is drawn, bit 1 = the speculative tile minima of step0 are in `work`.  A step may
+ * draw one batch ahead: size `words` for n_steps + 3 steps.  State, work and results as rhccq_mbk_steps (bit-identical). */
+int rhccq_mbk_steps_overlapped(rhccq_ctx* ctx, const uint32_t* keys, const rhccq_mbk_problem* probs_host,
+                               int32_t n_prob, int64_t step0, int32_t n_steps, const uint32_t* words, int64_t n_words,
+                               double* centres, double* weights, double* state, void* work, int64_t work_bytes,
+                               int32_t estep_split, int64_t since0, int32_t* carry);
 /* final E-step over all points: labels_out int32 at the key offsets (first arg-min of
  * csq_j + (-2 * dot), brute force order-independent; uses a centre grid for pruning) */
 int rhccq_mbk_assign(rhccq_ctx* ctx, const uint32_t* keys, const rhccq_mbk_problem* probs_host,

@@ -24,6 +24,8 @@
 //          exact) tiled through LDS; float64 VALU bound (K = 3 is not an MFMA shape).
 #include <hipcub/hipcub.hpp>
 
+#include <vector>
+
 #include "rhccq_common.h"
 
 namespace rhccq {
@@ -1446,44 +1448,43 @@ __global__ __launch_bounds__(64) void mbk_inertia_kernel(const MbkP* __restrict_
 // centres (one wave per SIMD, ~8 cycles per dependent f64 instruction) is the whole step; splitting the walk keeps
 // the arithmetic and the first-arg-min order (lower slices win ties) and shortens the chain.
 template <int kSplit>
-__global__ __launch_bounds__(256) void mbk_batch_estep_kernel(const uint32_t* __restrict__ keys, const MbkP* __restrict__ probs,
-                                                              const double* __restrict__ centres, double* __restrict__ state,
-                                                              long long step, const uint32_t* __restrict__ bkeys, double* __restrict__ pdist,
-                                                              int32_t* __restrict__ pidx, const long long* __restrict__ part_off,
-                                                              const double* __restrict__ pper_prev) {
+__device__ __forceinline__ void estep_tile(const int bx, const int p, const MbkP& P, const long long po, const double* __restrict__ centres,
+                                           const uint32_t* __restrict__ bkeys, double* __restrict__ pdist, int32_t* __restrict__ pidx,
+                                           const int32_t* __restrict__ excl_labels, double* sc, double* s_bd, int* s_bj) {
   // a thread owns TWO batch rows and one slice of the tile's centres: every centre it reads from LDS (a broadcast read, and
   // with four workgroups per CU the LDS pipe was the limit) serves two distance evaluations
   constexpr int kT = 256 / kSplit, kPts = 2 * kT, kSlice = kTileC / kSplit;
-  const int p = blockIdx.y;
-  const MbkP P = probs[p];                               // independent table reads, issued together
-  const long long po = part_off[p];
-  __shared__ double sc[kTileC * 4];
-  if (blockIdx.x == gridDim.x - 1) {                     // the extra workgroup: inertia + EWA rule of the PREVIOUS step
-    if (pper_prev != nullptr && !mbk_stopped(state + p * 16, step - 1, P.n))
-      mbk_inertia_block(P, state + p * 16, step - 1, pper_prev + (size_t)p * kBatch, sc);
-    return;
-  }
-  if (mbk_stopped(state + p * 16, step, P.n)) return;
   const int n_tiles = (int)((P.k + kTileC - 1) / kTileC);
-  const int tile = blockIdx.x / (kPtChunks * kSplit), chunk = blockIdx.x % (kPtChunks * kSplit);
+  const int tile = bx / (kPtChunks * kSplit), chunk = bx % (kPtChunks * kSplit);
   if (tile >= n_tiles) return;
   const int bs = (int)min((long long)1000, P.n);
-  __shared__ double s_bd[kSplit > 1 ? 512 : 1];
-  __shared__ int s_bj[kSplit > 1 ? 512 : 1];
   const int j0 = tile * kTileC, nj = (int)min((long long)kTileC, P.k - j0);
+  int ex[kBatch / 256];                                  // (requested together with the tile)
+  if (excl_labels != nullptr) {
+#pragma unroll
+    for (int q = 0; q < kBatch / 256; ++q) ex[q] = (int)threadIdx.x + q * 256 < bs ? excl_labels[threadIdx.x + q * 256] - j0 : -1;
+  }
   for (int i = threadIdx.x; i < nj * 4; i += blockDim.x) {
     const double v = centres[(P.koff + j0) * 4 + i];
     sc[i] = (i & 3) == 3 ? v : -2.0 * v;               // pre-scale by -2 (exact): dist = csq + dot'
   }
   __syncthreads();
+  if (excl_labels != nullptr) {
+    // speculative E-step (k8_overlap.h): the centres these labels name are being rewritten by the update that runs beside this
+    // launch -- distance +inf, they are compared at their new values by the next launch
+#pragma unroll
+    for (int q = 0; q < kBatch / 256; ++q)
+      if (ex[q] >= 0 && ex[q] < nj) sc[ex[q] * 4 + 3] = INFINITY;
+    __syncthreads();
+  }
   double* pd = pdist + po + (size_t)tile * kBatch;
   int32_t* pi = pidx + po + (size_t)tile * kBatch;
   const int pt = threadIdx.x % kT, slice = threadIdx.x / kT;
   const int b0 = chunk * kPts + pt, b1 = b0 + kT;
   double bd0 = INFINITY, bd1 = INFINITY;
-  int bj0 = 0x7fffffff, bj1 = 0x7fffffff;
+  int bj0 = excl_labels != nullptr ? 0 : 0x7fffffff, bj1 = bj0;      // (a tile whose centres are all excluded reports +inf)
   if (b0 < bs) {
-    const uint32_t k0 = bkeys[(size_t)p * kBatch + b0], k1 = bkeys[(size_t)p * kBatch + min(b1, bs - 1)];   // rows drawn by the previous update
+    const uint32_t k0 = bkeys[(size_t)p * kBatch + b0], k1 = bkeys[(size_t)p * kBatch + min(b1, bs - 1)];   // rows drawn by an earlier update
     const double x0 = (double)key_r(k0), x1 = (double)key_g(k0), x2 = (double)key_b(k0);
     const double y0 = (double)key_r(k1), y1 = (double)key_g(k1), y2 = (double)key_b(k1);
     const int ja = slice * kSlice, jb = min(ja + kSlice, nj);
@@ -1512,6 +1513,27 @@ __global__ __launch_bounds__(256) void mbk_batch_estep_kernel(const uint32_t* __
     if (b0 < bs) { pd[b0] = bd0; pi[b0] = j0 + bj0; }
     if (b1 < bs) { pd[b1] = bd1; pi[b1] = j0 + bj1; }
   }
+}
+
+template <int kSplit>
+__global__ __launch_bounds__(256) void mbk_batch_estep_kernel(const uint32_t* __restrict__ keys, const MbkP* __restrict__ probs,
+                                                              const double* __restrict__ centres, double* __restrict__ state,
+                                                              long long step, const uint32_t* __restrict__ bkeys, double* __restrict__ pdist,
+                                                              int32_t* __restrict__ pidx, const long long* __restrict__ part_off,
+                                                              const double* __restrict__ pper_prev) {
+  const int p = blockIdx.y;
+  const MbkP P = probs[p];                               // independent table reads, issued together
+  const long long po = part_off[p];
+  __shared__ double sc[kTileC * 4];
+  __shared__ double s_bd[kSplit > 1 ? 512 : 1];
+  __shared__ int s_bj[kSplit > 1 ? 512 : 1];
+  if (blockIdx.x == gridDim.x - 1) {                     // the extra workgroup: inertia + EWA rule of the PREVIOUS step
+    if (pper_prev != nullptr && !mbk_stopped(state + p * 16, step - 1, P.n))
+      mbk_inertia_block(P, state + p * 16, step - 1, pper_prev + (size_t)p * kBatch, sc);
+    return;
+  }
+  if (mbk_stopped(state + p * 16, step, P.n)) return;
+  estep_tile<kSplit>((int)blockIdx.x, p, P, po, centres, bkeys, pdist, pidx, nullptr, sc, s_bd, s_bj);
 }
 
 // Fold of the per-tile partial arg-mins, in tile order (first arg-min), into the slot of tile 0.  One wave per 16
@@ -1630,6 +1652,31 @@ __device__ __forceinline__ bool reassign_sel(double w, double thr, bool capped, 
   return w == sel_w && eq_rank < take;
 }
 
+// a centre with more batch members than its list holds: += x over the batch rows labelled j, in batch order.  Four labels per
+// LDS read, the reads independent of the sums (a row-by-row walk waited ~100 cycles for every one of the 1 000 rows: 27 us)
+__device__ __forceinline__ void walk_members(const int* __restrict__ lab, const uint32_t* __restrict__ bkey, int bs, int j, double& a0,
+                                             double& a1, double& a2) {
+  for (int b = 0; b < bs; b += 16) {
+    int4 l[4];
+#pragma unroll
+    for (int q = 0; q < 4; ++q) l[q] = *reinterpret_cast<const int4*>(lab + b + 4 * q);      // (lab has kBatch entries: rows >= bs hold -1)
+    bool any = false;
+#pragma unroll
+    for (int q = 0; q < 4; ++q) any = any || l[q].x == j || l[q].y == j || l[q].z == j || l[q].w == j;
+    if (!any) continue;
+#pragma unroll
+    for (int q = 0; q < 4; ++q) {
+      const int v[4] = {l[q].x, l[q].y, l[q].z, l[q].w};
+#pragma unroll
+      for (int e = 0; e < 4; ++e) {
+        if (v[e] != j) continue;
+        const uint32_t kk = bkey[b + 4 * q + e];
+        a0 = a0 + (double)key_r(kk); a1 = a1 + (double)key_g(kk); a2 = a2 + (double)key_b(kk);
+      }
+    }
+  }
+}
+
 // ---- numpy's legacy RandomState, replayed from its raw MT19937 words (resident on the device, mt.py) ----------
 // RandomState.randint(0, rng + 1, count) at word `cursor` (_bounded_integers.pyx, legacy use_masked path): candidates
 // `word & mask` (mask = smallest 2^b - 1 >= rng), one word each, kept when <= rng.  All threads of the workgroup:
@@ -1639,14 +1686,14 @@ __device__ __forceinline__ long long replay_randint(const uint32_t* __restrict__
                                                     int count, int* out, int* ired, long long* s_cursor) {
   const int tid = threadIdx.x;
   if (rng == 0u) {                                       // numpy draws nothing for a one-value range
-    for (int i = tid; i < count; i += kUpdThreads) out[i] = 0;
+    for (int i = tid; i < count; i += blockDim.x) out[i] = 0;
     __syncthreads();
     return cursor;
   }
   const uint32_t mask = 0xffffffffu >> __clz(rng);
   int produced = 0;
   while (true) {
-    if (cursor + (long long)kUpdThreads * kDrawWords > n_words) return -1;
+    if (cursor + (long long)blockDim.x * kDrawWords > n_words) return -1;
     const long long base = cursor + (long long)tid * kDrawWords;
     uint32_t v[kDrawWords];
     int cnt = 0;
@@ -1670,7 +1717,7 @@ __device__ __forceinline__ long long replay_randint(const uint32_t* __restrict__
     __syncthreads();
     if (produced + tot >= count) return *s_cursor;
     produced += tot;
-    cursor += (long long)kUpdThreads * kDrawWords;
+    cursor += (long long)blockDim.x * kDrawWords;
   }
 }
 
@@ -1751,7 +1798,7 @@ __device__ __forceinline__ long long draw_batch(const uint32_t* __restrict__ key
   const int bs = (int)min((long long)1000, P.n);
   const long long c = replay_randint(words, n_words, cursor, (unsigned)(P.n - 1), bs, out, ired, s_cursor);
   if (c < 0) return c;
-  for (int b = threadIdx.x; b < bs; b += kUpdThreads) bkeys_p[b] = keys[P.off + out[b]];
+  for (int b = threadIdx.x; b < bs; b += blockDim.x) bkeys_p[b] = keys[P.off + out[b]];
   return c;
 }
 
@@ -1791,19 +1838,29 @@ __device__ unsigned long long g_upd_stamps[16];
 //   role 1  the next step's batch (randint replay + colour gather) whenever this step does not reassign (then the stream
 //           position is known before the step starts).
 // (The third chain, batch inertia + EWA rule, rides in the next step's E-step kernel: mbk_inertia_block.)
-__global__ __launch_bounds__(kUpdThreads) void mbk_update_kernel(const uint32_t* __restrict__ keys, const MbkP* __restrict__ probs,
-                                                                 double* __restrict__ centres, double* __restrict__ weights,
-                                                                 double* __restrict__ state, long long step,
-                                                                 const uint32_t* __restrict__ words, long long n_words,
-                                                                 const uint32_t* __restrict__ bkeys_cur, uint32_t* __restrict__ bkeys_next,
-                                                                 const int32_t* __restrict__ pidx, const long long* __restrict__ part_off) {
-  __shared__ UpdShared sh;
-  const int p = blockIdx.x, role = blockIdx.y, tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+// Where the draws of a launch go (the batches live in a ring of four buffers, batch b in ring[b & 3]):
+//   role 1 draws the batches draw_first .. draw_first + draw_count - 1 (the classic sequence: the next step's batch; the overlapped
+//   sequence of rhccq_mbk_steps_overlapped runs one batch ahead, so that the NEXT step's E-step can start beside this step's update);
+//   a step that reassigns draws reassign_draws batches behind its choice() itself.
+// expect_reassign >= 0: the host scheduled this launch for a step that does (1) / does not (0) reassign; a device state that
+// disagrees stops the problem with code 5 before anything is modified.
+struct UpdDraws {
+  uint32_t* ring[4];
+  long long draw_first;
+  int draw_count, reassign_draws, expect_reassign, n_prob;
+};
+
+__device__ __forceinline__ void mbk_update_body(UpdShared& sh, const int p, const int role, const uint32_t* __restrict__ keys,
+                                                const MbkP* __restrict__ probs, double* __restrict__ centres, double* __restrict__ weights,
+                                                double* __restrict__ state, long long step, const uint32_t* __restrict__ words, long long n_words,
+                                                const uint32_t* __restrict__ bkeys_cur, const UpdDraws& dr,
+                                                const int32_t* __restrict__ labels_p) {
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
   double* st = state + p * kStateStride;
   // independent table reads issued together: the kernel is a chain of dependent accesses, every cold miss counts
-  const double st_since = st[st_slot(kStSince, step)], st_nzero = st[st_slot(kStNzero, step)], st_cursor = st[st_slot(kStCursor, step)];
+  const double st_since = st[st_slot(kStSince, step)], st_nzero = st[st_slot(kStNzero, step)];
+  const double st_cursor = st[st_slot(kStCursor, role == 1 ? dr.draw_first - 1 : step)];
   const MbkP P = probs[p];
-  const long long po = part_off[p];
   if (mbk_stopped(st, step, P.n)) return;
   const int k = (int)P.k;
   const long long n = P.n;
@@ -1821,13 +1878,22 @@ __global__ __launch_bounds__(kUpdThreads) void mbk_update_kernel(const uint32_t*
 #else
 #define ROLE_END(r) do {} while (0)
 #endif
+  if (dr.expect_reassign >= 0 && (int)do_reassign != dr.expect_reassign) {   // the host's schedule and the device state disagree
+    if (tid == 0) st[4] = 5.0;
+    return;
+  }
   if (role == 1) {
-    // ---- the next step's batch: minibatch_indices = random_state.randint(0, n_samples, batch_size) ------------
+    // ---- the batches ahead: minibatch_indices = random_state.randint(0, n_samples, batch_size) ------------
     if (do_reassign) return;                             // the stream position depends on this step's choice(): role 0 draws
-    const long long c = draw_batch(keys, P, words, n_words, cursor, bkeys_next + (size_t)p * kBatch, sh.lab, sh.ired, &sh.cursor);
+    for (int q = 0; q < dr.draw_count; ++q) {
+      const long long b = dr.draw_first + q;
+      cursor = draw_batch(keys, P, words, n_words, cursor, dr.ring[b & 3] + (size_t)p * kBatch, sh.lab, sh.ired, &sh.cursor);
+      if (cursor < 0) break;
+      if (tid == 0) st[st_slot(kStCursor, b)] = (double)cursor;
+      __syncthreads();                                   // (sh.lab / sh.cursor are reused by the next draw)
+    }
     if (tid == 0) {
-      if (c < 0) st[4] = 3.0;                            // word table exhausted (the host sizes it so that this cannot happen)
-      else st[st_slot(kStCursor, step + 1)] = (double)c;
+      if (cursor < 0) st[4] = 3.0;                       // word table exhausted (the host sizes it so that this cannot happen)
       ROLE_END(1);
     }
     return;
@@ -1850,11 +1916,13 @@ __global__ __launch_bounds__(kUpdThreads) void mbk_update_kernel(const uint32_t*
   // ---- labels of the batch (the E-step kernels leave the folded arg-min in the slot of tile 0) ------------
   double cb0 = 0.0, cb1 = 0.0, cb2 = 0.0, wb = 0.0;
   if (tid < bs) {
-    const int bj = pidx[po + tid];
+    const int bj = labels_p[tid];
     const uint32_t kk = bkeys_p[tid];
     sh.lab[tid] = bj;
     sh.bkey[tid] = kk;
     cb0 = C[bj * 4]; cb1 = C[bj * 4 + 1]; cb2 = C[bj * 4 + 2]; wb = W[bj];
+  } else {
+    sh.lab[tid] = -1;                                    // (walk_members reads whole groups of 16 rows)
   }
   USTAMP(0);
   __syncthreads();
@@ -1904,11 +1972,7 @@ __global__ __launch_bounds__(kUpdThreads) void mbk_update_kernel(const uint32_t*
           a0 = a0 + (double)key_r(kk); a1 = a1 + (double)key_g(kk); a2 = a2 + (double)key_b(kk);
         }
       } else {                                           // many members (small k): walk the batch
-        for (int b = 0; b < bs; ++b) {
-          if (sh.lab[b] != j) continue;
-          const uint32_t kk = sh.bkey[b];
-          a0 = a0 + (double)key_r(kk); a1 = a1 + (double)key_g(kk); a2 = a2 + (double)key_b(kk);
-        }
+        walk_members(sh.lab, sh.bkey, bs, j, a0, a1, a2);
       }
       const double wn = w + (double)cnt;
       const double alpha = 1.0 / wn;
@@ -2052,19 +2116,37 @@ __global__ __launch_bounds__(kUpdThreads) void mbk_update_kernel(const uint32_t*
   }
   USTAMP(4);
   // ---- a step that reassigned draws the next batch itself (role 2 stood back) -------------------------------------
-  if (do_reassign && cursor >= 0)
-    cursor = draw_batch(keys, P, words, n_words, cursor, bkeys_next + (size_t)p * kBatch, sh.lab, sh.ired, &sh.cursor);
+  if (do_reassign) {
+    for (int q = 0; q < dr.reassign_draws && cursor >= 0; ++q) {
+      const long long b = step + 1 + q;
+      cursor = draw_batch(keys, P, words, n_words, cursor, dr.ring[b & 3] + (size_t)p * kBatch, sh.lab, sh.ired, &sh.cursor);
+      if (cursor >= 0 && tid == 0) st[st_slot(kStCursor, b)] = (double)cursor;
+      __syncthreads();
+    }
+  }
   if (tid == 0) {
     st[st_slot(kStSince, step + 1)] = since;
     if (!do_reassign) st[st_slot(kStNzero, step + 1)] = st_nzero;        // (0: it stays 0)
-    if (do_reassign) {
-      if (cursor < 0) st[4] = 3.0;                       // cannot happen within kWordsMargin
-      else st[st_slot(kStCursor, step + 1)] = (double)cursor;
-    }
+    if (do_reassign && cursor < 0) st[4] = 3.0;          // cannot happen within kWordsMargin
   }
   USTAMP(5);
   if (tid == 0) ROLE_END(0);
 }
+
+__global__ __launch_bounds__(kUpdThreads) void mbk_update_kernel(const uint32_t* __restrict__ keys, const MbkP* __restrict__ probs,
+                                                                 double* __restrict__ centres, double* __restrict__ weights,
+                                                                 double* __restrict__ state, long long step,
+                                                                 const uint32_t* __restrict__ words, long long n_words,
+                                                                 const uint32_t* __restrict__ bkeys_cur, UpdDraws dr,
+                                                                 const int32_t* __restrict__ pidx, const long long* __restrict__ part_off,
+                                                                 const int32_t* __restrict__ lab) {
+  __shared__ UpdShared sh;
+  const int p = blockIdx.x;
+  mbk_update_body(sh, p, (int)blockIdx.y, keys, probs, centres, weights, state, step, words, n_words, bkeys_cur, dr,
+                  lab != nullptr ? lab + (size_t)p * kBatch : pidx + part_off[p]);
+}
+
+#include "k8_overlap.h"
 
 // ------------------------------------------------------------------------------------------------
 // final E-step over all points
@@ -2361,6 +2443,7 @@ int64_t rhccq_mbk_work_bytes(const rhccq_mbk_problem* probs, int32_t n_prob) {
   for (int i = 0; i < n_prob; ++i) ksum += (size_t)probs[i].k;
   bytes += align256((size_t)n_prob * (kGridCells + 1) * 4) + align256((size_t)n_prob * kGridCells * 4) + align256(ksum * 4);
   bytes += 2 * align256((size_t)n_prob * kBatch * 4) + 2 * align256((size_t)n_prob * kBatch * 8);
+  bytes += 4 * align256((size_t)n_prob * kBatch * 4);     // batches 2, 3 of the ring; the labels of even / odd steps
   return (int64_t)bytes;
 }
 
@@ -2373,8 +2456,9 @@ struct WorkView {
   uint32_t* cell_start;   // [n_prob][cells + 1]
   uint32_t* cursor;       // [n_prob][cells] (spare)
   uint32_t* order;        // [sum k] centre indices grouped by cell (problem-relative)
-  uint32_t* bkeys[2];     // [n_prob][1024] colours of the batch rows of even / odd steps (written by the draws)
+  uint32_t* bkeys[4];     // [n_prob][1024] colours of the batch rows of step s in bkeys[s & 3] (written by the draws)
   double* pper[2];        // [n_prob][1024] the rows' inertia terms of even / odd steps (fold kernel -> mbk_inertia_block)
+  int32_t* lab[2];        // [n_prob][1024] labels of even / odd steps (overlapped sequence: mbk_fix_kernel)
   long long max_k;
 };
 
@@ -2418,7 +2502,11 @@ static int layout_work(rhccq_ctx* ctx, const rhccq_mbk_problem* probs, int n_pro
   v->bkeys[0] = (uint32_t*)base; base += align256((size_t)n_prob * kBatch * 4);
   v->bkeys[1] = (uint32_t*)base; base += align256((size_t)n_prob * kBatch * 4);
   v->pper[0] = (double*)base; base += align256((size_t)n_prob * kBatch * 8);
-  v->pper[1] = (double*)base;
+  v->pper[1] = (double*)base; base += align256((size_t)n_prob * kBatch * 8);
+  v->bkeys[2] = (uint32_t*)base; base += align256((size_t)n_prob * kBatch * 4);
+  v->bkeys[3] = (uint32_t*)base; base += align256((size_t)n_prob * kBatch * 4);
+  v->lab[0] = (int32_t*)base; base += align256((size_t)n_prob * kBatch * 4);
+  v->lab[1] = (int32_t*)base;
   v->max_k = 0;
   for (int i = 0; i < n_prob; ++i) v->max_k = probs[i].k > v->max_k ? probs[i].k : v->max_k;
   if (int e = put(ctx, v->probs, hp, sizeof(MbkP) * n_prob)) return e;
@@ -2636,7 +2724,7 @@ int rhccq_mbk_steps(rhccq_ctx* ctx, const uint32_t* keys, const rhccq_mbk_proble
                        v.bkeys[0], centres);
   for (int s = 0; s < n_steps; ++s) {
     const long long step = step0 + s;
-    const uint32_t* bk = v.bkeys[step & 1];
+    const uint32_t* bk = v.bkeys[step & 3];
     // the previous step's inertia terms (none for the first step of this call: the last step of a call has a kernel of its own)
     const double* pprev = s > 0 ? (const double*)v.pper[(step - 1) & 1] : (const double*)nullptr;
     if (use_grid) {
@@ -2659,12 +2747,101 @@ int rhccq_mbk_steps(rhccq_ctx* ctx, const uint32_t* keys, const rhccq_mbk_proble
     // arg-min over the centre tiles (tiled E-step) and every row's inertia term against the centres before the update
     hipLaunchKernelGGL(mbk_fold_tiles_kernel, dim3((1000 + 15) / 16, n_prob), dim3(64), 0, ctx->stream, v.probs, (const double*)state, step,
                        (const double*)centres, bk, v.pdist, v.pidx, v.part_off, v.pper[step & 1], use_grid ? 0 : 1);
+    const UpdDraws dr{{v.bkeys[0], v.bkeys[1], v.bkeys[2], v.bkeys[3]}, step + 1, 1, 1, -1, n_prob};
     hipLaunchKernelGGL(mbk_update_kernel, dim3(n_prob, 2), dim3(kUpdThreads), 0, ctx->stream, keys, v.probs, centres, weights, state, step,
-                       words, (long long)n_words, bk, v.bkeys[(step + 1) & 1], (const int32_t*)v.pidx, v.part_off);
+                       words, (long long)n_words, bk, dr, (const int32_t*)v.pidx, v.part_off, (const int32_t*)nullptr);
   }
   if (n_steps > 0)
     hipLaunchKernelGGL(mbk_inertia_kernel, dim3(n_prob), dim3(64), 0, ctx->stream, v.probs, state, step0 + n_steps - 1,
                        (const double*)v.pper[(step0 + n_steps - 1) & 1]);
+  RHCCQ_LAUNCH_CHECK(ctx);
+  return 0;
+}
+
+// The same steps for ONE problem whose centres all carry weight (state: no zero-weight centre), with the E-step of step t + 1
+// started beside the update of step t (k8_overlap.h).  since0 = the problem's "samples since the last reassignment" as step0 sees
+// it (state[3] for an even step0, state[12] for an odd one): with it the host knows which steps of the call reassign.
+// *carry (in/out, 0 before the first call and whenever a classic call came in between): bit 0 = batch step0 + 1 has been
+// drawn, bit 1 = the speculative tile minima of step0 are in `work`.
+int rhccq_mbk_steps_overlapped(rhccq_ctx* ctx, const uint32_t* keys, const rhccq_mbk_problem* probs, int32_t n_prob, int64_t step0,
+                               int32_t n_steps, const uint32_t* words, int64_t n_words, double* centres, double* weights, double* state,
+                               void* work, int64_t work_bytes, int32_t estep_split, int64_t since0, int32_t* carry) {
+  if (!ctx || !keys || !probs || !words || !centres || !weights || !state || !work || !carry || n_steps < 0 || n_words <= 0 || step0 < 0 ||
+      since0 < 0 || (*carry & ~3) != 0)
+    return rhccq_fail(ctx, RHCCQ_E_ARG, "mbk_steps_overlapped: bad argument");
+  if (n_prob != 1) return rhccq_fail(ctx, RHCCQ_E_ARG, "mbk_steps_overlapped: exactly one problem");
+  if (estep_split != 0 && estep_split != 1 && estep_split != 2 && estep_split != 4 && estep_split != 8)
+    return rhccq_fail(ctx, RHCCQ_E_ARG, "mbk_steps_overlapped: estep_split must be 0, 1, 2, 4 or 8");
+  WorkView v;
+  long long blocks;
+  int max_tiles;
+  if (int e = layout_work(ctx, probs, n_prob, work, work_bytes, &v, &blocks, &max_tiles)) return e;
+  const long long k = probs[0].k, bs = probs[0].n < 1000 ? probs[0].n : 1000;
+  const int SS = estep_split == 0 ? 1 : estep_split;
+  // which steps of this call reassign (sklearn _random_reassign with no zero-weight centre left)
+  std::vector<char> R((size_t)n_steps + 2, 0);
+  {
+    long long since = since0;
+    for (int s = 0; s < n_steps + 2; ++s) {
+      since += bs;
+      R[s] = since >= 10 * k;
+      if (R[s]) since = 0;
+    }
+  }
+  long long drawn = step0 + ((*carry & 1) ? 1 : 0);        // newest batch in the ring
+  bool have_spec = (*carry & 2) != 0;
+  UpdDraws dr{{v.bkeys[0], v.bkeys[1], v.bkeys[2], v.bkeys[3]}, 0, 0, 0, 0, n_prob};
+  for (int s = 0; s < n_steps; ++s) {
+    const long long step = step0 + s;
+    const uint32_t* bk = v.bkeys[step & 3];
+    if (!have_spec) {
+#define RHCCQ_ESTEP_LAUNCH(S_)                                                                                                             \
+  hipLaunchKernelGGL(mbk_batch_estep_kernel<S_>, dim3(max_tiles * kPtChunks * S_ + 1, n_prob), dim3(256), 0, ctx->stream, keys, v.probs, centres, \
+                     state, step, bk, v.pdist, v.pidx, v.part_off, (const double*)nullptr)
+      switch (SS) {
+        case 8: RHCCQ_ESTEP_LAUNCH(8); break;
+        case 4: RHCCQ_ESTEP_LAUNCH(4); break;
+        case 2: RHCCQ_ESTEP_LAUNCH(2); break;
+        default: RHCCQ_ESTEP_LAUNCH(1); break;
+      }
+#undef RHCCQ_ESTEP_LAUNCH
+    }
+    hipLaunchKernelGGL(mbk_fix_kernel, dim3((1000 + kFixPts - 1) / kFixPts, n_prob), dim3(256), 0, ctx->stream, v.probs, (const double*)state, step,
+                       (const double*)centres, bk, (const double*)v.pdist, (const int32_t*)v.pidx, v.part_off, v.pper[step & 1],
+                       have_spec ? (const int32_t*)v.lab[(step - 1) & 1] : (const int32_t*)nullptr, v.lab[step & 1]);
+    dr.expect_reassign = R[s];
+    dr.draw_first = drawn + 1;
+    dr.draw_count = 0;
+    dr.reassign_draws = 0;
+    if (R[s]) {
+      // a reassigning step: the classic update (it draws the batches behind its choice() itself), the inertia in a launch of its own
+      if (drawn != step) return rhccq_fail(ctx, RHCCQ_E_LIMIT, "mbk_steps_overlapped: a batch was drawn past a reassignment (internal error)");
+      dr.reassign_draws = R[s + 1] ? 1 : 2;
+      drawn = step + dr.reassign_draws;
+      hipLaunchKernelGGL(mbk_update_kernel, dim3(n_prob, 2), dim3(kUpdThreads), 0, ctx->stream, keys, v.probs, centres, weights, state, step,
+                         words, (long long)n_words, bk, dr, (const int32_t*)v.pidx, v.part_off, (const int32_t*)v.lab[step & 1]);
+      hipLaunchKernelGGL(mbk_inertia_kernel, dim3(n_prob), dim3(64), 0, ctx->stream, v.probs, state, step, (const double*)v.pper[step & 1]);
+      have_spec = false;
+      continue;
+    }
+    // the speculative E-step of step + 1 needs its batch before this launch starts
+    const bool spec_next = drawn >= step + 1;
+    const long long target = R[s + 1] ? step + 1 : step + 2;
+    if (target > drawn) { dr.draw_count = (int)(target - drawn); drawn = target; }
+#define RHCCQ_PIPE_LAUNCH(S_)                                                                                                              \
+  hipLaunchKernelGGL(mbk_pipe_kernel<S_>, dim3(kPipeRoles + (spec_next ? max_tiles * kPtChunks * S_ : 0), n_prob), dim3(kPipeThreads), 0, ctx->stream,  \
+                     keys, v.probs, centres, weights, state, step, words, (long long)n_words, bk, dr, (const int32_t*)v.lab[step & 1],     \
+                     (const double*)v.pper[step & 1], (const uint32_t*)v.bkeys[(step + 1) & 3], v.pdist, v.pidx, v.part_off)
+    switch (SS) {
+      case 8: RHCCQ_PIPE_LAUNCH(8); break;
+      case 4: RHCCQ_PIPE_LAUNCH(4); break;
+      case 2: RHCCQ_PIPE_LAUNCH(2); break;
+      default: RHCCQ_PIPE_LAUNCH(1); break;
+    }
+#undef RHCCQ_PIPE_LAUNCH
+    have_spec = spec_next;
+  }
+  *carry = (drawn > step0 + n_steps ? 1 : 0) | (have_spec ? 2 : 0);
   RHCCQ_LAUNCH_CHECK(ctx);
   return 0;
 }

@@ -482,6 +482,10 @@ class Rhccq:
 
     # -- K8 -----------------------------------------------------------------------------------------
     MBK_LANES = 4        # problems of a small batch run as independent pipelines on this many HIP streams
+    MBK_OVERLAP = True   # a lone running problem: E-step of step t + 1 beside the update of step t (bit-identical; k8_overlap.h)
+    MBK_OVERLAP_MIN_K = 1024
+    MBK_OVERLAP_POLL = 128
+    MBK_FIRST_POLL = 16
 
     def _lane(self, i):
         """a sibling context on its own HIP stream (host thread `i` of a pipelined call); shares the MT19937 word table"""
@@ -539,11 +543,13 @@ class Rhccq:
             raise errors[0]
         labs = [None] * n_prob
         infos = [None] * n_prob
+        n_overlapped = 0
         for g in range(n_lanes):
             if not groups[g]:
                 continue
             (lg, ig), done = results[g]
             here.wait_event(done)
+            n_overlapped += ig["overlapped_launches"]
             for j, i in enumerate(groups[g]):
                 lg[j].record_stream(here)
                 labs[i] = lg[j]
@@ -554,7 +560,8 @@ class Rhccq:
         if return_info:
             koff = np.concatenate([[0], np.cumsum(k_list)]).astype(np.int64)
             return labs, {"state": np.stack([x[0] for x in infos]), "centres": np.concatenate([x[1] for x in infos]),
-                          "chosen": np.concatenate([x[2] for x in infos]), "koff": koff, "weights": np.concatenate([x[3] for x in infos])}
+                          "chosen": np.concatenate([x[2] for x in infos]), "koff": koff, "weights": np.concatenate([x[3] for x in infos]),
+                          "overlapped_launches": n_overlapped}
         return labs
 
     def minibatch_kmeans(self, key_list, k_list, return_info=False, poll_steps=64, return_device=False, timing=None, estep="auto", estep_split=0,
@@ -660,20 +667,40 @@ class Rhccq:
         limit = np.array([(100 * n) // min(1000, n) for n in sizes], np.int64)
         running = np.ones(n_prob, bool)
         step = 0                                             # launch index = step index of every problem still running
+        carry = C.c_int32(0)
+        st = st0
+        n_overlapped = 0
         while running.any():
-            ns = int(min(poll_steps, max(1, limit[running].max() - step)))
+            # most problems converge within a dozen steps: look early once, so that a finished problem does not sit through the
+            # launches of a whole poll interval
+            ns = int(min(poll_steps if step else min(poll_steps, self.MBK_FIRST_POLL), max(1, limit[running].max() - step)))
             # the grid E-step pays when many centres are in flight; once only stragglers are left the tiled
             # brute force has fewer and shorter launches per step
             mode = {"tiles": 1, "grid": 2}.get(estep) or (2 if int(k_arr[running].sum()) >= 200000 else 1)
             # few workgroups left (a straggler problem): several threads share a batch point in the tiled E-step
             wgs = int(((k_arr[running] + 511) // 512).sum()) * 2
             split = estep_split or next((sp for sp in (1, 2, 4, 8) if wgs * sp >= 1536), 8)
-            words = self._mt_words_dev(cur_max + (ns + 2) * WORDS_PER_STEP)     # a step consumes at most WORDS_PER_STEP
-            self._check(self.lib.rhccq_mbk_steps(self.ctx, self._p(keys), probs, n_prob, step, ns, self._p(words), words.numel(),
-                                                 self._p(centres), self._p(weights), self._p(state), self._p(work), wbytes, mode, split),
-                        "mbk_steps")
+            words = self._mt_words_dev(cur_max + (ns + 3) * WORDS_PER_STEP)     # a step consumes at most WORDS_PER_STEP
+            par = step & 1
+            # a lone problem whose centres all carry weight: the next E-step starts beside the update (rhccq_mbk_steps_overlapped)
+            overlapped = (self.MBK_OVERLAP and n_prob == 1 and step > 0 and mode == 1 and k_list[0] >= self.MBK_OVERLAP_MIN_K
+                          and st[0, 13 if par else 8] == 0)
+            if overlapped:
+                ns = int(min(max(poll_steps, self.MBK_OVERLAP_POLL), max(1, limit[0] - step)))
+                words = self._mt_words_dev(cur_max + (ns + 3) * WORDS_PER_STEP)
+                self._check(self.lib.rhccq_mbk_steps_overlapped(self.ctx, self._p(keys), probs, 1, step, ns, self._p(words), words.numel(),
+                                                                self._p(centres), self._p(weights), self._p(state), self._p(work), wbytes,
+                                                                split, int(st[0, 12 if par else 3]), C.byref(carry)), "mbk_steps_overlapped")
+                n_overlapped += ns
+            else:
+                carry.value = 0
+                self._check(self.lib.rhccq_mbk_steps(self.ctx, self._p(keys), probs, n_prob, step, ns, self._p(words), words.numel(),
+                                                     self._p(centres), self._p(weights), self._p(state), self._p(work), wbytes, mode, split),
+                            "mbk_steps")
             step += ns
             st = state.cpu().numpy()
+            if (st[:, 4] == 5).any():
+                raise RhccqError("the overlapped mini-batch schedule and the device state disagree about a reassignment (internal error)")
             cur_max = int(max(st[:, 9].max(), st[:, 14].max()))
             if (st[:, 4] == 3).any():
                 raise RhccqError("mini-batch steps ran past the end of the MT19937 word table (internal sizing error)")
@@ -690,7 +717,7 @@ class Rhccq:
             out = [lab[offs[i]:offs[i + 1]] for i in range(n_prob)]
         if return_info:
             return out, {"state": state.cpu().numpy(), "centres": centres.cpu().numpy(), "chosen": chosen.cpu().numpy(),
-                         "koff": koff, "weights": weights.cpu().numpy()}
+                         "koff": koff, "weights": weights.cpu().numpy(), "overlapped_launches": n_overlapped}
         return out
 
     # -- EXTENSION: pixel-space DBSCAN on (x, y, L, a, b) (no reference counterpart) ------------------------

@@ -158,6 +158,59 @@ def test_minibatch_equals_sklearn_golden(rh, O):
             assert np.array_equal(labs[i], untouched[n]), (n, "HIP labels vs the untouched scikit-learn fit")
 
 
+def test_minibatch_overlapped_steps_equal_the_classic_sequence(rh, O):
+    """A lone problem whose centres all carry weight runs rhccq_mbk_steps_overlapped (k8_overlap.h): the E-step of step t + 1 beside
+    the update of step t -- untouched centres speculatively, touched ones at their new values afterwards.  State (steps, EWA
+    values, MT cursor), centres, weights and labels must equal the classic three-launch sequence bit for bit; the cases put
+    reassignment steps (every 10 k / 1000 steps) inside the overlapped range, k below and above one speculative tile, a
+    ragged last tile, and n < 1000 rows per batch is covered by the classic path only (k >= 1024 is required)."""
+    cls = type(rh)
+    rng = np.random.default_rng(77)
+    g = load("g10_minibatch.npz")
+    pal, _ = O.unique_colors(g["img"])
+    pal = pal[~np.all(pal == 0, axis=1)]
+    cases = [(np.unique(rng.integers(0, 256, (90000, 3)).astype(np.uint8), axis=0), 1100),
+             (np.unique(rng.integers(0, 256, (260000, 3)).astype(np.uint8), axis=0), 4321),
+             (np.unique((rng.normal(128, 40, (500000, 3))).clip(0, 255).astype(np.uint8), axis=0), 16400),
+             (pal, max(1024, len(pal) // 40))]
+    total = 0
+    for P, k in cases:
+        keys = O.pack_rgb(P)
+        out = {}
+        for overlap in (False, True):
+            cls.MBK_OVERLAP = overlap
+            try:
+                out[overlap] = rh.minibatch_kmeans([keys], [k], return_info=True)
+            finally:
+                cls.MBK_OVERLAP = True
+        (l0, i0), (l1, i1) = out[False], out[True]
+        assert i0["overlapped_launches"] == 0
+        total += i1["overlapped_launches"]
+        s0, s1 = i0["state"][0], i1["state"][0]
+        par = int(s0[5]) & 1
+        live = [0, 1, 2, 4, 5, 6, 7, 11] + ([12, 13] if par else [3, 8])     # (the cursor may sit one batch ahead)
+        assert np.array_equal(s0[live], s1[live]), (k, s0, s1)
+        assert np.array_equal(i0["centres"], i1["centres"]), (k, int(s0[5]))
+        assert np.array_equal(i0["weights"], i1["weights"]), k
+        assert np.array_equal(l0[0], l1[0]), k
+    assert total >= 300, total                                # the overlapped sequence did run
+
+
+def test_minibatch_overlapped_equals_sklearn_golden(rh, O):
+    """The overlapped sequence against scikit-learn itself: the g11 fixtures with every problem on a lane of its own (a lone
+    problem is what rhccq_mbk_steps_overlapped takes)."""
+    from test_oracle_golden import check_against_g11, g11_cases, g11_palette
+    cases = g11_cases()
+    g = load("g11_mbk_sklearn.npz")
+    names = list(cases)
+    pals = [g11_palette(n, cases[n]) for n in names]
+    labs, info = rh.minibatch_kmeans([O.pack_rgb(P) for P in pals], [cases[n]["k"] for n in names], return_info=True, lanes=len(names))
+    assert info["overlapped_launches"] > 0
+    for i, n in enumerate(names):
+        a, b = info["koff"][i], info["koff"][i + 1]
+        check_against_g11(n, cases[n], g, info["chosen"][a:b], info["state"][i][5], info["centres"][a:b, :3], labs[i])
+
+
 def test_minibatch_more_than_256_problems(rh, O):
     """the Morton sort names the problem in 8 bits of its key -- rhccq_mbk_order chunks by 256 problems.
     300 small problems in one call (a batch of 65+ 4K frames has that many segments), spot-checked against the oracle."""

@@ -1,0 +1,73 @@
+"""diagnostic only: host-side timeline of one single-4K-frame encode -- every C call and a few Python stages per thread, with
+start / end relative to the frame start (no synchronisation added):  python tools/hosttrace.py [t_max_ms]"""
+import os, sys
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+import threading, time
+import torch
+import bench
+from roibasedimagecompression_amd import ops, frame, palette, mt
+from roibasedimagecompression_amd.ops import Rhccq
+from roibasedimagecompression_amd.frame import FrameEncoder
+
+rh = Rhccq(0)
+enc = FrameEncoder(rh)
+_, rgb, specs, roi, _ = bench.build_inputs(rh, 2160, 3840, 1234, (2, 1), 20, 20, 2.0)
+for _ in range(3):
+    enc.encode(rgb, specs)
+torch.cuda.synchronize()
+ev = []
+T0 = [0.0]
+
+
+def wrap(fn, name):
+    def g(*a, **k):
+        t0 = time.perf_counter()
+        try:
+            return fn(*a, **k)
+        finally:
+            ev.append((threading.current_thread().name, name, t0 - T0[0], time.perf_counter() - T0[0]))
+    return g
+
+
+class L:
+    def __init__(self, lib):
+        self._lib, self._w = lib, {}
+
+    def __getattr__(self, n):
+        if n.startswith("rhccq_") and n != "rhccq_last_error":
+            if n not in self._w:
+                self._w[n] = wrap(getattr(self._lib, n), n)
+            return self._w[n]
+        return getattr(self._lib, n)
+
+
+rh.lib = L(rh.lib)
+for ln in list(getattr(rh, "_lanes", {}).values()):
+    ln[1].lib = L(ln[1].lib)
+    for l2 in list(getattr(ln[1], "_lanes", {}).values()):
+        l2[1].lib = L(l2[1].lib)
+Rhccq.minibatch_kmeans = wrap(Rhccq.minibatch_kmeans, "PY minibatch_kmeans")
+Rhccq._mt_words_dev = wrap(Rhccq._mt_words_dev, "PY _mt_words_dev")
+Rhccq.dev = wrap(Rhccq.dev, "PY dev(H2D)")
+mt.MtWords.randint = wrap(mt.MtWords.randint, "PY mt.randint")
+frame.cluster_palettes = wrap(frame.cluster_palettes, "PY cluster_palettes")
+FrameEncoder.level1_jobs = wrap(FrameEncoder.level1_jobs, "PY level1_jobs")
+FrameEncoder.prepare = wrap(FrameEncoder.prepare, "PY prepare")
+FrameEncoder._first_pos_pass = wrap(FrameEncoder._first_pos_pass, "PY first_pos_pass")
+frame._merge = wrap(frame._merge, "PY _merge")
+FrameEncoder.level2_finish = staticmethod(wrap(FrameEncoder.level2_finish, "PY level2_finish"))
+FrameEncoder.level3_job = wrap(FrameEncoder.level3_job, "PY level3_job")
+FrameEncoder.finish = wrap(FrameEncoder.finish, "PY finish")
+torch.cuda.synchronize()
+T0[0] = time.perf_counter()
+enc.encode(rgb, specs)
+torch.cuda.synchronize()
+total = time.perf_counter() - T0[0]
+tmax = float(sys.argv[1]) if len(sys.argv) > 1 else 1e9
+print(f"frame {1e3 * total:.2f} ms")
+for th in sorted({e[0] for e in ev}):
+    print("==", th)
+    for _, n, a, b in sorted((e for e in ev if e[0] == th), key=lambda e: e[2]):
+        if 1e3 * a <= tmax or 1e3 * a >= 1e3 * total - tmax:
+            if b - a >= 20e-6 or n.startswith("PY"):
+                print(f"   {1e3 * a:8.3f} .. {1e3 * b:8.3f}  ({1e3 * (b - a):7.3f} ms)  {n}")
