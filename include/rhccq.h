@@ -201,6 +201,11 @@ typedef struct rhccq_mbk_problem {
 int64_t rhccq_mbk_order_bytes(int64_t total_samples);
 int rhccq_mbk_order(rhccq_ctx* ctx, const uint32_t* keys, const rhccq_mbk_problem* probs_host,
                     int32_t n_prob, const int32_t* init_idx, int32_t* perm, void* tmp, int64_t tmp_bytes);
+/* RandomState.randint(0, n, size) of numpy's legacy generator replayed ON THE HOST from raw MT19937 words in host memory
+ * (masked rejection, one word per attempt): sklearn MiniBatchKMeans draws its validation and init samples this way before
+ * k-means++ (clustering.py:207-218 -> _kmeans.py MiniBatchKMeans.fit).  out: int32[size] or NULL (stream position only).
+ * Returns the words consumed, -1 when the table ends first, -2 for a bad argument.  Pure host code, no ctx. */
+int64_t rhccq_mt_randint_host(const uint32_t* words, int64_t n_words, int64_t pos, int64_t n, int64_t size, int32_t* out);
 /* out[i] = the i-th double numpy's legacy RandomState.uniform(size=count) / random_sample() yields when its
  * MT19937 stream stands at raw word `pos`: ((w[pos+2i] >> 5) * 2^26 + (w[pos+2i+1] >> 6)) / 2^53.  words: the raw
  * 32-bit outputs of MT19937(seed 42), resident on the device (roibasedimagecompression_amd/mt.py generates them
@@ -212,8 +217,8 @@ int rhccq_mt_uniforms(rhccq_ctx* ctx, const uint32_t* words, int64_t pos, int64_
 int rhccq_mbk_init(rhccq_ctx* ctx, const uint32_t* keys, const rhccq_mbk_problem* probs_host,
                    int32_t n_prob, const int32_t* init_idx, const int32_t* perm, const double* rand,
                    double* centres, int32_t* chosen);
-/* run mini-batch steps step0 .. step0 + n_steps - 1 for every problem that has not stopped (call with step0 = 0 first, then
- * with the number of steps launched so far; all problems of a call sequence share the step index).  state:
+/* run mini-batch steps step0 .. step0 + n_steps - 1 for every problem that has not stopped (call with step0 = 0 first -- that
+ * call writes the problem tables at the head of `work`, later calls only queue kernels -- then with the number of steps launched so far; all problems of a call sequence share the step index).  state:
  * double[n_prob][16] = {[0] ewa, [1] ewa_min, [2] no_improvement, [3] samples since the last reassignment, [4] why the
  * problem stopped (0 running, 1 converged, 2 out of steps, 3 word table exhausted -- fatal: size `words` so that it
  * cannot happen; 4 sharded chain hand-off lost; 5 overlapped schedule diverged), [5] steps done, [6] have_ewa, [7] have_min, [8] zero-weight centres (initialise to k), [9] MT cursor

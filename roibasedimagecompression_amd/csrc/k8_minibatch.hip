@@ -24,6 +24,7 @@
 //          exact) tiled through LDS; float64 VALU bound (K = 3 is not an MFMA shape).
 #include <hipcub/hipcub.hpp>
 
+#include <cstring>
 #include <vector>
 
 #include "rhccq_common.h"
@@ -1597,7 +1598,7 @@ constexpr int kHistBins = 2048;
 constexpr int kStateStride = 16;    // doubles per problem, see rhccq_mbk_steps
 constexpr int kMemCap = 8;          // batch members listed per touched centre; beyond, the centre's thread scans the batch
 constexpr int kStageWords = 2048;   // MT19937 words staged in LDS for the shuffle replay (expected need: ~1 400)
-constexpr int kDrawWords = 4;       // words per thread and round of the randint replay (4 096 per round)
+constexpr int kDrawWords = 4;       // words per thread and round of the randint replay (4 096 per round with 1 024 threads)
 constexpr long long kWordsMargin = 16384;   // words a step may consume at most (randint ~2 000, shuffle ~1 400 expected)
 
 struct UpdShared {
@@ -1682,6 +1683,7 @@ __device__ __forceinline__ void walk_members(const int* __restrict__ lab, const 
 // `word & mask` (mask = smallest 2^b - 1 >= rng), one word each, kept when <= rng.  All threads of the workgroup:
 // thread t looks at kDrawWords consecutive words per round, a block scan orders the survivors.  out[0 .. count) (LDS)
 // receives the values in draw order.  Returns the cursor behind the last consumed word (-1: the table is exhausted).
+template <int kDW = kDrawWords>
 __device__ __forceinline__ long long replay_randint(const uint32_t* __restrict__ words, long long n_words, long long cursor, unsigned rng,
                                                     int count, int* out, int* ired, long long* s_cursor) {
   const int tid = threadIdx.x;
@@ -1693,19 +1695,19 @@ __device__ __forceinline__ long long replay_randint(const uint32_t* __restrict__
   const uint32_t mask = 0xffffffffu >> __clz(rng);
   int produced = 0;
   while (true) {
-    if (cursor + (long long)blockDim.x * kDrawWords > n_words) return -1;
-    const long long base = cursor + (long long)tid * kDrawWords;
-    uint32_t v[kDrawWords];
+    if (cursor + (long long)blockDim.x * kDW > n_words) return -1;
+    const long long base = cursor + (long long)tid * kDW;
+    uint32_t v[kDW];
     int cnt = 0;
 #pragma unroll
-    for (int q = 0; q < kDrawWords; ++q) {
+    for (int q = 0; q < kDW; ++q) {
       v[q] = words[base + q] & mask;
       cnt += v[q] <= rng;
     }
     int tot;
     int pos = produced + block_exscan<int>(cnt, ired, &tot);
 #pragma unroll
-    for (int q = 0; q < kDrawWords; ++q) {
+    for (int q = 0; q < kDW; ++q) {
       if (v[q] <= rng) {
         if (pos < count) {
           out[pos] = (int)v[q];
@@ -1717,7 +1719,7 @@ __device__ __forceinline__ long long replay_randint(const uint32_t* __restrict__
     __syncthreads();
     if (produced + tot >= count) return *s_cursor;
     produced += tot;
-    cursor += (long long)blockDim.x * kDrawWords;
+    cursor += (long long)blockDim.x * kDW;
   }
 }
 
@@ -1792,11 +1794,12 @@ __device__ __forceinline__ long long replay_permutation(const uint32_t* __restri
 }
 
 // the batch of the next step: rows = randint(0, n, bs), their colours -> bkeys (what the E-step kernels read)
+template <int kDW = kDrawWords>
 __device__ __forceinline__ long long draw_batch(const uint32_t* __restrict__ keys, const MbkP& P, const uint32_t* __restrict__ words,
                                                 long long n_words, long long cursor, uint32_t* __restrict__ bkeys_p, int* out, int* ired,
                                                 long long* s_cursor) {
   const int bs = (int)min((long long)1000, P.n);
-  const long long c = replay_randint(words, n_words, cursor, (unsigned)(P.n - 1), bs, out, ired, s_cursor);
+  const long long c = replay_randint<kDW>(words, n_words, cursor, (unsigned)(P.n - 1), bs, out, ired, s_cursor);
   if (c < 0) return c;
   for (int b = threadIdx.x; b < bs; b += blockDim.x) bkeys_p[b] = keys[P.off + out[b]];
   return c;
@@ -1824,12 +1827,6 @@ __global__ __launch_bounds__(kUpdThreads) void mbk_draw0_kernel(const uint32_t* 
   }
 }
 
-#ifdef RHCCQ_STAMPS
-__device__ unsigned long long g_upd_stamps[16];
-#define USTAMP(slot) do { if (tid == 0 && p == 0) { const unsigned long long _t = clock64(); atomicAdd(&g_upd_stamps[slot], _t - _ul); _ul = _t; } } while (0)
-#else
-#define USTAMP(slot) do {} while (0)
-#endif
 
 // One mini-batch step after its E-step (sklearn _mini_batch_step): TWO workgroups per problem (blockIdx.y = role), on two
 // CUs, because the step is a chain of latencies and these chains are independent:
@@ -1838,6 +1835,175 @@ __device__ unsigned long long g_upd_stamps[16];
 //   role 1  the next step's batch (randint replay + colour gather) whenever this step does not reassign (then the stream
 //           position is known before the step starts).
 // (The third chain, batch inertia + EWA rule, rides in the next step's E-step kernel: mbk_inertia_block.)
+#ifdef RHCCQ_STAMPS
+__device__ unsigned long long g_upd_stamps[16];
+#define USTAMP(slot) do { if (tid == 0 && p == 0) { const unsigned long long _t = clock64(); atomicAdd(&g_upd_stamps[slot], _t - _ul); _ul = _t; } } while (0)
+#else
+#define USTAMP(slot) do {} while (0)
+#endif
+#ifdef RHCCQ_STAMPS
+#define RSTAMP(slot) do { if (tid == 0 && stamp) { const unsigned long long _t = clock64(); atomicAdd(&g_upd_stamps[slot], _t - _rl); _rl = _t; } } while (0)
+#else
+#define RSTAMP(slot) do {} while (0)
+#endif
+// The low-count reassignment of one step (sklearn _mini_batch_step with random_reassign): centres whose weight is below 1 % of
+// the largest weight -- at most batch / 2 of them, the lightest first -- move to random rows of the batch and take the smallest
+// weight of the centres that stay.  Wave w owns the contiguous index range [w R, (w + 1) R), 64 entries at a time.  The five
+// sweeps over the weights read an LDS copy when it fits (kLds: the weights are counts, integers below 100 n <= 1.7e9, exact in
+// 32 bits; the copy lives in the member tables of the update, which is over by now: k <= 30 720), otherwise global memory (L2)
+// -- with 20 dependent reads per thread and sweep that was ~50 us of an 80 us step.
+// Returns the MT cursor behind the choice() replay (-1: word table exhausted).
+constexpr size_t kWLdsOff = offsetof(UpdShared, per);
+constexpr int kWLds = (int)((offsetof(UpdShared, perm) - offsetof(UpdShared, per)) / 4);
+template <bool kLds>
+__device__ __forceinline__ long long reassign_phase(UpdShared& sh, double* __restrict__ C, double* __restrict__ W, const int k, const int bs,
+                                                    const uint32_t* __restrict__ words, long long n_words, long long cursor,
+                                                    const long long stage_base, double* st, const long long step, const bool stamp) {
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+#ifdef RHCCQ_STAMPS
+  unsigned long long _rl = clock64();
+#endif
+  const int R = (((k + kUpdWaves - 1) / kUpdWaves) + 63) & ~63;
+  const int j0 = wave * R, j1 = min(j0 + R, k);
+  const int n_it = j1 > j0 ? (j1 - j0 + 63) / 64 : 0;
+  unsigned* wl = reinterpret_cast<unsigned*>(reinterpret_cast<char*>(&sh) + kWLdsOff);
+  if (kLds) {
+#pragma unroll 8
+    for (int j = tid; j < k; j += kUpdThreads) wl[j] = (unsigned)W[j];
+    __syncthreads();
+  }
+  RSTAMP(6);
+#define RHCCQ_WSWEEP(...)                                                                                                     \
+  for (int i = 0; i < n_it; ++i) {                                                                                            \
+    const int j = j0 + lane + 64 * i;                                                                                         \
+    (void)j;                                                                                                                  \
+    const double w = j < j1 ? (kLds ? (double)wl[j] : W[j]) : INFINITY;   /* (+inf: never a candidate, never the minimum) */  \
+    __VA_ARGS__                                                                                                               \
+  }
+  double wm = 0.0;
+  RHCCQ_WSWEEP({ if (j < j1) wm = fmax(wm, w); })
+  wm = block_max_d(wm, sh);
+  const double thr = 0.01 * wm;
+  const int cap = (int)(0.5 * (double)bs);
+  const int nbins = (int)ceil(thr);                   // candidate weights are integers in [0, thr)
+  const bool use_hist = nbins <= kHistBins;
+  for (int i = tid; i < kHistBins; i += kUpdThreads) sh.hist[i] = 0;
+  __syncthreads();
+  int cnt = 0, c0 = 0, c1 = 0;                           // candidates; of them with weight 0 / 1 (the hot bins of the first
+  RHCCQ_WSWEEP({                                         // steps: ~k centres share them -- counted in registers, not by atomics)
+    if (w < thr) {
+      ++cnt;
+      if (w == 0.0) ++c0;
+      else if (w == 1.0) ++c1;
+      else if (use_hist) atomicAdd(&sh.hist[(int)w], 1);
+    }
+  })
+  cnt = block_sum_i(cnt, sh);
+  c0 = block_sum_i(c0, sh);
+  c1 = block_sum_i(c1, sh);
+  if (tid == 0 && use_hist) { sh.hist[0] = c0; if (kHistBins > 1 && thr > 1.0) sh.hist[1] = c1; }
+  __syncthreads();
+  // more than batch/2 candidates: sklearn keeps np.argsort(weights)[:batch/2] -- an unstable sort over tied counts;
+  // CANONICAL: the stable order (weight, index), the one choice of this path that is not sklearn's own
+  const bool capped = cnt > 0.5 * (double)bs;
+  double sel_w = thr;
+  int take = 0;
+  if (capped) {
+    if (use_hist) {
+      if (tid == 0) {                                 // smallest weight v with #(W <= v) >= cap
+        int below = 0, v = 0;
+        for (; v < nbins; ++v) {
+          if (below + sh.hist[v] >= cap) break;
+          below += sh.hist[v];
+        }
+        sh.sel_w = (double)v;
+        sh.take = cap - below;
+      }
+      __syncthreads();
+      sel_w = sh.sel_w;
+      take = sh.take;
+    } else {
+      double lo_v = -1.0, hi_v = floor(thr);
+      if (hi_v >= thr) hi_v -= 1.0;
+      while (hi_v - lo_v > 1.0) {
+        const double mid = floor((lo_v + hi_v) * 0.5);
+        int c2 = 0;
+        RHCCQ_WSWEEP({ c2 += (w < thr) && (w <= mid); })
+        c2 = block_sum_i(c2, sh);
+        if (c2 >= cap) hi_v = mid; else lo_v = mid;
+      }
+      int below = 0;
+      RHCCQ_WSWEEP({ below += (w < thr) && (w < hi_v); })
+      below = block_sum_i(below, sh);
+      sel_w = hi_v;
+      take = cap - below;
+    }
+  }
+  // index-ordered ranks inside the wave's range, 64 at a time
+  int eq_base = 0;
+  if (capped) {
+    int eq = 0;
+    RHCCQ_WSWEEP({ eq += (w < thr) && (w == sel_w); })
+    eq = (int)wave_sum((unsigned long long)eq);
+    if (lane == 0) sh.weq[wave] = eq;
+    __syncthreads();
+    for (int w = 0; w < wave; ++w) eq_base += sh.weq[w];
+  }
+  RSTAMP(7);
+  // sweep 2: selected count per wave, min weight of the centres that stay
+  int nsel = 0, eq_run = eq_base;
+  double wmin = INFINITY;
+  RHCCQ_WSWEEP({
+    const bool is_eq = capped && (w < thr) && (w == sel_w);
+    const unsigned long long meq = __ballot(is_eq);
+    const int rank = eq_run + __popcll(meq & ((1ull << lane) - 1ull));
+    const bool sel = j < j1 && reassign_sel(w, thr, capped, sel_w, take, rank);
+    nsel += __popcll(__ballot(sel));
+    if (j < j1 && !sel) wmin = fmin(wmin, w);
+    eq_run += __popcll(meq);
+  })
+  if (lane == 0) sh.wsel[wave] = nsel;
+  wmin = block_min_d(wmin, sh);                        // (two barriers: wsel is visible afterwards)
+  int rbase = 0, n_re = 0;
+  for (int w = 0; w < kUpdWaves; ++w) { if (w < wave) rbase += sh.wsel[w]; n_re += sh.wsel[w]; }
+  RSTAMP(11);
+  if (n_re > 0) {
+    // new_centers = random_state.choice(batch, replace=False, size=n_reassigns): rows of the batch
+    cursor = replay_permutation(words, n_words, cursor, bs, n_re, sh, stage_base);
+  }
+  RSTAMP(12);
+  if (cursor >= 0) {
+    // sweep 3: apply; count the centres whose weight is still zero afterwards
+    int nzero = 0, r_run = rbase;
+    eq_run = eq_base;
+    RHCCQ_WSWEEP({
+      const bool is_eq = capped && (w < thr) && (w == sel_w);
+      const unsigned long long meq = __ballot(is_eq);
+      const int rank = eq_run + __popcll(meq & ((1ull << lane) - 1ull));
+      const bool sel = j < j1 && reassign_sel(w, thr, capped, sel_w, take, rank);
+      const unsigned long long msel = __ballot(sel);
+      double wf = w;
+      if (sel) {
+        // centers_new[to_reassign] = X[new_centers]: the i-th reassigned centre (ascending index) takes batch row perm[i]
+        const uint32_t kk = sh.bkey[sh.perm[r_run + __popcll(msel & ((1ull << lane) - 1ull))]];
+        const double n0 = (double)key_r(kk), n1 = (double)key_g(kk), n2 = (double)key_b(kk);
+        C[j * 4] = n0; C[j * 4 + 1] = n1; C[j * 4 + 2] = n2;
+        C[j * 4 + 3] = km64_csq(n0, n1, n2);
+        W[j] = wmin;
+        wf = wmin;
+      }
+      nzero += (j < j1) && (wf == 0.0);
+      eq_run += __popcll(meq);
+      r_run += __popcll(msel);
+    })
+    nzero = block_sum_i(nzero, sh);
+    if (tid == 0) st[st_slot(kStNzero, step + 1)] = (double)nzero;
+  }
+  RSTAMP(13);
+#undef RHCCQ_WSWEEP
+  return cursor;
+}
+
 // Where the draws of a launch go (the batches live in a ring of four buffers, batch b in ring[b & 3]):
 //   role 1 draws the batches draw_first .. draw_first + draw_count - 1 (the classic sequence: the next step's batch; the overlapped
 //   sequence of rhccq_mbk_steps_overlapped runs one batch ahead, so that the NEXT step's E-step can start beside this step's update);
@@ -1855,7 +2021,7 @@ __device__ __forceinline__ void mbk_update_body(UpdShared& sh, const int p, cons
                                                 double* __restrict__ state, long long step, const uint32_t* __restrict__ words, long long n_words,
                                                 const uint32_t* __restrict__ bkeys_cur, const UpdDraws& dr,
                                                 const int32_t* __restrict__ labels_p) {
-  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const int tid = threadIdx.x;
   double* st = state + p * kStateStride;
   // independent table reads issued together: the kernel is a chain of dependent accesses, every cold miss counts
   const double st_since = st[st_slot(kStSince, step)], st_nzero = st[st_slot(kStNzero, step)];
@@ -1984,135 +2150,15 @@ __device__ __forceinline__ void mbk_update_body(UpdShared& sh, const int p, cons
   }
   __syncthreads();
   USTAMP(3);
-  // ---- low-count reassignment (sklearn _mini_batch_step), coalesced sweeps over the weights ------------
+  // ---- low-count reassignment (sklearn _mini_batch_step) ----------------------------------------------------------
   if (do_reassign) {
 #ifdef RHCCQ_STAMPS
     if (tid == 0 && p == 0) atomicAdd(&g_upd_stamps[14], 1ull);
 #endif
-    double wm = 0.0;
-#pragma unroll 8
-    for (int j = tid; j < k; j += kUpdThreads) wm = fmax(wm, W[j]);
-    wm = block_max_d(wm, sh);
-    const double thr = 0.01 * wm;
-    const int cap = (int)(0.5 * (double)bs);
-    const int nbins = (int)ceil(thr);                   // candidate weights are integers in [0, thr)
-    const bool use_hist = nbins <= kHistBins;
-    for (int i = tid; i < kHistBins; i += kUpdThreads) sh.hist[i] = 0;
-    __syncthreads();
-    int cnt = 0, c0 = 0, c1 = 0;                           // candidates; of them with weight 0 / 1 (the hot bins of the first
-    for (int j = tid; j < k; j += kUpdThreads) {           // steps: ~k centres share them -- counted in registers, not by atomics)
-      const double w = W[j];
-      if (w < thr) {
-        ++cnt;
-        if (w == 0.0) ++c0;
-        else if (w == 1.0) ++c1;
-        else if (use_hist) atomicAdd(&sh.hist[(int)w], 1);
-      }
-    }
-    cnt = block_sum_i(cnt, sh);
-    c0 = block_sum_i(c0, sh);
-    c1 = block_sum_i(c1, sh);
-    if (tid == 0 && use_hist) { sh.hist[0] = c0; if (kHistBins > 1 && thr > 1.0) sh.hist[1] = c1; }
-    __syncthreads();
-    // more than batch/2 candidates: sklearn keeps np.argsort(weights)[:batch/2] -- an unstable sort over tied counts;
-    // CANONICAL: the stable order (weight, index), the one choice of this path that is not sklearn's own
-    const bool capped = cnt > 0.5 * (double)bs;
-    double sel_w = thr;
-    int take = 0;
-    if (capped) {
-      if (use_hist) {
-        if (tid == 0) {                                 // smallest weight v with #(W <= v) >= cap
-          int below = 0, v = 0;
-          for (; v < nbins; ++v) {
-            if (below + sh.hist[v] >= cap) break;
-            below += sh.hist[v];
-          }
-          sh.sel_w = (double)v;
-          sh.take = cap - below;
-        }
-        __syncthreads();
-        sel_w = sh.sel_w;
-        take = sh.take;
-      } else {
-        double lo_v = -1.0, hi_v = floor(thr);
-        if (hi_v >= thr) hi_v -= 1.0;
-        while (hi_v - lo_v > 1.0) {
-          const double mid = floor((lo_v + hi_v) * 0.5);
-          int c2 = 0;
-          for (int j = tid; j < k; j += kUpdThreads) c2 += (W[j] < thr) && (W[j] <= mid);
-          c2 = block_sum_i(c2, sh);
-          if (c2 >= cap) hi_v = mid; else lo_v = mid;
-        }
-        int below = 0;
-        for (int j = tid; j < k; j += kUpdThreads) below += (W[j] < thr) && (W[j] < hi_v);
-        below = block_sum_i(below, sh);
-        sel_w = hi_v;
-        take = cap - below;
-      }
-    }
-    // index-ordered ranks: wave w owns the contiguous index range [w * R, (w + 1) * R), swept 64 at a time
-    const int R = (((k + kUpdWaves - 1) / kUpdWaves) + 63) & ~63;
-    const int j0 = wave * R, j1 = min(j0 + R, k);
-    int eq_base = 0;
-    if (capped) {
-      int eq = 0;
-      for (int j = j0 + lane; j < j1; j += 64) { const double w = W[j]; eq += (w < thr) && (w == sel_w); }
-      eq = (int)wave_sum((unsigned long long)eq);
-      if (lane == 0) sh.weq[wave] = eq;
-      __syncthreads();
-      for (int w = 0; w < wave; ++w) eq_base += sh.weq[w];
-    }
-    // sweep 2: selected count per wave, min weight of the centres that stay
-    int nsel = 0, eq_run = eq_base;
-    double wmin = INFINITY;
-    for (int jb = j0; jb < j1; jb += 64) {
-      const int j = jb + lane;
-      const double w = j < j1 ? W[j] : INFINITY;
-      const bool is_eq = capped && (w < thr) && (w == sel_w);
-      const unsigned long long meq = __ballot(is_eq);
-      const int rank = eq_run + __popcll(meq & ((1ull << lane) - 1ull));
-      const bool sel = j < j1 && reassign_sel(w, thr, capped, sel_w, take, rank);
-      nsel += __popcll(__ballot(sel));
-      if (j < j1 && !sel) wmin = fmin(wmin, w);
-      eq_run += __popcll(meq);
-    }
-    if (lane == 0) sh.wsel[wave] = nsel;
-    wmin = block_min_d(wmin, sh);                        // (two barriers: wsel is visible afterwards)
-    int rbase = 0, n_re = 0;
-    for (int w = 0; w < kUpdWaves; ++w) { if (w < wave) rbase += sh.wsel[w]; n_re += sh.wsel[w]; }
-    if (n_re > 0) {
-      // new_centers = random_state.choice(batch, replace=False, size=n_reassigns): rows of the batch
-      cursor = replay_permutation(words, n_words, cursor, bs, n_re, sh, (long long)st_cursor);
-    }
-    if (cursor >= 0) {
-      // sweep 3: apply; count the centres whose weight is still zero afterwards
-      int nzero = 0, r_run = rbase;
-      eq_run = eq_base;
-      for (int jb = j0; jb < j1; jb += 64) {
-        const int j = jb + lane;
-        const double w = j < j1 ? W[j] : INFINITY;
-        const bool is_eq = capped && (w < thr) && (w == sel_w);
-        const unsigned long long meq = __ballot(is_eq);
-        const int rank = eq_run + __popcll(meq & ((1ull << lane) - 1ull));
-        const bool sel = j < j1 && reassign_sel(w, thr, capped, sel_w, take, rank);
-        const unsigned long long msel = __ballot(sel);
-        double wf = w;
-        if (sel) {
-          // centers_new[to_reassign] = X[new_centers]: the i-th reassigned centre (ascending index) takes batch row perm[i]
-          const uint32_t kk = sh.bkey[sh.perm[r_run + __popcll(msel & ((1ull << lane) - 1ull))]];
-          const double c0 = (double)key_r(kk), c1 = (double)key_g(kk), c2 = (double)key_b(kk);
-          C[j * 4] = c0; C[j * 4 + 1] = c1; C[j * 4 + 2] = c2;
-          C[j * 4 + 3] = km64_csq(c0, c1, c2);
-          W[j] = wmin;
-          wf = wmin;
-        }
-        nzero += (j < j1) && (wf == 0.0);
-        eq_run += __popcll(meq);
-        r_run += __popcll(msel);
-      }
-      nzero = block_sum_i(nzero, sh);
-      if (tid == 0) st[st_slot(kStNzero, step + 1)] = (double)nzero;
-    }
+    if (k <= kWLds && P.n <= (1ll << 24))
+      cursor = reassign_phase<true>(sh, C, W, k, bs, words, n_words, cursor, (long long)st_cursor, st, step, p == 0);
+    else
+      cursor = reassign_phase<false>(sh, C, W, k, bs, words, n_words, cursor, (long long)st_cursor, st, step, p == 0);
   }
   USTAMP(4);
   // ---- a step that reassigned draws the next batch itself (role 2 stood back) -------------------------------------
@@ -2462,8 +2508,10 @@ struct WorkView {
   long long max_k;
 };
 
+// upload = false: the tables at the head of `work` are those an earlier call of the same sequence put there (step0 > 0): no
+// copies, no stream synchronisation -- the steps of a chunk then queue behind the previous chunk's without a bubble
 static int layout_work(rhccq_ctx* ctx, const rhccq_mbk_problem* probs, int n_prob, void* work, int64_t work_bytes, WorkView* v,
-                       long long* total_blocks, int* max_tiles) {
+                       long long* total_blocks, int* max_tiles, bool upload = true) {
   if (work_bytes < rhccq_mbk_work_bytes(probs, n_prob)) return rhccq_fail(ctx, RHCCQ_E_ARG, "mbk: work buffer too small");
   char* base = (char*)work;
   v->probs = (MbkP*)base; base += align256(sizeof(MbkP) * n_prob);
@@ -2509,11 +2557,13 @@ static int layout_work(rhccq_ctx* ctx, const rhccq_mbk_problem* probs, int n_pro
   v->lab[1] = (int32_t*)base;
   v->max_k = 0;
   for (int i = 0; i < n_prob; ++i) v->max_k = probs[i].k > v->max_k ? probs[i].k : v->max_k;
-  if (int e = put(ctx, v->probs, hp, sizeof(MbkP) * n_prob)) return e;
-  if (int e = put(ctx, v->part_off, hpo, 8 * (size_t)n_prob)) return e;
-  if (int e = put(ctx, v->blk_off, hbo, 8 * (size_t)(n_prob + 1))) return e;
-  // the staging string dies at return: make sure the copies have been issued from it
-  RHCCQ_HIP(ctx, hipStreamSynchronize(ctx->stream));
+  if (upload) {
+    if (int e = put(ctx, v->probs, hp, sizeof(MbkP) * n_prob)) return e;
+    if (int e = put(ctx, v->part_off, hpo, 8 * (size_t)n_prob)) return e;
+    if (int e = put(ctx, v->blk_off, hbo, 8 * (size_t)(n_prob + 1))) return e;
+    // the staging string dies at return: make sure the copies have been issued from it
+    RHCCQ_HIP(ctx, hipStreamSynchronize(ctx->stream));
+  }
   *total_blocks = blocks;
   *max_tiles = mt;
   return 0;
@@ -2528,6 +2578,11 @@ int rhccq_debug_upd_stamps(unsigned long long* out16_host) {
 int rhccq_debug_wave_stamps(unsigned long long* out64_host) {
   if (hipDeviceSynchronize() != hipSuccess) return -2;
   if (hipMemcpyFromSymbol(out64_host, HIP_SYMBOL(g_wave_stamps), sizeof(unsigned long long) * 128) != hipSuccess) return -2;
+  return 0;
+}
+int rhccq_debug_pipe_stamps(unsigned long long* out8_host) {
+  if (hipDeviceSynchronize() != hipSuccess) return -2;
+  if (hipMemcpyFromSymbol(out8_host, HIP_SYMBOL(g_pipe_stamps), sizeof(unsigned long long) * 8) != hipSuccess) return -2;
   return 0;
 }
 int rhccq_debug_stamps(unsigned long long* out16_host) {
@@ -2587,6 +2642,38 @@ int rhccq_mbk_order(rhccq_ctx* ctx, const uint32_t* keys, const rhccq_mbk_proble
     RHCCQ_LAUNCH_CHECK(ctx);
   }
   return 0;
+}
+
+// RandomState.randint(0, n, size) of numpy's legacy generator replayed ON THE HOST from raw MT19937 words (host memory): masked
+// rejection, one word per attempt (_bounded_integers.pyx, legacy path for ranges below 2^32).  out (int32[size], may be NULL when
+// only the stream position matters: sklearn's validation draw) receives the values; returns the words consumed, -1 when the
+// table ends first, -2 for a bad argument.  No HIP call inside: the k-means++ set-up of a frame's problems runs on several host
+// threads and this loop, unlike its numpy twin (mt.py), does not hold the interpreter lock.
+int64_t rhccq_mt_randint_host(const uint32_t* words, int64_t n_words, int64_t pos, int64_t n, int64_t size, int32_t* out) {
+  if (!words || pos < 0 || n <= 0 || n > 0x7fffffffll || size < 0 || n_words < 0) return -2;
+  if (size == 0) return 0;
+  const uint32_t rng = (uint32_t)(n - 1);
+  if (rng == 0u) {                                         // numpy draws nothing for a one-value range
+    if (out) memset(out, 0, sizeof(int32_t) * (size_t)size);
+    return 0;
+  }
+  uint32_t mask = rng;
+  mask |= mask >> 1; mask |= mask >> 2; mask |= mask >> 4; mask |= mask >> 8; mask |= mask >> 16;
+  int64_t got = 0;
+  if (out) {
+    for (int64_t i = pos; i < n_words; ++i) {
+      const uint32_t v = words[i] & mask;
+      out[got] = (int32_t)v;                               // (kept only when accepted: `got` moves on)
+      got += v <= rng;
+      if (got == size) return i + 1 - pos;
+    }
+  } else {
+    for (int64_t i = pos; i < n_words; ++i) {
+      got += (words[i] & mask) <= rng;
+      if (got == size) return i + 1 - pos;
+    }
+  }
+  return -1;
 }
 
 int rhccq_mt_uniforms(rhccq_ctx* ctx, const uint32_t* words, int64_t pos, int64_t count, double* out) {
@@ -2708,7 +2795,7 @@ int rhccq_mbk_steps(rhccq_ctx* ctx, const uint32_t* keys, const rhccq_mbk_proble
   WorkView v;
   long long blocks;
   int max_tiles;
-  if (int e = layout_work(ctx, probs, n_prob, work, work_bytes, &v, &blocks, &max_tiles)) return e;
+  if (int e = layout_work(ctx, probs, n_prob, work, work_bytes, &v, &blocks, &max_tiles, step0 == 0)) return e;
   // many problems in flight (a batch of frames): the brute-force E-step (sum k x 1000 float64 distance
   // evaluations per step) would dominate, so the centres are re-binned every step and the batch is assigned
   // through the grid; with few problems the tiled brute-force kernel has fewer launches per step
@@ -2775,7 +2862,8 @@ int rhccq_mbk_steps_overlapped(rhccq_ctx* ctx, const uint32_t* keys, const rhccq
   WorkView v;
   long long blocks;
   int max_tiles;
-  if (int e = layout_work(ctx, probs, n_prob, work, work_bytes, &v, &blocks, &max_tiles)) return e;
+  if (step0 == 0) return rhccq_fail(ctx, RHCCQ_E_ARG, "mbk_steps_overlapped: the first steps of a problem are rhccq_mbk_steps'");
+  if (int e = layout_work(ctx, probs, n_prob, work, work_bytes, &v, &blocks, &max_tiles, false)) return e;
   const long long k = probs[0].k, bs = probs[0].n < 1000 ? probs[0].n : 1000;
   const int SS = estep_split == 0 ? 1 : estep_split;
   // which steps of this call reassign (sklearn _random_reassign with no zero-weight centre left)

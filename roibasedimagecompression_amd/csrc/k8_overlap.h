@@ -140,6 +140,13 @@ __device__ __forceinline__ void lean_update(LeanShared& sh, const int p, const M
   }
 }
 
+#ifdef RHCCQ_STAMPS
+__device__ unsigned long long g_pipe_stamps[8];          // cycles of the update / draw / inertia role, [3] launches (problem 0)
+#define PIPE_ROLE_END(r) do { if (threadIdx.x == 0 && blockIdx.y == 0) { atomicAdd(&g_pipe_stamps[r], clock64() - _t_pipe); if ((r) == 0) atomicAdd(&g_pipe_stamps[3], 1ull); } } while (0)
+#else
+#define PIPE_ROLE_END(r) do {} while (0)
+#endif
+
 template <int kSplit>
 __global__ __launch_bounds__(kPipeThreads) void mbk_pipe_kernel(const uint32_t* __restrict__ keys, const MbkP* __restrict__ probs,
                                                                 double* __restrict__ centres, double* __restrict__ weights,
@@ -151,8 +158,12 @@ __global__ __launch_bounds__(kPipeThreads) void mbk_pipe_kernel(const uint32_t* 
                                                                 int32_t* __restrict__ pidx, const long long* __restrict__ part_off) {
   __shared__ __align__(16) unsigned char smem[kPipeLds];
   const int p = blockIdx.y, tid = threadIdx.x;
+#ifdef RHCCQ_STAMPS
+  const unsigned long long _t_pipe = clock64();
+#endif
   if (blockIdx.x == 0) {
     lean_update(*reinterpret_cast<LeanShared*>(smem), p, probs, centres, weights, state, step, bkeys_cur, lab_cur + (size_t)p * kBatch);
+    PIPE_ROLE_END(0);
     return;
   }
   const MbkP P = probs[p];
@@ -164,16 +175,19 @@ __global__ __launch_bounds__(kPipeThreads) void mbk_pipe_kernel(const uint32_t* 
     long long cursor = (long long)st[st_slot(kStCursor, dr.draw_first - 1)];
     for (int q = 0; q < dr.draw_count; ++q) {
       const long long b = dr.draw_first + q;
-      cursor = draw_batch(keys, P, words, n_words, cursor, dr.ring[b & 3] + (size_t)p * kBatch, sh.lab, sh.ired, &sh.cursor);
+      // (256 threads x 8 words: one round of the rejection replay covers a batch unless half the candidates are rejected)
+      cursor = draw_batch<8>(keys, P, words, n_words, cursor, dr.ring[b & 3] + (size_t)p * kBatch, sh.lab, sh.ired, &sh.cursor);
       if (cursor < 0) break;
       if (tid == 0) st[st_slot(kStCursor, b)] = (double)cursor;
       __syncthreads();
     }
     if (tid == 0 && cursor < 0) st[4] = 3.0;               // word table exhausted (the host sizes it so that this cannot happen)
+    PIPE_ROLE_END(1);
     return;
   }
   if (blockIdx.x == 2) {
     mbk_inertia_block(P, st, step, pper_cur + (size_t)p * kBatch, nullptr);
+    PIPE_ROLE_END(2);
     return;
   }
   // ---- speculative E-step of step + 1: every centre this step's batch does not touch -----------------------------------------

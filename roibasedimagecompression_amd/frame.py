@@ -472,11 +472,10 @@ class FrameEncoder:
             except BaseException as e:                        # surfaced to the caller below
                 errors.append(e)
 
-        threads = [threading.Thread(target=run, args=(ci,), name=f"rhccq-class{ci}") for ci in range(len(classes))]
-        for t in threads:
-            t.start()
-        for t in threads:
-            t.join()
+        from .ops import lane_pool
+        futs = [lane_pool("class").submit(run, ci) for ci in range(len(classes))]
+        for f in futs:
+            f.result()
         if errors:
             torch.cuda.synchronize(rh.device)                     # (the other class may still be writing the shared tables)
             raise errors[0]

@@ -41,6 +41,23 @@ def _draw_pool():
     return _DRAW_POOL
 
 
+_LANE_POOLS = {}
+
+
+def lane_pool(kind):
+    """Persistent worker threads for the per-problem / per-class pipelines of a frame (one pool per nesting level, so that a
+    class pipeline waiting for its problems never occupies the workers those need): handing a task to a parked worker costs
+    tens of microseconds, starting a thread per problem and frame cost 0.3-0.8 ms each in front of the k-means++ chains."""
+    pool = _LANE_POOLS.get(kind)
+    if pool is None:
+        with _words_lock:
+            pool = _LANE_POOLS.get(kind)
+            if pool is None:
+                from concurrent.futures import ThreadPoolExecutor
+                pool = _LANE_POOLS[kind] = ThreadPoolExecutor(max_workers=16, thread_name_prefix=f"rhccq-{kind}")
+    return pool
+
+
 def pack_rgb(rgb):
     rgb = np.asarray(rgb, dtype=np.uint8).reshape(-1, 3).astype(np.uint32)
     return (rgb[:, 0] << 16) | (rgb[:, 1] << 8) | rgb[:, 2]
@@ -484,7 +501,7 @@ class Rhccq:
     MBK_LANES = 4        # problems of a small batch run as independent pipelines on this many HIP streams
     MBK_OVERLAP = True   # a lone running problem: E-step of step t + 1 beside the update of step t (bit-identical; k8_overlap.h)
     MBK_OVERLAP_MIN_K = 1024
-    MBK_OVERLAP_POLL = 128
+    MBK_OVERLAP_POLL = 64    # steps per overlapped call (the state is looked at one call behind: no drain between the calls)
     MBK_FIRST_POLL = 16
 
     def _lane(self, i):
@@ -534,11 +551,9 @@ class Rhccq:
             except BaseException as e:                        # surfaced to the caller below
                 errors.append(e)
 
-        threads = [threading.Thread(target=run, args=(g,), name=f"rhccq-mbk{g}") for g in range(n_lanes) if groups[g]]
-        for t in threads:
-            t.start()
-        for t in threads:
-            t.join()
+        futs = [lane_pool("mbk").submit(run, g) for g in range(n_lanes) if groups[g]]
+        for f in futs:
+            f.result()
         if errors:
             raise errors[0]
         labs = [None] * n_prob
@@ -563,6 +578,57 @@ class Rhccq:
                           "chosen": np.concatenate([x[2] for x in infos]), "koff": koff, "weights": np.concatenate([x[3] for x in infos]),
                           "overlapped_launches": n_overlapped}
         return labs
+
+    def _overlapped_steps(self, keys, probs, k, n, limit, step, st, cur_max, centres, weights, state, work, wbytes, estep_split, chunk,
+                          words_per_step):
+        """The remaining steps of ONE problem through rhccq_mbk_steps_overlapped, chunk after chunk WITHOUT draining the stream in
+        between: chunk i + 1 is queued before chunk i's state is looked at (an asynchronous copy into pinned memory behind each
+        chunk), so the kernels of a ~2000-step problem run back to back.  Everything the host needs for the next chunk it can
+        derive itself: which steps reassign follows from "samples since the last reassignment" (+ batch per step, reset at
+        10 k), the carry flags come back from the call, and the MT19937 table is sized for all remaining steps up front.  A
+        problem that stops inside chunk i leaves chunk i + 1 as launches that return at once.  Returns (steps launched, state,
+        launches that went through the overlapped entry)."""
+        bs = min(1000, n)
+        par = step & 1
+        since = int(st[0, 12 if par else 3])
+        split = estep_split or next((sp for sp in (1, 2, 4, 8) if ((k + 511) // 512) * 2 * sp >= 1536), 8)
+        # MT19937 words for ALL remaining steps (no regrowth mid-run): a draw of 1000 rows consumes < 2000 words on average even at
+        # the worst acceptance (1/2), a reassigning step (at most one in 10 k / 1000 + the first steps) another ~1400 for its shuffle;
+        # twice that plus the kernels' own end-of-table margins
+        words = self._mt_words_dev(cur_max + (limit - step + 4) * 4200 + 8 * words_per_step)
+        carry = C.c_int32(0)
+        stream = torch.cuda.current_stream(self.device)
+        pending = []                                         # (pinned copy of the state, event) per chunk in flight
+        n_ov = 0
+        while True:
+            if step < limit:
+                ns = int(min(chunk, limit - step))
+                self._check(self.lib.rhccq_mbk_steps_overlapped(self.ctx, self._p(keys), probs, 1, step, ns, self._p(words), words.numel(),
+                                                                self._p(centres), self._p(weights), self._p(state), self._p(work), wbytes,
+                                                                split, since, C.byref(carry)), "mbk_steps_overlapped")
+                for _ in range(ns):                          # the schedule's own arithmetic (sklearn _random_reassign)
+                    since += bs
+                    if since >= 10 * k:
+                        since = 0
+                step += ns
+                n_ov += ns
+                host = torch.empty(state.shape, dtype=state.dtype, pin_memory=True)
+                host.copy_(state, non_blocking=True)
+                ev = torch.cuda.Event()
+                ev.record(stream)
+                pending.append((host, ev))
+            if len(pending) >= 2 or step >= limit:
+                host, ev = pending.pop(0)
+                ev.synchronize()
+                st = host.numpy().copy()
+                if st[0, 4] >= 3 or st[0, 11] != 0 or st[0, 5] >= limit:
+                    break
+                if not pending and step >= limit:
+                    break
+        if pending:                                          # launches queued behind the stop: they return at once
+            pending[-1][1].synchronize()
+            st = pending[-1][0].numpy().copy()
+        return step, st, n_ov
 
     def minibatch_kmeans(self, key_list, k_list, return_info=False, poll_steps=64, return_device=False, timing=None, estep="auto", estep_split=0,
                          lanes=None):
@@ -596,6 +662,19 @@ class Rhccq:
         mtw = self.mtw
         upos = []
 
+        def randint(pos, n, size, want):
+            # (the native loop of rhccq_mt_randint_host: the problems' draws run on several threads, numpy's passes queue on the GIL)
+            win = int(size / (n / (1 << int(n - 1).bit_length())) * 1.05) + 256 if n > 1 else 0
+            out = np.empty(size, np.int32) if want else None
+            while True:
+                w = mtw.ensure(pos + win)
+                used = int(self.lib.rhccq_mt_randint_host(w.ctypes.data, len(w), pos, n, size, out.ctypes.data if want else None))
+                if used >= 0:
+                    return out, used
+                if used != -1:
+                    raise RhccqError("rhccq_mt_randint_host: bad argument")
+                win = 2 * win + 1024
+
         def draw(args):
             n, k = args
             bs = min(1000, n)
@@ -604,15 +683,15 @@ class Rhccq:
                 init_size = 3 * k
             init_size = min(init_size, n)
             pos = 0
-            _, used = mtw.randint(pos, n, init_size)             # validation_indices: stream position only
+            _, used = randint(pos, n, init_size, False)          # validation_indices: stream position only
             pos += used
             if init_size < n:
-                init_idx, used = mtw.randint(pos, n, init_size)
+                init_idx, used = randint(pos, n, init_size, True)
                 pos += used
             else:
-                init_idx = np.arange(n)
+                init_idx = np.arange(n, dtype=np.int32)
             first = first_centre_index(init_size, mtw.double(pos))
-            return init_idx.astype(np.int32), first, pos + 2
+            return init_idx, first, pos + 2
 
         todo = list(zip(sizes, k_list))
         # the numpy passes of a replay release the GIL: the problems' draws run side by side (the GPU waits for them)
@@ -670,42 +749,43 @@ class Rhccq:
         carry = C.c_int32(0)
         st = st0
         n_overlapped = 0
+
+        def check(st):
+            if (st[:, 4] == 3).any():
+                raise RhccqError("mini-batch steps ran past the end of the MT19937 word table (internal sizing error)")
+            if (st[:, 4] == 4).any():
+                raise RhccqError("the sharded k-means++ chain gave up waiting for a partner workgroup (RHCCQ_OPT_INIT_SHARDS = 1 avoids the hand-offs)")
+            if (st[:, 4] == 5).any():
+                raise RhccqError("the overlapped mini-batch schedule and the device state disagree about a reassignment (internal error)")
+
         while running.any():
+            par = step & 1
+            # a lone problem whose centres all carry weight: the next E-step starts beside the update (rhccq_mbk_steps_overlapped)
+            tiles_mode = {"tiles": 1, "grid": 2}.get(estep) or (2 if int(k_arr[running].sum()) >= 200000 else 1)
+            if (self.MBK_OVERLAP and n_prob == 1 and step > 0 and tiles_mode == 1 and k_list[0] >= self.MBK_OVERLAP_MIN_K
+                    and st[0, 13 if par else 8] == 0):
+                step, st, n_ov = self._overlapped_steps(keys, probs, k_list[0], sizes[0], int(limit[0]), step, st, cur_max, centres, weights,
+                                                        state, work, wbytes, estep_split, max(poll_steps, self.MBK_OVERLAP_POLL), WORDS_PER_STEP)
+                n_overlapped += n_ov
+                check(st)
+                break                                        # (the problem has stopped or used up its steps)
             # most problems converge within a dozen steps: look early once, so that a finished problem does not sit through the
             # launches of a whole poll interval
             ns = int(min(poll_steps if step else min(poll_steps, self.MBK_FIRST_POLL), max(1, limit[running].max() - step)))
             # the grid E-step pays when many centres are in flight; once only stragglers are left the tiled
             # brute force has fewer and shorter launches per step
-            mode = {"tiles": 1, "grid": 2}.get(estep) or (2 if int(k_arr[running].sum()) >= 200000 else 1)
+            mode = tiles_mode
             # few workgroups left (a straggler problem): several threads share a batch point in the tiled E-step
             wgs = int(((k_arr[running] + 511) // 512).sum()) * 2
             split = estep_split or next((sp for sp in (1, 2, 4, 8) if wgs * sp >= 1536), 8)
             words = self._mt_words_dev(cur_max + (ns + 3) * WORDS_PER_STEP)     # a step consumes at most WORDS_PER_STEP
-            par = step & 1
-            # a lone problem whose centres all carry weight: the next E-step starts beside the update (rhccq_mbk_steps_overlapped)
-            overlapped = (self.MBK_OVERLAP and n_prob == 1 and step > 0 and mode == 1 and k_list[0] >= self.MBK_OVERLAP_MIN_K
-                          and st[0, 13 if par else 8] == 0)
-            if overlapped:
-                ns = int(min(max(poll_steps, self.MBK_OVERLAP_POLL), max(1, limit[0] - step)))
-                words = self._mt_words_dev(cur_max + (ns + 3) * WORDS_PER_STEP)
-                self._check(self.lib.rhccq_mbk_steps_overlapped(self.ctx, self._p(keys), probs, 1, step, ns, self._p(words), words.numel(),
-                                                                self._p(centres), self._p(weights), self._p(state), self._p(work), wbytes,
-                                                                split, int(st[0, 12 if par else 3]), C.byref(carry)), "mbk_steps_overlapped")
-                n_overlapped += ns
-            else:
-                carry.value = 0
-                self._check(self.lib.rhccq_mbk_steps(self.ctx, self._p(keys), probs, n_prob, step, ns, self._p(words), words.numel(),
-                                                     self._p(centres), self._p(weights), self._p(state), self._p(work), wbytes, mode, split),
-                            "mbk_steps")
+            self._check(self.lib.rhccq_mbk_steps(self.ctx, self._p(keys), probs, n_prob, step, ns, self._p(words), words.numel(),
+                                                 self._p(centres), self._p(weights), self._p(state), self._p(work), wbytes, mode, split),
+                        "mbk_steps")
             step += ns
             st = state.cpu().numpy()
-            if (st[:, 4] == 5).any():
-                raise RhccqError("the overlapped mini-batch schedule and the device state disagree about a reassignment (internal error)")
             cur_max = int(max(st[:, 9].max(), st[:, 14].max()))
-            if (st[:, 4] == 3).any():
-                raise RhccqError("mini-batch steps ran past the end of the MT19937 word table (internal sizing error)")
-            if (st[:, 4] == 4).any():
-                raise RhccqError("the sharded k-means++ chain gave up waiting for a partner workgroup (RHCCQ_OPT_INIT_SHARDS = 1 avoids the hand-offs)")
+            check(st)
             running = (st[:, 11] == 0) & (st[:, 5] < limit)
         labels = self.empty((int(offs[-1]),), torch.int32)
         self._check(self.lib.rhccq_mbk_assign(self.ctx, self._p(keys), probs, n_prob, self._p(centres), self._p(work), wbytes,

@@ -215,6 +215,30 @@ def test_mt_replay_equals_numpy_randomstate():
         assert np.array_equal(m.doubles(pos + 2, count), u)
 
 
+def test_native_randint_replay_equals_numpy_randomstate():
+    """rhccq_mt_randint_host (the host loop the k-means++ set-up calls from several threads) against RandomState(42) itself and
+    against the numpy replay of mt.py: values, words consumed, the position-only form, a table that ends one word early."""
+    from roibasedimagecompression_amd import _lib
+    from roibasedimagecompression_amd.mt import MtWords
+    lib = _lib.load()
+    m = MtWords()
+    for n, size in ((1500000, 90000), (10000, 3000), (65536, 70000), (65537, 100), (3, 10), (1, 5), (2 ** 31 - 5, 1000), (30000, 30000)):
+        rs = np.random.RandomState(42)
+        a, b = rs.randint(0, n, size), rs.randint(0, n, size)
+        _, u1 = m.randint(0, n, size)
+        _, u2 = m.randint(u1, n, size)
+        w = m.ensure(u1 + u2 + 8)
+        o1, o2 = np.empty(size, np.int32), np.empty(size, np.int32)
+        assert lib.rhccq_mt_randint_host(w.ctypes.data, len(w), 0, n, size, o1.ctypes.data) == u1
+        assert lib.rhccq_mt_randint_host(w.ctypes.data, len(w), 0, n, size, None) == u1
+        assert lib.rhccq_mt_randint_host(w.ctypes.data, len(w), u1, n, size, o2.ctypes.data) == u2
+        assert np.array_equal(a, o1) and np.array_equal(b, o2), n
+        if u1:
+            assert lib.rhccq_mt_randint_host(w.ctypes.data, u1 - 1, 0, n, size, None) == -1
+    assert lib.rhccq_mt_randint_host(None, 10, 0, 5, 5, None) == -2
+    assert lib.rhccq_mt_randint_host(w.ctypes.data, len(w), 0, 0, 5, None) == -2
+
+
 def test_hostsort_helpers_equal_numpy():
     """hostsort._stable_order / _unique_first_inverse (one unstable sort of key<<32|position composites) against
     np.argsort(kind="stable") / np.unique(return_index, return_inverse), duplicates included"""

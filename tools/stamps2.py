@@ -19,7 +19,7 @@ k = math.ceil(len(pal) * 0.2 / 10)
 print("N", len(pal), "k", k)
 t = {}
 labs, info = rh.minibatch_kmeans([pal], [k], return_info=True, timing=t)
-print("init ms", t["init_ms"], "us/pick", t["init_ms"] * 1e3 / k)
+print("init ms", t["init_ms"], "us/pick", t["init_ms"] * 1e3 / k, "steps", int(info["state"][0][5]), "overlapped launches", info["overlapped_launches"])
 out = (ctypes.c_ulonglong * 16)()
 rh._raw.rhccq_debug_stamps.argtypes = [ctypes.c_void_p]
 print("rc", rh._raw.rhccq_debug_stamps(out))
@@ -43,3 +43,12 @@ u = np.array(list(out2), dtype=np.float64)
 calls = max(u[15], 1)
 print("update kernel, problem 0: steps", int(calls), "cycles per step: role0", round(u[8] / calls), "role1", round(u[9] / calls), "role2", round(u[10] / calls),
       "| role 0 phases:", [round(x / calls) for x in u[:6]])
+re = max(u[14], 1)
+print("reassigning steps", int(u[14]), "cycles per such step: weights->LDS", round(u[6] / re), "max/hist/select sweeps", round(u[7] / re), "sweep 2", round(u[11] / re),
+      "choice() replay", round(u[12] / re), "sweep 3", round(u[13] / re), "| whole reassignment phase (stamp 4)", round(u[4] / re), "draw behind it (stamp 5)", round(u[5] / re))
+out3 = (ctypes.c_ulonglong * 8)()
+rh._raw.rhccq_debug_pipe_stamps.argtypes = [ctypes.c_void_p]
+print("rc", rh._raw.rhccq_debug_pipe_stamps(out3))
+q = np.array(list(out3), dtype=np.float64)
+n = max(q[3], 1)
+print("overlapped launches", int(q[3]), "cycles per launch: update role", round(q[0] / n), "draw role", round(q[1] / n), "inertia role", round(q[2] / n))
