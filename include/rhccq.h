@@ -46,10 +46,12 @@ const char* rhccq_last_error(const rhccq_ctx* ctx);
  *                              most this many 64-sample blocks (0..4096, default 4096), in global memory beyond;
  *   RHCCQ_OPT_INIT_MAX_ITEMS   capacity of the shared (candidate, block) work list (1..12288, default 12288);
  *                              picks that exceed it evaluate each candidate by its own enumeration instead;
- *   RHCCQ_OPT_INIT_KERNEL      0 (default): the newest k-means++ chain whose tables fit LDS -- third generation (leaves of
- *                              16 samples) up to 98 304 init samples, second generation (blocks of 64) up to 262 144, first
- *                              generation beyond; 1: the first-generation chain always; 2: the second generation whenever its
- *                              tables fit (same picks everywhere; the older chains serve larger problems and as cross-checks);
+ *   RHCCQ_OPT_INIT_KERNEL      0 (default): the k-means++ chain that fits the call -- brute force with the samples in registers
+ *                              up to 3 072 init samples, third generation (leaves of 16 samples, box pruning) up to 98 304,
+ *                              second generation (blocks of 64) up to 262 144, first generation beyond; 1: the first-generation
+ *                              chain always; 2: the second generation whenever its tables fit; 3: third generation even for small
+ *                              samples; 4: the register chain (fails beyond 8 192 samples).  Same picks everywhere; the other
+ *                              chains serve other sizes and as cross-checks;
  *   RHCCQ_OPT_INIT_CANDS_PER_WAVE  third-generation chain: how many of a pick's candidates ONE search wave finds and descends for,
  *                              as interleaved dependency chains of one instruction stream (1, 2 or 3; same picks);
  *   RHCCQ_OPT_INIT_SHARDS      workgroups (CUs) per problem of the second-generation chain: 1 (default) = one; 2 / 4 / 8 =
@@ -240,6 +242,11 @@ int rhccq_mbk_steps(rhccq_ctx* ctx, const uint32_t* keys, const rhccq_mbk_proble
 #define RHCCQ_ESTEP_AUTO 0
 #define RHCCQ_ESTEP_TILES 1
 #define RHCCQ_ESTEP_GRID 2
+/* ORed into estep_mode: the caller has read the state and knows that no running problem reassigns during this call (state[8] /
+ * [13] == 0 and fewer than 10 k samples since the last reassignment throughout): the second launch of a reassigning step
+ * (the centres move, the next batch is drawn behind the shuffle) is left out; a problem that wants to reassign all the same
+ * stops with state[4] = 5 */
+#define RHCCQ_STEPS_NO_REASSIGN 0x100
 int64_t rhccq_mbk_work_bytes(const rhccq_mbk_problem* probs_host, int32_t n_prob);
 /* The same steps for ONE problem (n_prob == 1) that has no zero-weight centre left (state[8] / [13] == 0), with the batch
  * E-step of step t + 1 started BESIDE the update of step t: a step that does not reassign changes only the <= 1000 centres its

@@ -16,11 +16,15 @@
 
 namespace rhccq {
 
+#include "kpp_flat.h"
+
 constexpr int kKmThreads = 1024;
 constexpr int kKmWaves = kKmThreads / 64;
 constexpr int kKmCentLds = 1024;   // centres kept in LDS up to this k
 constexpr int kTMax = 16;
 constexpr int kKmPts = 4;          // points a thread holds in registers per pass of the Lloyd E-step
+constexpr int kKmFlatS = 10;       // k-means++ with every point in a register up to this many points per thread (LDS-resident inputs)
+static_assert(sizeof(FlatShared) <= sizeof(unsigned) * kKmCentLds * 4, "the register k-means++ borrows the member-sum table");
 
 struct KmShared {
   unsigned long long red64[kKmWaves * kTMax];
@@ -68,7 +72,7 @@ __global__ __launch_bounds__(kKmThreads) void kmeans_kernel(const uint32_t* __re
   __shared__ uint32_t s_keys[RHCCQ_KM_LDS_MAX];
   __shared__ uint32_t s_aux[RHCCQ_KM_LDS_MAX];
   __shared__ double s_cent[kKmCentLds * 4];
-  __shared__ unsigned s_sum[kKmCentLds * 4];
+  __shared__ __align__(16) unsigned s_sum[kKmCentLds * 4];
   __shared__ KmShared sh;
 
   const int p = blockIdx.x, tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
@@ -111,81 +115,88 @@ __global__ __launch_bounds__(kKmThreads) void kmeans_kernel(const uint32_t* __re
   const double tol = ((v0 + v1) + v2) / 3.0 * 1e-4;
 
   // ---- k-means++ in exact integers ----------------------------------------------------------
-  const int per = (n + kKmThreads - 1) / kKmThreads;
-  const int lo = min(tid * per, n), hi = min(lo + per, n);
-  unsigned long long pot;
-  {
-    const uint32_t kf = P[first];
-    unsigned long long s = 0;
-    for (int i = tid; i < n; i += kKmThreads) {
-      const unsigned d = (unsigned)dist2_keys(P[i], kf);
-      aux[i] = d;
-      s += d;
-    }
-    pot = block_sum<unsigned long long>(s, sh.red64);
-    if (tid == 0) chosen[0] = first;
-  }
-  for (int c = 1; c < k; ++c) {
-    const double* u = rand + rand_off + (size_t)(c - 1) * T;
-    const double dpot = (double)pot;
-    // cumulative-sum search (np.searchsorted(cumsum(closest), u*pot, 'left'), clipped to n-1)
-    unsigned long long loc = 0;
-    for (int i = lo; i < hi; ++i) loc += aux[i];
-    unsigned long long tot;
-    const unsigned long long base = block_exscan64(loc, sh, &tot);
-    if (tid < T) sh.cand[tid] = (u[tid] * dpot <= 0.0) ? 0 : n - 1;
+  // (up to 10 points per thread: every point in a register, two barriers per pick -- kpp_flat.h; the loop below, a block scan, a
+  // candidate search and a block reduction per pick, ~7 us each, serves larger inputs)
+  if (n <= kKmFlatS * kKmThreads) {
     __syncthreads();
-    if (loc > 0) {
-      for (int t = 0; t < T; ++t) {
-        const double r = u[t] * dpot;
-        if ((double)base < r && r <= (double)(base + loc)) {
-          unsigned long long cum = base;
-          int i = lo;
-          for (; i < hi; ++i) {
-            cum += aux[i];
-            if ((double)cum >= r) break;
+    kpp_flat<kKmFlatS, kKmWaves>([&](int i) { return P[i]; }, n, k, T, first, rand + rand_off, chosen, *reinterpret_cast<FlatShared*>(s_sum));
+  } else {
+    const int per = (n + kKmThreads - 1) / kKmThreads;
+    const int lo = min(tid * per, n), hi = min(lo + per, n);
+    unsigned long long pot;
+    {
+      const uint32_t kf = P[first];
+      unsigned long long s = 0;
+      for (int i = tid; i < n; i += kKmThreads) {
+        const unsigned d = (unsigned)dist2_keys(P[i], kf);
+        aux[i] = d;
+        s += d;
+      }
+      pot = block_sum<unsigned long long>(s, sh.red64);
+      if (tid == 0) chosen[0] = first;
+    }
+    for (int c = 1; c < k; ++c) {
+      const double* u = rand + rand_off + (size_t)(c - 1) * T;
+      const double dpot = (double)pot;
+      // cumulative-sum search (np.searchsorted(cumsum(closest), u*pot, 'left'), clipped to n-1)
+      unsigned long long loc = 0;
+      for (int i = lo; i < hi; ++i) loc += aux[i];
+      unsigned long long tot;
+      const unsigned long long base = block_exscan64(loc, sh, &tot);
+      if (tid < T) sh.cand[tid] = (u[tid] * dpot <= 0.0) ? 0 : n - 1;
+      __syncthreads();
+      if (loc > 0) {
+        for (int t = 0; t < T; ++t) {
+          const double r = u[t] * dpot;
+          if ((double)base < r && r <= (double)(base + loc)) {
+            unsigned long long cum = base;
+            int i = lo;
+            for (; i < hi; ++i) {
+              cum += aux[i];
+              if ((double)cum >= r) break;
+            }
+            sh.cand[t] = i < hi ? i : hi - 1;
           }
-          sh.cand[t] = i < hi ? i : hi - 1;
         }
       }
-    }
-    __syncthreads();
-    // potentials of the T candidates
-    uint32_t ck[kTMax];
-    unsigned long long acc[kTMax];
-#pragma unroll
-    for (int t = 0; t < kTMax; ++t) { acc[t] = 0; ck[t] = t < T ? P[sh.cand[t]] : 0u; }
-    for (int i = tid; i < n; i += kKmThreads) {
-      const uint32_t ki = P[i];
-      const unsigned cl = aux[i];
-#pragma unroll
-      for (int t = 0; t < kTMax; ++t)
-        if (t < T) acc[t] += min(cl, (unsigned)dist2_keys(ki, ck[t]));
-    }
-#pragma unroll
-    for (int t = 0; t < kTMax; ++t) {
-      if (t < T) {
-        const unsigned long long w = wave_sum(acc[t]);
-        if (lane == 0) sh.red64[t * kKmWaves + wave] = w;
+      __syncthreads();
+      // potentials of the T candidates
+      uint32_t ck[kTMax];
+      unsigned long long acc[kTMax];
+  #pragma unroll
+      for (int t = 0; t < kTMax; ++t) { acc[t] = 0; ck[t] = t < T ? P[sh.cand[t]] : 0u; }
+      for (int i = tid; i < n; i += kKmThreads) {
+        const uint32_t ki = P[i];
+        const unsigned cl = aux[i];
+  #pragma unroll
+        for (int t = 0; t < kTMax; ++t)
+          if (t < T) acc[t] += min(cl, (unsigned)dist2_keys(ki, ck[t]));
       }
+  #pragma unroll
+      for (int t = 0; t < kTMax; ++t) {
+        if (t < T) {
+          const unsigned long long w = wave_sum(acc[t]);
+          if (lane == 0) sh.red64[t * kKmWaves + wave] = w;
+        }
+      }
+      __syncthreads();
+      if (tid < T) {
+        unsigned long long s = 0;
+        for (int w = 0; w < kKmWaves; ++w) s += sh.red64[tid * kKmWaves + w];
+        sh.pots[tid] = s;
+      }
+      __syncthreads();
+      int best = 0;
+      unsigned long long bp = sh.pots[0];
+      for (int t = 1; t < T; ++t)
+        if (sh.pots[t] < bp) { bp = sh.pots[t]; best = t; }
+      pot = bp;
+      const int bi = sh.cand[best];
+      const uint32_t kb = P[bi];
+      for (int i = tid; i < n; i += kKmThreads) aux[i] = min(aux[i], (unsigned)dist2_keys(P[i], kb));
+      if (tid == 0) chosen[c] = bi;
+      __syncthreads();
     }
-    __syncthreads();
-    if (tid < T) {
-      unsigned long long s = 0;
-      for (int w = 0; w < kKmWaves; ++w) s += sh.red64[tid * kKmWaves + w];
-      sh.pots[tid] = s;
-    }
-    __syncthreads();
-    int best = 0;
-    unsigned long long bp = sh.pots[0];
-    for (int t = 1; t < T; ++t)
-      if (sh.pots[t] < bp) { bp = sh.pots[t]; best = t; }
-    pot = bp;
-    const int bi = sh.cand[best];
-    const uint32_t kb = P[bi];
-    for (int i = tid; i < n; i += kKmThreads) aux[i] = min(aux[i], (unsigned)dist2_keys(P[i], kb));
-    if (tid == 0) chosen[c] = bi;
-    __syncthreads();
   }
   __threadfence_block();
   __syncthreads();

@@ -1349,6 +1349,33 @@ __global__ __launch_bounds__(kJThreads) void mbk_init2_kernel(const uint32_t* __
 }
 
 #include "k8_init3.h"
+#ifdef RHCCQ_STAMPS
+#define KPP_STAMPS
+#endif
+#include "kpp_flat.h"
+
+// ---- k-means++ chain for small init samples (kpp_flat.h): one workgroup of 512 threads per problem, up to 16 samples per thread ----
+constexpr int kFlatThreads = 512;
+constexpr int kFlatMaxSamples = kFlatThreads * 16;
+template <int kS>
+__global__ __launch_bounds__(kFlatThreads) void mbk_init_flat_kernel(const uint32_t* __restrict__ keys, const MbkP* __restrict__ probs,
+                                                                     const int32_t* __restrict__ init_idx, const double* __restrict__ rand,
+                                                                     double* __restrict__ centres, int32_t* __restrict__ chosen) {
+  __shared__ FlatShared sh;
+  const MbkP P = probs[blockIdx.x];
+  const int n = (int)P.init_n, k = (int)P.k;
+  if (n > kS * kFlatThreads) return;                      // (rhccq_mbk_init picks kS from the largest problem of the call)
+  const int32_t* idx = init_idx + P.init_off;
+  const uint32_t* kp = keys + P.off;
+  int32_t* cho = chosen + P.koff;
+  kpp_flat<kS, kFlatThreads / 64>([&](int i) { return kp[idx[i]]; }, n, k, P.T, P.first, rand + P.rand_off, cho, sh);
+  for (int j = threadIdx.x; j < k; j += kFlatThreads) {
+    const uint32_t kk = kp[idx[cho[j]]];
+    const double c0 = (double)key_r(kk), c1 = (double)key_g(kk), c2 = (double)key_b(kk);
+    double* C = centres + (P.koff + j) * 4;
+    C[0] = c0; C[1] = c1; C[2] = c2; C[3] = km64_csq(c0, c1, c2);
+  }
+}
 
 // ------------------------------------------------------------------------------------------------
 // mini-batch steps
@@ -1448,6 +1475,12 @@ __global__ __launch_bounds__(64) void mbk_inertia_kernel(const MbkP* __restrict_
 // straggler problem still running there are only ~160 workgroups for 256 CUs and a thread's serial walk over 512
 // centres (one wave per SIMD, ~8 cycles per dependent f64 instruction) is the whole step; splitting the walk keeps
 // the arithmetic and the first-arg-min order (lower slices win ties) and shortens the chain.
+#ifdef RHCCQ_STAMPS
+__device__ unsigned long long g_spec_stamps[8];          // speculative E-step, summed over workgroups: load, exclude, loop, merge; [7] workgroups
+#define SSTAMP(slot) do { if (excl_labels != nullptr && threadIdx.x == 0) { const unsigned long long _t = clock64(); atomicAdd(&g_spec_stamps[slot], _t - _sl); _sl = _t; } } while (0)
+#else
+#define SSTAMP(slot) do {} while (0)
+#endif
 template <int kSplit>
 __device__ __forceinline__ void estep_tile(const int bx, const int p, const MbkP& P, const long long po, const double* __restrict__ centres,
                                            const uint32_t* __restrict__ bkeys, double* __restrict__ pdist, int32_t* __restrict__ pidx,
@@ -1460,16 +1493,35 @@ __device__ __forceinline__ void estep_tile(const int bx, const int p, const MbkP
   if (tile >= n_tiles) return;
   const int bs = (int)min((long long)1000, P.n);
   const int j0 = tile * kTileC, nj = (int)min((long long)kTileC, P.k - j0);
+#ifdef RHCCQ_STAMPS
+  unsigned long long _sl = clock64();
+  if (excl_labels != nullptr && threadIdx.x == 0) atomicAdd(&g_spec_stamps[7], 1ull);
+#endif
   int ex[kBatch / 256];                                  // (requested together with the tile)
   if (excl_labels != nullptr) {
 #pragma unroll
     for (int q = 0; q < kBatch / 256; ++q) ex[q] = (int)threadIdx.x + q * 256 < bs ? excl_labels[threadIdx.x + q * 256] - j0 : -1;
   }
-  for (int i = threadIdx.x; i < nj * 4; i += blockDim.x) {
-    const double v = centres[(P.koff + j0) * 4 + i];
-    sc[i] = (i & 3) == 3 ? v : -2.0 * v;               // pre-scale by -2 (exact): dist = csq + dot'
+  {
+    // the tile: all of a thread's loads in flight together (a load -> store loop waited for every one of its 8 reads in turn:
+    // 8 us of a 14 us kernel)
+    constexpr int kLd = kTileC * 2 / 256;                 // 16 bytes per load: (c0, c1) or (c2, csq)
+    const double2* src = reinterpret_cast<const double2*>(centres + (P.koff + j0) * 4);
+    double2 cv[kLd];
+#pragma unroll
+    for (int q = 0; q < kLd; ++q) {
+      const int i = (int)threadIdx.x + q * 256;
+      cv[q] = i < nj * 2 ? src[i] : make_double2(0.0, 0.0);
+    }
+#pragma unroll
+    for (int q = 0; q < kLd; ++q) {
+      const int i = (int)threadIdx.x + q * 256;
+      // pre-scale by -2 (exact): dist = csq + dot'
+      if (i < nj * 2) reinterpret_cast<double2*>(sc)[i] = make_double2(-2.0 * cv[q].x, (i & 1) ? cv[q].y : -2.0 * cv[q].y);
+    }
   }
   __syncthreads();
+  SSTAMP(0);
   if (excl_labels != nullptr) {
     // speculative E-step (k8_overlap.h): the centres these labels name are being rewritten by the update that runs beside this
     // launch -- distance +inf, they are compared at their new values by the next launch
@@ -1478,6 +1530,7 @@ __device__ __forceinline__ void estep_tile(const int bx, const int p, const MbkP
       if (ex[q] >= 0 && ex[q] < nj) sc[ex[q] * 4 + 3] = INFINITY;
     __syncthreads();
   }
+  SSTAMP(1);
   double* pd = pdist + po + (size_t)tile * kBatch;
   int32_t* pi = pidx + po + (size_t)tile * kBatch;
   const int pt = threadIdx.x % kT, slice = threadIdx.x / kT;
@@ -1497,6 +1550,7 @@ __device__ __forceinline__ void estep_tile(const int bx, const int p, const MbkP
       if (d1 < bd1) { bd1 = d1; bj1 = j; }
     }
   }
+  SSTAMP(2);
   if (kSplit > 1) {
     s_bd[threadIdx.x] = bd0; s_bd[256 + threadIdx.x] = bd1;
     s_bj[threadIdx.x] = bj0; s_bj[256 + threadIdx.x] = bj1;
@@ -1514,6 +1568,7 @@ __device__ __forceinline__ void estep_tile(const int bx, const int p, const MbkP
     if (b0 < bs) { pd[b0] = bd0; pi[b0] = j0 + bj0; }
     if (b1 < bs) { pd[b1] = bd1; pi[b1] = j0 + bj1; }
   }
+  SSTAMP(3);
 }
 
 template <int kSplit>
@@ -1525,7 +1580,7 @@ __global__ __launch_bounds__(256) void mbk_batch_estep_kernel(const uint32_t* __
   const int p = blockIdx.y;
   const MbkP P = probs[p];                               // independent table reads, issued together
   const long long po = part_off[p];
-  __shared__ double sc[kTileC * 4];
+  __shared__ __align__(16) double sc[kTileC * 4];
   __shared__ double s_bd[kSplit > 1 ? 512 : 1];
   __shared__ int s_bj[kSplit > 1 ? 512 : 1];
   if (blockIdx.x == gridDim.x - 1) {                     // the extra workgroup: inertia + EWA rule of the PREVIOUS step
@@ -1852,13 +1907,24 @@ __device__ unsigned long long g_upd_stamps[16];
 // sweeps over the weights read an LDS copy when it fits (kLds: the weights are counts, integers below 100 n <= 1.7e9, exact in
 // 32 bits; the copy lives in the member tables of the update, which is over by now: k <= 30 720), otherwise global memory (L2)
 // -- with 20 dependent reads per thread and sweep that was ~50 us of an 80 us step.
-// Returns the MT cursor behind the choice() replay (-1: word table exhausted).
+// The step is split over two launches so that the three chains of a reassigning step run side by side instead of one after the
+// other (~85 us): launch 1 = the update kernel, role 0 selects (reassign_select: everything up to "which centres, how many")
+// while role 1 replays choice() (the shuffle's stream position does not depend on the selection); launch 2
+// (mbk_reassign_apply_kernel) moves the selected centres and, beside that, draws the next batch.  What travels between the
+// launches is a ReSel record per problem.
+struct ReSel {
+  double thr, sel_w, wmin;
+  long long cursor_choice;          // MT cursor behind the shuffle (-1: word table exhausted)
+  int tag_sel, tag_choice;          // step + 1 of the step the two halves belong to
+  int capped, take, n_re, pad;
+  int eq_base[kUpdWaves], rbase[kUpdWaves];
+  int perm[kBatch / 2];             // permutation(batch)[:batch / 2]: more rows are never reassigned
+};
 constexpr size_t kWLdsOff = offsetof(UpdShared, per);
 constexpr int kWLds = (int)((offsetof(UpdShared, perm) - offsetof(UpdShared, per)) / 4);
 template <bool kLds>
-__device__ __forceinline__ long long reassign_phase(UpdShared& sh, double* __restrict__ C, double* __restrict__ W, const int k, const int bs,
-                                                    const uint32_t* __restrict__ words, long long n_words, long long cursor,
-                                                    const long long stage_base, double* st, const long long step, const bool stamp) {
+__device__ __forceinline__ void reassign_select(UpdShared& sh, const double* __restrict__ W, const int k, const int bs, ReSel* __restrict__ rs,
+                                                const long long step, const bool stamp) {
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
 #ifdef RHCCQ_STAMPS
   unsigned long long _rl = clock64();
@@ -1967,41 +2033,13 @@ __device__ __forceinline__ long long reassign_phase(UpdShared& sh, double* __res
   int rbase = 0, n_re = 0;
   for (int w = 0; w < kUpdWaves; ++w) { if (w < wave) rbase += sh.wsel[w]; n_re += sh.wsel[w]; }
   RSTAMP(11);
-  if (n_re > 0) {
-    // new_centers = random_state.choice(batch, replace=False, size=n_reassigns): rows of the batch
-    cursor = replay_permutation(words, n_words, cursor, bs, n_re, sh, stage_base);
+  if (lane == 0) { rs->eq_base[wave] = eq_base; rs->rbase[wave] = rbase; }
+  if (tid == 0) {
+    rs->thr = thr; rs->sel_w = sel_w; rs->wmin = wmin;
+    rs->capped = capped ? 1 : 0; rs->take = take; rs->n_re = n_re;
+    rs->tag_sel = (int)(step + 1);
   }
-  RSTAMP(12);
-  if (cursor >= 0) {
-    // sweep 3: apply; count the centres whose weight is still zero afterwards
-    int nzero = 0, r_run = rbase;
-    eq_run = eq_base;
-    RHCCQ_WSWEEP({
-      const bool is_eq = capped && (w < thr) && (w == sel_w);
-      const unsigned long long meq = __ballot(is_eq);
-      const int rank = eq_run + __popcll(meq & ((1ull << lane) - 1ull));
-      const bool sel = j < j1 && reassign_sel(w, thr, capped, sel_w, take, rank);
-      const unsigned long long msel = __ballot(sel);
-      double wf = w;
-      if (sel) {
-        // centers_new[to_reassign] = X[new_centers]: the i-th reassigned centre (ascending index) takes batch row perm[i]
-        const uint32_t kk = sh.bkey[sh.perm[r_run + __popcll(msel & ((1ull << lane) - 1ull))]];
-        const double n0 = (double)key_r(kk), n1 = (double)key_g(kk), n2 = (double)key_b(kk);
-        C[j * 4] = n0; C[j * 4 + 1] = n1; C[j * 4 + 2] = n2;
-        C[j * 4 + 3] = km64_csq(n0, n1, n2);
-        W[j] = wmin;
-        wf = wmin;
-      }
-      nzero += (j < j1) && (wf == 0.0);
-      eq_run += __popcll(meq);
-      r_run += __popcll(msel);
-    })
-    nzero = block_sum_i(nzero, sh);
-    if (tid == 0) st[st_slot(kStNzero, step + 1)] = (double)nzero;
-  }
-  RSTAMP(13);
 #undef RHCCQ_WSWEEP
-  return cursor;
 }
 
 // Where the draws of a launch go (the batches live in a ring of four buffers, batch b in ring[b & 3]):
@@ -2014,6 +2052,7 @@ struct UpdDraws {
   uint32_t* ring[4];
   long long draw_first;
   int draw_count, reassign_draws, expect_reassign, n_prob;
+  ReSel* resel;                      // [n_prob] what a reassigning step hands from the update kernel to mbk_reassign_apply_kernel
 };
 
 __device__ __forceinline__ void mbk_update_body(UpdShared& sh, const int p, const int role, const uint32_t* __restrict__ keys,
@@ -2049,8 +2088,23 @@ __device__ __forceinline__ void mbk_update_body(UpdShared& sh, const int p, cons
     return;
   }
   if (role == 1) {
+    if (do_reassign) {
+      // ---- new_centers = random_state.choice(batch, replace=False, size=n_reassigns) = permutation(batch)[:n_reassigns]: the whole
+      // shuffle is consumed however many rows are taken, so it is replayed beside the selection (role 0) for the batch / 2 rows
+      // that may be needed; if nothing is reassigned the record is ignored (numpy then draws nothing)
+      ReSel* rs = dr.resel + p;
+      long long c = cursor;
+      if (c + kWordsMargin > n_words) c = -1;
+      else {
+        for (int i = tid; i < kStageWords; i += kUpdThreads) sh.stage[i] = words[c + i];
+        __syncthreads();
+        c = replay_permutation(words, n_words, c, bs, bs / 2, sh, c);
+        if (c >= 0 && tid < bs / 2) rs->perm[tid] = sh.perm[tid];
+      }
+      if (tid == 0) { rs->cursor_choice = c; rs->tag_choice = (int)(step + 1); }
+      return;
+    }
     // ---- the batches ahead: minibatch_indices = random_state.randint(0, n_samples, batch_size) ------------
-    if (do_reassign) return;                             // the stream position depends on this step's choice(): role 0 draws
     for (int q = 0; q < dr.draw_count; ++q) {
       const long long b = dr.draw_first + q;
       cursor = draw_batch(keys, P, words, n_words, cursor, dr.ring[b & 3] + (size_t)p * kBatch, sh.lab, sh.ired, &sh.cursor);
@@ -2075,9 +2129,6 @@ __device__ __forceinline__ void mbk_update_body(UpdShared& sh, const int p, cons
   double* C = centres + P.koff * 4;
   double* W = weights + P.koff;
   const uint32_t* bkeys_p = bkeys_cur + (size_t)p * kBatch;
-  if (do_reassign) {                                     // the words a shuffle would read: requested now, needed much later
-    for (int i = tid; i < kStageWords; i += kUpdThreads) sh.stage[i] = words[cursor + i];
-  }
   for (int i = tid; i < kHashSlots; i += kUpdThreads) { sh.hkey[i] = -1; sh.hcnt[i] = 0; }
   // ---- labels of the batch (the E-step kernels leave the folded arg-min in the slot of tile 0) ------------
   double cb0 = 0.0, cb1 = 0.0, cb2 = 0.0, wb = 0.0;
@@ -2155,25 +2206,15 @@ __device__ __forceinline__ void mbk_update_body(UpdShared& sh, const int p, cons
 #ifdef RHCCQ_STAMPS
     if (tid == 0 && p == 0) atomicAdd(&g_upd_stamps[14], 1ull);
 #endif
-    if (k <= kWLds && P.n <= (1ll << 24))
-      cursor = reassign_phase<true>(sh, C, W, k, bs, words, n_words, cursor, (long long)st_cursor, st, step, p == 0);
-    else
-      cursor = reassign_phase<false>(sh, C, W, k, bs, words, n_words, cursor, (long long)st_cursor, st, step, p == 0);
+    if (k <= kWLds && P.n <= (1ll << 24)) reassign_select<true>(sh, W, k, bs, dr.resel + p, step, p == 0);
+    else reassign_select<false>(sh, W, k, bs, dr.resel + p, step, p == 0);
   }
   USTAMP(4);
   // ---- a step that reassigned draws the next batch itself (role 2 stood back) -------------------------------------
-  if (do_reassign) {
-    for (int q = 0; q < dr.reassign_draws && cursor >= 0; ++q) {
-      const long long b = step + 1 + q;
-      cursor = draw_batch(keys, P, words, n_words, cursor, dr.ring[b & 3] + (size_t)p * kBatch, sh.lab, sh.ired, &sh.cursor);
-      if (cursor >= 0 && tid == 0) st[st_slot(kStCursor, b)] = (double)cursor;
-      __syncthreads();
-    }
-  }
+  // (a step that reassigns: the centres move, the zero-weight count and the next batch follow in mbk_reassign_apply_kernel)
   if (tid == 0) {
     st[st_slot(kStSince, step + 1)] = since;
     if (!do_reassign) st[st_slot(kStNzero, step + 1)] = st_nzero;        // (0: it stays 0)
-    if (do_reassign && cursor < 0) st[4] = 3.0;          // cannot happen within kWordsMargin
   }
   USTAMP(5);
   if (tid == 0) ROLE_END(0);
@@ -2190,6 +2231,84 @@ __global__ __launch_bounds__(kUpdThreads) void mbk_update_kernel(const uint32_t*
   const int p = blockIdx.x;
   mbk_update_body(sh, p, (int)blockIdx.y, keys, probs, centres, weights, state, step, words, n_words, bkeys_cur, dr,
                   lab != nullptr ? lab + (size_t)p * kBatch : pidx + part_off[p]);
+}
+
+// Launch 2 of a reassigning step (see ReSel): role 0 moves the selected centres to their batch rows (sklearn _mini_batch_step:
+// centers_new[to_reassign] = X[new_centers]; weight_sums[to_reassign] = min(weight_sums[~to_reassign])) and counts the centres
+// that still have no weight; role 1 draws the next batch(es) behind the shuffle.  A step that did not reassign left no record
+// with its tag: both roles return at once.
+struct ApplyShared {
+  int perm[kBatch / 2];
+  uint32_t bkey[kBatch];
+  int out[kBatch];
+  int ired[kUpdWaves + 1];
+  long long cursor;
+};
+__global__ __launch_bounds__(kUpdThreads) void mbk_reassign_apply_kernel(const uint32_t* __restrict__ keys, const MbkP* __restrict__ probs,
+                                                                         double* __restrict__ centres, double* __restrict__ weights,
+                                                                         double* __restrict__ state, long long step,
+                                                                         const uint32_t* __restrict__ words, long long n_words,
+                                                                         const uint32_t* __restrict__ bkeys_cur, UpdDraws dr) {
+  __shared__ ApplyShared sh;
+  const int p = blockIdx.x, role = blockIdx.y, tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  double* st = state + p * kStateStride;
+  const MbkP P = probs[p];
+  const ReSel* rs = dr.resel + p;
+  const int tag_sel = rs->tag_sel, tag_choice = rs->tag_choice, n_re = rs->n_re;
+  const long long cursor_choice = rs->cursor_choice;
+  if (mbk_stopped(st, step, P.n) || tag_sel != (int)(step + 1)) return;
+  const int k = (int)P.k;
+  const int bs = (int)min((long long)1000, P.n);
+  if (n_re > 0 && (tag_choice != (int)(step + 1) || cursor_choice < 0)) {      // the shuffle ran out of words (cannot happen
+    if (tid == 0) st[4] = 3.0;                                                 // within kWordsMargin)
+    return;
+  }
+  if (role == 1) {
+    long long cursor = n_re > 0 ? cursor_choice : (long long)st[st_slot(kStCursor, step)];
+    for (int q = 0; q < dr.reassign_draws && cursor >= 0; ++q) {
+      const long long b = step + 1 + q;
+      cursor = draw_batch(keys, P, words, n_words, cursor, dr.ring[b & 3] + (size_t)p * kBatch, sh.out, sh.ired, &sh.cursor);
+      if (cursor >= 0 && tid == 0) st[st_slot(kStCursor, b)] = (double)cursor;
+      __syncthreads();
+    }
+    if (tid == 0 && cursor < 0) st[4] = 3.0;
+    return;
+  }
+  double* C = centres + P.koff * 4;
+  double* W = weights + P.koff;
+  const double thr = rs->thr, sel_w = rs->sel_w, wmin = rs->wmin;
+  const bool capped = rs->capped != 0;
+  const int take = rs->take;
+  if (tid < bs / 2) sh.perm[tid] = n_re > 0 ? rs->perm[tid] : 0;
+  if (tid < bs) sh.bkey[tid] = bkeys_cur[(size_t)p * kBatch + tid];
+  __syncthreads();
+  const int R = (((k + kUpdWaves - 1) / kUpdWaves) + 63) & ~63;
+  const int j0 = wave * R, j1 = min(j0 + R, k);
+  int nzero = 0, r_run = rs->rbase[wave], eq_run = rs->eq_base[wave];
+  for (int jb = j0; jb < j1; jb += 64) {
+    const int j = jb + lane;
+    const double w = j < j1 ? W[j] : INFINITY;
+    const bool is_eq = capped && (w < thr) && (w == sel_w);
+    const unsigned long long meq = __ballot(is_eq);
+    const int rank = eq_run + __popcll(meq & ((1ull << lane) - 1ull));
+    const bool sel = j < j1 && reassign_sel(w, thr, capped, sel_w, take, rank);
+    const unsigned long long msel = __ballot(sel);
+    double wf = w;
+    if (sel) {
+      // the i-th reassigned centre (ascending index) takes batch row perm[i]
+      const uint32_t kk = sh.bkey[sh.perm[r_run + __popcll(msel & ((1ull << lane) - 1ull))]];
+      const double n0 = (double)key_r(kk), n1 = (double)key_g(kk), n2 = (double)key_b(kk);
+      C[j * 4] = n0; C[j * 4 + 1] = n1; C[j * 4 + 2] = n2;
+      C[j * 4 + 3] = km64_csq(n0, n1, n2);
+      W[j] = wmin;
+      wf = wmin;
+    }
+    nzero += (j < j1) && (wf == 0.0);
+    eq_run += __popcll(meq);
+    r_run += __popcll(msel);
+  }
+  nzero = block_sum<int>(nzero, sh.ired);
+  if (tid == 0) st[st_slot(kStNzero, step + 1)] = (double)nzero;
 }
 
 #include "k8_overlap.h"
@@ -2490,6 +2609,7 @@ int64_t rhccq_mbk_work_bytes(const rhccq_mbk_problem* probs, int32_t n_prob) {
   bytes += align256((size_t)n_prob * (kGridCells + 1) * 4) + align256((size_t)n_prob * kGridCells * 4) + align256(ksum * 4);
   bytes += 2 * align256((size_t)n_prob * kBatch * 4) + 2 * align256((size_t)n_prob * kBatch * 8);
   bytes += 4 * align256((size_t)n_prob * kBatch * 4);     // batches 2, 3 of the ring; the labels of even / odd steps
+  bytes += align256((size_t)n_prob * sizeof(ReSel));        // what a reassigning step hands to its second launch
   return (int64_t)bytes;
 }
 
@@ -2505,6 +2625,7 @@ struct WorkView {
   uint32_t* bkeys[4];     // [n_prob][1024] colours of the batch rows of step s in bkeys[s & 3] (written by the draws)
   double* pper[2];        // [n_prob][1024] the rows' inertia terms of even / odd steps (fold kernel -> mbk_inertia_block)
   int32_t* lab[2];        // [n_prob][1024] labels of even / odd steps (overlapped sequence: mbk_fix_kernel)
+  ReSel* resel;           // [n_prob]
   long long max_k;
 };
 
@@ -2554,13 +2675,15 @@ static int layout_work(rhccq_ctx* ctx, const rhccq_mbk_problem* probs, int n_pro
   v->bkeys[2] = (uint32_t*)base; base += align256((size_t)n_prob * kBatch * 4);
   v->bkeys[3] = (uint32_t*)base; base += align256((size_t)n_prob * kBatch * 4);
   v->lab[0] = (int32_t*)base; base += align256((size_t)n_prob * kBatch * 4);
-  v->lab[1] = (int32_t*)base;
+  v->lab[1] = (int32_t*)base; base += align256((size_t)n_prob * kBatch * 4);
+  v->resel = (ReSel*)base;
   v->max_k = 0;
   for (int i = 0; i < n_prob; ++i) v->max_k = probs[i].k > v->max_k ? probs[i].k : v->max_k;
   if (upload) {
     if (int e = put(ctx, v->probs, hp, sizeof(MbkP) * n_prob)) return e;
     if (int e = put(ctx, v->part_off, hpo, 8 * (size_t)n_prob)) return e;
     if (int e = put(ctx, v->blk_off, hbo, 8 * (size_t)(n_prob + 1))) return e;
+    RHCCQ_HIP(ctx, hipMemsetAsync(v->resel, 0, sizeof(ReSel) * (size_t)n_prob, ctx->stream));   // (no step has the tag 0)
     // the staging string dies at return: make sure the copies have been issued from it
     RHCCQ_HIP(ctx, hipStreamSynchronize(ctx->stream));
   }
@@ -2583,6 +2706,11 @@ int rhccq_debug_wave_stamps(unsigned long long* out64_host) {
 int rhccq_debug_pipe_stamps(unsigned long long* out8_host) {
   if (hipDeviceSynchronize() != hipSuccess) return -2;
   if (hipMemcpyFromSymbol(out8_host, HIP_SYMBOL(g_pipe_stamps), sizeof(unsigned long long) * 8) != hipSuccess) return -2;
+  return 0;
+}
+int rhccq_debug_spec_stamps(unsigned long long* out8_host) {
+  if (hipDeviceSynchronize() != hipSuccess) return -2;
+  if (hipMemcpyFromSymbol(out8_host, HIP_SYMBOL(g_spec_stamps), sizeof(unsigned long long) * 8) != hipSuccess) return -2;
   return 0;
 }
 int rhccq_debug_stamps(unsigned long long* out16_host) {
@@ -2717,8 +2845,21 @@ int rhccq_mbk_init(rhccq_ctx* ctx, const uint32_t* keys, const rhccq_mbk_problem
   for (int i = 0; i < n_prob && lean; ++i) lean = (probs[i].init_n + 63) / 64 <= lds_blocks;
   // third generation (leaves of 16 samples, k8_init3.h) whenever every problem's leaf table fits LDS: init samples <= 98 304,
   // the regime of 4K frames; RHCCQ_OPT_INIT_KERNEL = 2 keeps the second generation (A/B runs, parity tests)
-  bool gen3 = lean && ctx->opt_init_kernel == 0 && ctx->opt_init_shards <= 1 && lds_blocks >= kInitLdsBlocks;
+  bool gen3 = lean && (ctx->opt_init_kernel == 0 || ctx->opt_init_kernel == 3) && ctx->opt_init_shards <= 1 && lds_blocks >= kInitLdsBlocks;
   for (int i = 0; i < n_prob && gen3; ++i) gen3 = probs[i].init_n <= kG3MaxSamples;
+  // the smallest init samples (3 000: every problem with k <= 1 000 -- the segments of a many-segment frame): brute force with the
+  // samples in registers (kpp_flat.h).  MEASURED per pick, same process: 3.2 us against the third generation's 3.7 at 3 000
+  // samples, 3.8-4.0 against 3.5 at 3 600-6 000 (its per-candidate bookkeeping grows with the samples per thread, the third
+  // generation's pruning does not care), hence automatic only up to 3 072 samples; RHCCQ_OPT_INIT_KERNEL = 4 takes it up to 8 192,
+  // = 3 keeps the third generation
+  bool flat = (ctx->opt_init_kernel == 0 || ctx->opt_init_kernel == 4) && ctx->opt_init_shards <= 1 && lds_blocks >= kInitLdsBlocks &&
+              max_items >= kMaxItems;
+  long long flat_n = 0;
+  for (int i = 0; i < n_prob && flat; ++i) {
+    flat = probs[i].init_n <= (ctx->opt_init_kernel == 4 ? kFlatMaxSamples : 6 * kFlatThreads);
+    flat_n = probs[i].init_n > flat_n ? probs[i].init_n : flat_n;
+  }
+  if (ctx->opt_init_kernel == 4 && !flat) return rhccq_fail(ctx, RHCCQ_E_LIMIT, "mbk_init: RHCCQ_OPT_INIT_KERNEL = 4 takes at most 8192 init samples per problem");
   // sharded chain: C workgroups per problem, all resident at once (they wait for each other), so only for a handful of
   // problems; every shard must own at least one draw super-block and the pick number must fit the 24-bit granule tag
   // MEASURED (MI355X, k = 30 000, 90 000 init samples): 4.84 us per pick on one workgroup, 7.7-8.0 us on 2, 4 or 8 -- each of
@@ -2761,7 +2902,15 @@ int rhccq_mbk_init(rhccq_ctx* ctx, const uint32_t* keys, const rhccq_mbk_problem
   if (int e = put(ctx, dof, ho, 8 * (size_t)n_wg)) return e;
   if (nshard > 1) RHCCQ_HIP(ctx, hipMemsetAsync(xch, 0, xbytes, ctx->stream));
   RHCCQ_HIP(ctx, hipStreamSynchronize(ctx->stream));
-  if (gen3) {
+  if (flat) {
+#define RHCCQ_FLAT_LAUNCH(S_) hipLaunchKernelGGL(mbk_init_flat_kernel<S_>, dim3(n_prob), dim3(kFlatThreads), 0, ctx->stream, keys, dp, init_idx, rand, centres, chosen)
+    if (flat_n <= 6 * kFlatThreads) RHCCQ_FLAT_LAUNCH(6);          // (3 000 samples: every problem with k <= 1 000)
+    else if (flat_n <= 8 * kFlatThreads) RHCCQ_FLAT_LAUNCH(8);
+    else if (flat_n <= 10 * kFlatThreads) RHCCQ_FLAT_LAUNCH(10);
+    else if (flat_n <= 12 * kFlatThreads) RHCCQ_FLAT_LAUNCH(12);
+    else RHCCQ_FLAT_LAUNCH(16);
+#undef RHCCQ_FLAT_LAUNCH
+  } else if (gen3) {
     const int mi = max_items < kG3MaxItems ? max_items : kG3MaxItems;
     int cw = ctx->opt_init_cands_per_wave;
     bool t16 = false;                                      // (more than 12 trials cannot occur below 98 304 samples; a fourth candidate per wave is not built)
@@ -2801,6 +2950,11 @@ int rhccq_mbk_steps(rhccq_ctx* ctx, const uint32_t* keys, const rhccq_mbk_proble
   // through the grid; with few problems the tiled brute-force kernel has fewer launches per step
   long long ksum = 0;
   for (int i = 0; i < n_prob; ++i) ksum += probs[i].k;
+  // RHCCQ_STEPS_NO_REASSIGN: the caller has read the state and knows that no running problem reassigns in this call (no centre
+  // without weight, fewer than 10 k samples since the last reassignment throughout): the second launch of a reassigning step is
+  // left out; a problem that wants to reassign all the same stops with code 5
+  const bool no_reassign = (estep_mode & RHCCQ_STEPS_NO_REASSIGN) != 0;
+  estep_mode &= ~RHCCQ_STEPS_NO_REASSIGN;
   if (estep_mode < RHCCQ_ESTEP_AUTO || estep_mode > RHCCQ_ESTEP_GRID) return rhccq_fail(ctx, RHCCQ_E_ARG, "mbk_steps: bad estep_mode");
   if (estep_split != 0 && estep_split != 1 && estep_split != 2 && estep_split != 4 && estep_split != 8)
     return rhccq_fail(ctx, RHCCQ_E_ARG, "mbk_steps: estep_split must be 0, 1, 2, 4 or 8");
@@ -2834,9 +2988,12 @@ int rhccq_mbk_steps(rhccq_ctx* ctx, const uint32_t* keys, const rhccq_mbk_proble
     // arg-min over the centre tiles (tiled E-step) and every row's inertia term against the centres before the update
     hipLaunchKernelGGL(mbk_fold_tiles_kernel, dim3((1000 + 15) / 16, n_prob), dim3(64), 0, ctx->stream, v.probs, (const double*)state, step,
                        (const double*)centres, bk, v.pdist, v.pidx, v.part_off, v.pper[step & 1], use_grid ? 0 : 1);
-    const UpdDraws dr{{v.bkeys[0], v.bkeys[1], v.bkeys[2], v.bkeys[3]}, step + 1, 1, 1, -1, n_prob};
+    const UpdDraws dr{{v.bkeys[0], v.bkeys[1], v.bkeys[2], v.bkeys[3]}, step + 1, 1, 1, no_reassign ? 0 : -1, n_prob, v.resel};
     hipLaunchKernelGGL(mbk_update_kernel, dim3(n_prob, 2), dim3(kUpdThreads), 0, ctx->stream, keys, v.probs, centres, weights, state, step,
                        words, (long long)n_words, bk, dr, (const int32_t*)v.pidx, v.part_off, (const int32_t*)nullptr);
+    if (!no_reassign)
+      hipLaunchKernelGGL(mbk_reassign_apply_kernel, dim3(n_prob, 2), dim3(kUpdThreads), 0, ctx->stream, keys, v.probs, centres, weights, state,
+                         step, words, (long long)n_words, bk, dr);
   }
   if (n_steps > 0)
     hipLaunchKernelGGL(mbk_inertia_kernel, dim3(n_prob), dim3(64), 0, ctx->stream, v.probs, state, step0 + n_steps - 1,
@@ -2878,7 +3035,7 @@ int rhccq_mbk_steps_overlapped(rhccq_ctx* ctx, const uint32_t* keys, const rhccq
   }
   long long drawn = step0 + ((*carry & 1) ? 1 : 0);        // newest batch in the ring
   bool have_spec = (*carry & 2) != 0;
-  UpdDraws dr{{v.bkeys[0], v.bkeys[1], v.bkeys[2], v.bkeys[3]}, 0, 0, 0, 0, n_prob};
+  UpdDraws dr{{v.bkeys[0], v.bkeys[1], v.bkeys[2], v.bkeys[3]}, 0, 0, 0, 0, n_prob, v.resel};
   for (int s = 0; s < n_steps; ++s) {
     const long long step = step0 + s;
     const uint32_t* bk = v.bkeys[step & 3];
@@ -2908,6 +3065,8 @@ int rhccq_mbk_steps_overlapped(rhccq_ctx* ctx, const uint32_t* keys, const rhccq
       drawn = step + dr.reassign_draws;
       hipLaunchKernelGGL(mbk_update_kernel, dim3(n_prob, 2), dim3(kUpdThreads), 0, ctx->stream, keys, v.probs, centres, weights, state, step,
                          words, (long long)n_words, bk, dr, (const int32_t*)v.pidx, v.part_off, (const int32_t*)v.lab[step & 1]);
+      hipLaunchKernelGGL(mbk_reassign_apply_kernel, dim3(n_prob, 2), dim3(kUpdThreads), 0, ctx->stream, keys, v.probs, centres, weights, state,
+                         step, words, (long long)n_words, bk, dr);
       hipLaunchKernelGGL(mbk_inertia_kernel, dim3(n_prob), dim3(64), 0, ctx->stream, v.probs, state, step, (const double*)v.pper[step & 1]);
       have_spec = false;
       continue;

@@ -779,6 +779,13 @@ class Rhccq:
             wgs = int(((k_arr[running] + 511) // 512).sum()) * 2
             split = estep_split or next((sp for sp in (1, 2, 4, 8) if wgs * sp >= 1536), 8)
             words = self._mt_words_dev(cur_max + (ns + 3) * WORDS_PER_STEP)     # a step consumes at most WORDS_PER_STEP
+            if step > 0:
+                # no running problem reassigns during these steps (no centre without weight, fewer than 10 k samples since the last
+                # reassignment throughout): the second launch of a reassigning step is left out (RHCCQ_STEPS_NO_REASSIGN)
+                bs_arr = np.minimum(1000, np.asarray(sizes, np.int64))
+                quiet = (st[:, 13 if par else 8] == 0) & (st[:, 12 if par else 3] + ns * bs_arr < 10 * k_arr)
+                if quiet[running].all():
+                    mode |= 0x100
             self._check(self.lib.rhccq_mbk_steps(self.ctx, self._p(keys), probs, n_prob, step, ns, self._p(words), words.numel(),
                                                  self._p(centres), self._p(weights), self._p(state), self._p(work), wbytes, mode, split),
                         "mbk_steps")

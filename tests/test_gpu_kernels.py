@@ -272,7 +272,7 @@ def test_dct_quant_extension(rh, O, block):
     assert np.array_equal(q.cpu().numpy(), oq)
 
 
-@pytest.mark.parametrize("path", ["default", "tiny_work_list", "small_work_list", "one_candidate_per_wave", "two_candidates_per_wave", "three_candidates_per_wave",
+@pytest.mark.parametrize("path", ["default", "register_chain", "third_generation", "tiny_work_list", "small_work_list", "one_candidate_per_wave", "two_candidates_per_wave", "three_candidates_per_wave",
                                   "three_candidates_per_wave_small_work_list", "second_generation", "second_generation_tiny_work_list",
                                   "first_generation", "first_generation_tiny_work_list", "global_tables"])
 def test_minibatch_init_chain_many_cases(rh, O, path):
@@ -297,8 +297,12 @@ def test_minibatch_init_chain_many_cases(rh, O, path):
         rh.set_option(rh.OPT_INIT_KERNEL, 1)
     if path.startswith("second_generation"):
         rh.set_option(rh.OPT_INIT_KERNEL, 2)
+    if path == "third_generation":                         # (the default for more than 8 192 init samples; here for all sizes)
+        rh.set_option(rh.OPT_INIT_KERNEL, 3)
+    if path == "register_chain":                           # kpp_flat.h: the default up to 8 192 init samples, here forced
+        rh.set_option(rh.OPT_INIT_KERNEL, 4)
     try:
-        _init_chain_cases(rh, O)
+        _init_chain_cases(rh, O, small_only=path == "register_chain")
     finally:
         rh.set_option(rh.OPT_INIT_LDS_BLOCKS, 4096)
         rh.set_option(rh.OPT_INIT_MAX_ITEMS, 12288)
@@ -335,15 +339,18 @@ def test_minibatch_init_chain_sharded(rh, O, shards):
         rh.set_option(rh.OPT_INIT_SHARDS, 1)
 
 
-def _init_chain_cases(rh, O):
+def _init_chain_cases(rh, O, small_only=False):
     import math
     rng = np.random.default_rng(123)
     cases = []
-    for n, hi, k in ((12000, 256, 130), (30000, 256, 900), (45000, 96, 2500), (20000, 40, 400), (70000, 256, 4200), (400000, 256, 9000)):
+    for n, hi, k in ((12000, 256, 130), (30000, 256, 900), (45000, 96, 2500), (20000, 40, 400), (70000, 256, 4200), (400000, 256, 9000),
+                     (26000, 256, 2730), (16000, 30, 1001)):
         P = np.unique(rng.integers(0, hi, (n, 3)).astype(np.uint8), axis=0)
-        if len(P) >= 10000:
+        if len(P) >= 10000 and (not small_only or max(3000, 3 * k) <= 8192):
             cases.append((P, k))
-    labs, info = rh.minibatch_kmeans([O.pack_rgb(P) for P, _ in cases], [k for _, k in cases], return_info=True)
+    # (small_only: one problem per call, so that every call is one the register chain takes -- 3 000 to 8 190 init samples)
+    labs, info = rh.minibatch_kmeans([O.pack_rgb(P) for P, _ in cases], [k for _, k in cases], return_info=True,
+                                      lanes=len(cases) if small_only else None)
     for i, (P, k) in enumerate(cases):
         n = len(P)
         if i == 0:                                         # the numpy statement once, the native one (same picks, G11) for the rest

@@ -58,6 +58,25 @@ frame._merge = wrap(frame._merge, "PY _merge")
 FrameEncoder.level2_finish = staticmethod(wrap(FrameEncoder.level2_finish, "PY level2_finish"))
 FrameEncoder.level3_job = wrap(FrameEncoder.level3_job, "PY level3_job")
 FrameEncoder.finish = wrap(FrameEncoder.finish, "PY finish")
+_ks = Rhccq.kmeans_split
+
+
+def ks(self, key_list, k_list, return_info=False):
+    out, info = _ks(self, key_list, k_list, return_info=True)
+    print("kmeans_split: n", [len(k) for k in key_list], "k", list(k_list), "info (n_iter ...)", info.tolist(), flush=True)
+    return (out, info) if return_info else out
+
+
+Rhccq.kmeans_split = wrap(ks, "PY kmeans_split")
+_ec = Rhccq.eps_components
+
+
+def ec(self, key_list, eps_list, *a, **k):
+    print("eps_components: n", [len(x) for x in key_list], "eps", list(eps_list), flush=True)
+    return _ec(self, key_list, eps_list, *a, **k)
+
+
+Rhccq.eps_components = wrap(ec, "PY eps_components")
 torch.cuda.synchronize()
 T0[0] = time.perf_counter()
 enc.encode(rgb, specs)

@@ -52,3 +52,9 @@ print("rc", rh._raw.rhccq_debug_pipe_stamps(out3))
 q = np.array(list(out3), dtype=np.float64)
 n = max(q[3], 1)
 print("overlapped launches", int(q[3]), "cycles per launch: update role", round(q[0] / n), "draw role", round(q[1] / n), "inertia role", round(q[2] / n))
+out4 = (ctypes.c_ulonglong * 8)()
+rh._raw.rhccq_debug_spec_stamps.argtypes = [ctypes.c_void_p]
+print("rc", rh._raw.rhccq_debug_spec_stamps(out4))
+q = np.array(list(out4), dtype=np.float64)
+n = max(q[7], 1)
+print("speculative E-step workgroups", int(q[7]), "cycles per workgroup: tile load", round(q[0] / n), "exclude", round(q[1] / n), "loop", round(q[2] / n), "merge + store", round(q[3] / n))
