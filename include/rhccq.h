@@ -203,6 +203,12 @@ typedef struct rhccq_mbk_problem {
 int64_t rhccq_mbk_order_bytes(int64_t total_samples);
 int rhccq_mbk_order(rhccq_ctx* ctx, const uint32_t* keys, const rhccq_mbk_problem* probs_host,
                     int32_t n_prob, const int32_t* init_idx, int32_t* perm, void* tmp, int64_t tmp_bytes);
+/* merge_region_components_simple in palette space (encoder/compression/merging.py:8-120), host code: the components are painted
+ * in REVERSED order, every component's entries in the order of their first raster positions fp; a colour gets the index of its
+ * first appearance in that sequence (index 0 = canvas black) and the smallest first position of its members.  Entries with key
+ * 0 or fp >= fp_none do not appear (lut 0).  gkeys / gfp: room for 1 + sum(counts); lut[c]: counts[c] ints.  Pure host code. */
+int rhccq_merge_palettes_host(int32_t n_comp, const uint32_t* const* keys, const int64_t* const* fp, const int32_t* counts,
+                              int64_t fp_none, uint32_t* gkeys, int64_t* gfp, int32_t* const* lut, int64_t* n_out);
 /* RandomState.randint(0, n, size) of numpy's legacy generator replayed ON THE HOST from raw MT19937 words in host memory
  * (masked rejection, one word per attempt): sklearn MiniBatchKMeans draws its validation and init samples this way before
  * k-means++ (clustering.py:207-218 -> _kmeans.py MiniBatchKMeans.fit).  out: int32[size] or NULL (stream position only).

@@ -1,6 +1,7 @@
 // Context management and host-only entry points of librhccq_hip.so.
 #include <cmath>
 #include <cstring>
+#include <vector>
 
 #include "rhccq_common.h"
 
@@ -113,6 +114,97 @@ int rhccq_eps_threshold(double eps, int32_t* thr_host, int32_t* boundary_host, d
     *thr_host = (int32_t)ip;
     *boundary_host = -1;
   }
+  return 0;
+}
+
+// merge_region_components_simple in palette space (encoder/compression/merging.py:8-120) on the host: the components' palettes
+// are painted in REVERSED order, every component's entries in the order of their first raster positions; a colour gets the
+// index of its first appearance in that sequence (0 = canvas black), the merged first position of an index is the smallest
+// of its members'.  keys[c] / fp[c]: counts[c] entries; entries with key 0 or fp >= fp_none do not appear.
+// Out: gkeys[0] = 0 and the merged palette behind it, gfp (fp_none for index 0), lut[c][i] = merged index of entry i (0 when it
+// does not appear); *n_out = merged entries including index 0.  Streaming radix passes instead of five numpy sorts (2-3 ms per
+// class of a 4K frame, on the critical path between level 1 and level 2).  Pure host code.
+int rhccq_merge_palettes_host(int32_t n_comp, const uint32_t* const* keys, const int64_t* const* fp, const int32_t* counts, int64_t fp_none,
+                              uint32_t* gkeys, int64_t* gfp, int32_t* const* lut, int64_t* n_out) {
+  if (n_comp < 0 || !counts || !gkeys || !gfp || !n_out || (n_comp > 0 && (!keys || !fp || !lut))) return RHCCQ_E_ARG;
+  size_t total = 0;
+  for (int c = 0; c < n_comp; ++c) {
+    if (counts[c] < 0 || (counts[c] > 0 && (!keys[c] || !fp[c] || !lut[c]))) return RHCCQ_E_ARG;
+    total += (size_t)counts[c];
+  }
+  // 1. the painting sequence: components reversed, entries by first position (LSD radix on the position bits in use)
+  std::vector<uint64_t> ord, tmp;
+  std::vector<uint32_t> skey;                              // colour of sequence entry s
+  std::vector<int64_t> sfp;
+  std::vector<int32_t*> slot;                              // where its merged index goes
+  skey.reserve(total); sfp.reserve(total); slot.reserve(total);
+  for (int c = n_comp - 1; c >= 0; --c) {
+    const uint32_t* k = keys[c];
+    const int64_t* f = fp[c];
+    const int32_t m = counts[c];
+    if (m >= (1 << 24)) return RHCCQ_E_LIMIT;
+    ord.clear();
+    for (int32_t i = 0; i < m; ++i) {
+      lut[c][i] = 0;
+      if (k[i] != 0u && f[i] < fp_none) {
+        if (f[i] < 0 || f[i] >= (1ll << 40)) return RHCCQ_E_ARG;
+        ord.push_back(((uint64_t)f[i] << 24) | (uint64_t)(uint32_t)i);     // first positions of distinct entries are distinct
+      }
+    }
+    uint64_t top = 0;
+    for (uint64_t v : ord) top |= v >> 24;
+    tmp.resize(ord.size());
+    for (int shift = 24; (top >> (shift - 24)) != 0; shift += 11) {
+      size_t cnt[2049] = {0};
+      for (uint64_t v : ord) ++cnt[((v >> shift) & 2047) + 1];
+      for (int b = 0; b < 2048; ++b) cnt[b + 1] += cnt[b];
+      for (uint64_t v : ord) tmp[cnt[(v >> shift) & 2047]++] = v;
+      ord.swap(tmp);
+    }
+    for (uint64_t v : ord) {
+      const int32_t i = (int32_t)(v & 0xffffffu);
+      skey.push_back(k[i]); sfp.push_back(f[i]); slot.push_back(&lut[c][i]);
+    }
+  }
+  // 2. equal colours next to each other, sequence order kept inside a run (stable LSD radix over the 24 colour bits): streaming
+  // passes only -- a hash table of this size (1 MB) cost a cache miss per entry
+  const size_t M = skey.size();
+  if (M >= (1ull << 32)) return RHCCQ_E_LIMIT;
+  std::vector<uint64_t> a(M), b2(M);
+  for (size_t q = 0; q < M; ++q) a[q] = ((uint64_t)skey[q] << 32) | (uint64_t)q;
+  for (int shift = 32; shift < 56; shift += 8) {
+    size_t cnt[257] = {0};
+    for (uint64_t v : a) ++cnt[((v >> shift) & 255) + 1];
+    for (int q = 0; q < 256; ++q) cnt[q + 1] += cnt[q];
+    for (uint64_t v : a) b2[cnt[(v >> shift) & 255]++] = v;
+    a.swap(b2);
+  }
+  // 3. a run's first member is the colour's first appearance; appearances in sequence order number the merged palette
+  std::vector<uint32_t> leader(M);                         // sequence entry -> sequence entry of its colour's first appearance
+  for (size_t q = 0; q < M;) {
+    const uint32_t key = (uint32_t)(a[q] >> 32), lead = (uint32_t)a[q];
+    size_t e = q;
+    while (e < M && (uint32_t)(a[e] >> 32) == key) leader[(uint32_t)a[e++]] = lead;
+    q = e;
+  }
+  std::vector<int32_t> rank(M);
+  gkeys[0] = 0u;
+  gfp[0] = fp_none;
+  int64_t n = 1;
+  for (size_t q = 0; q < M; ++q) {
+    if (leader[q] == q) {
+      rank[q] = (int32_t)n;
+      gkeys[n] = skey[q];
+      gfp[n] = sfp[q];
+      ++n;
+    }
+  }
+  for (size_t q = 0; q < M; ++q) {
+    const int32_t g = rank[leader[q]];
+    *slot[q] = g;
+    if (sfp[q] < gfp[g]) gfp[g] = sfp[q];
+  }
+  *n_out = n;
   return 0;
 }
 

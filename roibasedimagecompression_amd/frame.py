@@ -81,36 +81,36 @@ def _scatter_min(n, idx, val, out=None):
 
 
 def _merge(comps, bbox):
-    """merge_region_components_simple in palette space (merging.py:8-120)."""
+    """merge_region_components_simple in palette space (merging.py:8-120): one native hash pass (rhccq_merge_palettes_host)."""
     if not comps:
         return None
     if len(comps) == 1:
         return comps[0]
-    seqs, sel = [], []
-    for c in reversed(comps):
-        valid = np.nonzero((c.keys != 0) & (c.fp < _FP_NONE))[0]
-        v = valid[_stable_order(c.fp[valid])]                 # first positions of distinct entries are distinct
-        sel.append(v)
-        seqs.append(c.keys[v])
-    allk = np.concatenate(seqs) if seqs else np.zeros(0, np.uint32)
-    u, first, inv = _unique_first_inverse(allk)
-    order = np.argsort(first)                                 # distinct values: any sort gives the same order
-    gkeys = np.concatenate([np.zeros(1, np.uint32), u[order]])
-    rank = np.empty(len(u), np.int64)
-    rank[order] = np.arange(1, len(u) + 1)
-    gidx = rank[inv.reshape(-1)]                              # global index of every listed entry, in allk order
-    gfp = np.full(len(gkeys), _FP_NONE, np.int64)
+    import ctypes as C
+    from . import _lib
+    lib = _lib.load()
+    n = len(comps)
+    keys = [np.ascontiguousarray(c.keys, dtype=np.uint32) for c in comps]
+    fps = [np.ascontiguousarray(c.fp, dtype=np.int64) for c in comps]
+    luts = [np.empty(len(k), np.int32) for k in keys]
+    counts = np.array([len(k) for k in keys], np.int32)
+    total = int(counts.sum())
+    gkeys = np.empty(total + 1, np.uint32)
+    gfp = np.empty(total + 1, np.int64)
+    n_out = C.c_int64(0)
+    pk = (C.c_void_p * n)(*[k.ctypes.data for k in keys])
+    pf = (C.c_void_p * n)(*[f.ctypes.data for f in fps])
+    pl = (C.c_void_p * n)(*[l.ctypes.data for l in luts])
+    rc = lib.rhccq_merge_palettes_host(n, pk, pf, counts.ctypes.data, int(_FP_NONE), gkeys.ctypes.data, gfp.ctypes.data, pl, C.byref(n_out))
+    if rc != 0:
+        raise RuntimeError(f"rhccq_merge_palettes_host failed ({rc})")
+    m = int(n_out.value)
     maps = {}
-    off = len(allk)
-    for c, v in zip(comps, reversed(sel)):                    # comps in their own order; allk holds them reversed
-        off -= len(v)
-        lut = np.zeros(len(c.keys), np.int32)                 # black / unused -> canvas 0
-        lut[v] = gidx[off:off + len(v)]
-        _scatter_min(len(gfp), lut[v], c.fp[v], out=gfp)
-        for job, m in c.maps.items():
-            maps[job] = lut[m]
+    for c, lut in zip(comps, luts):
+        for job, mp in c.maps.items():
+            maps[job] = lut[mp]
     minr, minc, maxr, maxc = bbox
-    return _Comp(gkeys, gfp, (minr, minc), (maxr - minr, maxc - minc), maps, True)
+    return _Comp(gkeys[:m].copy(), gfp[:m].copy(), (minr, minc), (maxr - minr, maxc - minc), maps, True)
 
 
 class FrameEncoder:

@@ -239,6 +239,56 @@ def test_native_randint_replay_equals_numpy_randomstate():
     assert lib.rhccq_mt_randint_host(w.ctypes.data, len(w), 0, 0, 5, None) == -2
 
 
+def test_native_palette_merge_equals_the_numpy_statement():
+    """rhccq_merge_palettes_host (frame._merge) against the numpy statement of merge_region_components_simple in palette space
+    it replaced: components painted in reversed order, entries by first position, first appearance numbers the colours, the
+    smallest first position survives; black and unseen entries map to the canvas."""
+    from roibasedimagecompression_amd import frame
+    from roibasedimagecompression_amd.hostsort import _stable_order, _unique_first_inverse
+    NONE = int(frame._FP_NONE)
+
+    def numpy_merge(comps):
+        seqs, sel = [], []
+        for c in reversed(comps):
+            valid = np.nonzero((c.keys != 0) & (c.fp < NONE))[0]
+            v = valid[_stable_order(c.fp[valid])]
+            sel.append(v)
+            seqs.append(c.keys[v])
+        allk = np.concatenate(seqs)
+        u, first, inv = _unique_first_inverse(allk)
+        order = np.argsort(first)
+        gkeys = np.concatenate([np.zeros(1, np.uint32), u[order]])
+        rank = np.empty(len(u), np.int64)
+        rank[order] = np.arange(1, len(u) + 1)
+        gidx = rank[inv.reshape(-1)]
+        gfp = np.full(len(gkeys), NONE, np.int64)
+        maps, off = {}, len(allk)
+        for c, v in zip(comps, reversed(sel)):
+            off -= len(v)
+            lut = np.zeros(len(c.keys), np.int32)
+            lut[v] = gidx[off:off + len(v)]
+            np.minimum.at(gfp, lut[v], c.fp[v])
+            for job, m in c.maps.items():
+                maps[job] = lut[m]
+        return gkeys, gfp, maps
+
+    rng = np.random.default_rng(9)
+    for trial in range(6):
+        comps = []
+        for j in range(int(rng.integers(2, 5))):
+            K = int(rng.integers(1, 4000))
+            keys = rng.integers(0, 3000 if trial % 2 else 1 << 24, K).astype(np.uint32)
+            keys = np.unique(keys)                                   # a palette: distinct colours (possibly black)
+            rng.shuffle(keys)
+            fp = rng.permutation(1 << 22)[:len(keys)].astype(np.int64)
+            fp[rng.random(len(keys)) < 0.1] = NONE                   # entries no pixel shows
+            comps.append(frame._Comp(keys, fp, (0, 0), (1, 1), {j: rng.integers(0, len(keys), 500).astype(np.int32)}, False))
+        got = frame._merge(comps, (0, 0, 10, 10))
+        gk, gf, maps = numpy_merge(comps)
+        assert np.array_equal(got.keys, gk) and np.array_equal(got.fp, gf)
+        assert set(got.maps) == set(maps) and all(np.array_equal(got.maps[j], maps[j]) for j in maps)
+
+
 def test_hostsort_helpers_equal_numpy():
     """hostsort._stable_order / _unique_first_inverse (one unstable sort of key<<32|position composites) against
     np.argsort(kind="stable") / np.unique(return_index, return_inverse), duplicates included"""
