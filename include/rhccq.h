@@ -163,8 +163,9 @@ int rhccq_eps_border(rhccq_ctx* ctx, const uint32_t* keys, int32_t n, int32_t th
                      int32_t* labels_out);
 
 /* ---- K2: per-cluster floor-mean colour (clustering.py:304-310,346-355) ----------------------
- * sums[k*4] (uint64 r,g,b,count) zero-initialised by the caller; labels < 0 are skipped. */
-int rhccq_cluster_sums(rhccq_ctx* ctx, const uint32_t* keys, const int32_t* labels, int64_t n,
+ * sums[k*4] (uint64 r,g,b,count) zero-initialised by the caller (one call per buffer: up to 2^24 points the sums are gathered
+ * as two packed words per label and spread over the four fields at the end); labels in [0, k) or < 0 (skipped). */
+int rhccq_cluster_sums(rhccq_ctx* ctx, const uint32_t* keys, const int32_t* labels, int64_t n, int64_t k,
                        unsigned long long* sums);
 int rhccq_cluster_means(rhccq_ctx* ctx, const unsigned long long* sums, int64_t k, uint32_t* keys_out);
 

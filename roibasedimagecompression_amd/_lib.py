@@ -53,7 +53,7 @@ PROTOTYPES = {
     "rhccq_frame_remap_ranked": (c_int32, [c_void_p, c_int32, c_int32, c_int32, C.POINTER(c_void_p), C.POINTER(c_int32), c_void_p, c_void_p, c_void_p, c_void_p,
                                            c_int32, c_void_p, c_int32]),
     "rhccq_eps_components": (c_int32, [c_void_p, c_void_p, c_void_p, c_void_p, c_int32, c_int32, c_void_p, c_void_p]),
-    "rhccq_cluster_sums": (c_int32, [c_void_p, c_void_p, c_void_p, c_int64, c_void_p]),
+    "rhccq_cluster_sums": (c_int32, [c_void_p, c_void_p, c_void_p, c_int64, c_int64, c_void_p]),
     "rhccq_cluster_means": (c_int32, [c_void_p, c_void_p, c_int64, c_void_p]),
     "rhccq_kmeans": (c_int32, [c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_int32, c_int32, c_void_p, c_void_p, c_void_p]),
     "rhccq_mbk_init": (c_int32, [c_void_p, c_void_p, C.POINTER(MbkProblem), c_int32, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p]),

@@ -492,7 +492,7 @@ class Rhccq:
     def cluster_means(self, keys, labels, k):
         """floor-mean colour per label: keys int32[n] device, labels int32[n] device -> int32[k] keys."""
         sums = self.zeros((max(k, 1), 4), torch.int64)
-        self._check(self.lib.rhccq_cluster_sums(self.ctx, self._p(keys), self._p(labels), keys.numel(), self._p(sums)), "cluster_sums")
+        self._check(self.lib.rhccq_cluster_sums(self.ctx, self._p(keys), self._p(labels), keys.numel(), max(k, 1), self._p(sums)), "cluster_sums")
         out = self.empty((max(k, 1),), torch.int32)
         self._check(self.lib.rhccq_cluster_means(self.ctx, self._p(sums), k, self._p(out)), "cluster_means")
         return out[:k], sums[:k]
