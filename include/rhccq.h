@@ -46,12 +46,12 @@ const char* rhccq_last_error(const rhccq_ctx* ctx);
  *                              most this many 64-sample blocks (0..4096, default 4096), in global memory beyond;
  *   RHCCQ_OPT_INIT_MAX_ITEMS   capacity of the shared (candidate, block) work list (1..12288, default 12288);
  *                              picks that exceed it evaluate each candidate by its own enumeration instead;
- *   RHCCQ_OPT_INIT_KERNEL      0 (default): the k-means++ chain that fits the call -- brute force with the samples in registers
- *                              up to 3 072 init samples, third generation (leaves of 16 samples, box pruning) up to 98 304,
- *                              second generation (blocks of 64) up to 262 144, first generation beyond; 1: the first-generation
- *                              chain always; 2: the second generation whenever its tables fit; 3: third generation even for small
- *                              samples; 4: the register chain (fails beyond 8 192 samples).  Same picks everywhere; the other
- *                              chains serve other sizes and as cross-checks;
+ *   RHCCQ_OPT_INIT_KERNEL      0 (default): the newest k-means++ chain whose tables fit LDS -- third generation (leaves of 16
+ *                              samples, box pruning) up to 98 304 init samples, second generation (blocks of 64) up to 262 144,
+ *                              first generation beyond; 1: the first-generation chain always; 2: the second generation whenever
+ *                              its tables fit; 3: same as 0; 4: brute force with the samples in registers (kpp_flat.h, at most
+ *                              8 192 init samples; the chain KMeans uses).  Same picks everywhere; the other chains serve other
+ *                              sizes and as cross-checks;
  *   RHCCQ_OPT_INIT_CANDS_PER_WAVE  third-generation chain: how many of a pick's candidates ONE search wave finds and descends for,
  *                              as interleaved dependency chains of one instruction stream (1, 2 or 3; same picks);
  *   RHCCQ_OPT_INIT_SHARDS      workgroups (CUs) per problem of the second-generation chain: 1 (default) = one; 2 / 4 / 8 =

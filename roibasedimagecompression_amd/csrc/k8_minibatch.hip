@@ -2847,16 +2847,15 @@ int rhccq_mbk_init(rhccq_ctx* ctx, const uint32_t* keys, const rhccq_mbk_problem
   // the regime of 4K frames; RHCCQ_OPT_INIT_KERNEL = 2 keeps the second generation (A/B runs, parity tests)
   bool gen3 = lean && (ctx->opt_init_kernel == 0 || ctx->opt_init_kernel == 3) && ctx->opt_init_shards <= 1 && lds_blocks >= kInitLdsBlocks;
   for (int i = 0; i < n_prob && gen3; ++i) gen3 = probs[i].init_n <= kG3MaxSamples;
-  // the smallest init samples (3 000: every problem with k <= 1 000 -- the segments of a many-segment frame): brute force with the
-  // samples in registers (kpp_flat.h).  MEASURED per pick, same process: 3.2 us against the third generation's 3.7 at 3 000
-  // samples, 3.8-4.0 against 3.5 at 3 600-6 000 (its per-candidate bookkeeping grows with the samples per thread, the third
-  // generation's pruning does not care), hence automatic only up to 3 072 samples; RHCCQ_OPT_INIT_KERNEL = 4 takes it up to 8 192,
-  // = 3 keeps the third generation
-  bool flat = (ctx->opt_init_kernel == 0 || ctx->opt_init_kernel == 4) && ctx->opt_init_shards <= 1 && lds_blocks >= kInitLdsBlocks &&
-              max_items >= kMaxItems;
+  // brute force with the samples in registers (kpp_flat.h): RHCCQ_OPT_INIT_KERNEL = 4 only.  MEASURED per pick: alone on the
+  // chip 3.2 us at 3 000 init samples (every problem with k <= 3 000) against the third generation's 3.5-3.7, 3.8-4.0 at
+  // 3 600-6 000; INSIDE a 4K frame 5.2 us (profiles/r03: its 512 threads share their CU with the other class's step kernels,
+  // the third generation's 144 KB of LDS keep a CU to itself) -- so the block-tree chain stays the default at every size and
+  // this one serves KMeans (k7_kmeans.hip, where it replaced a six-barrier pick) and as a cross-check
+  bool flat = ctx->opt_init_kernel == 4 && ctx->opt_init_shards <= 1 && lds_blocks >= kInitLdsBlocks && max_items >= kMaxItems;
   long long flat_n = 0;
   for (int i = 0; i < n_prob && flat; ++i) {
-    flat = probs[i].init_n <= (ctx->opt_init_kernel == 4 ? kFlatMaxSamples : 6 * kFlatThreads);
+    flat = probs[i].init_n <= kFlatMaxSamples;
     flat_n = probs[i].init_n > flat_n ? probs[i].init_n : flat_n;
   }
   if (ctx->opt_init_kernel == 4 && !flat) return rhccq_fail(ctx, RHCCQ_E_LIMIT, "mbk_init: RHCCQ_OPT_INIT_KERNEL = 4 takes at most 8192 init samples per problem");

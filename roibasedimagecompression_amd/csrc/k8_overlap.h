@@ -6,9 +6,10 @@
 // batch touched (<= 1 000 of k, sklearn _minibatch_update_dense: a centre without members keeps its value), so almost all of the
 // next E-step does not depend on this step's update:
 //
-//   launch A(t)   role 0  update of step t                      (lean_update: the non-reassigning part of mbk_update_body)
-//                 role 1  draws batch t + 2                     (one batch ahead of the classic sequence)
-//                 role 2  batch inertia + EWA rule of step t    (mbk_inertia_block, unchanged)
+//   launch A(t)   roles 0-3  update of step t, a quarter of the touched centres each (lean_update: the non-reassigning part of
+//                            mbk_update_body)
+//                 role 4  draws batch t + 2                     (one batch ahead of the classic sequence)
+//                 role 5  batch inertia + EWA rule of step t    (mbk_inertia_block, unchanged)
 //                 rest    SPECULATIVE E-step of step t + 1: batch t + 1 against every centre that step t does NOT touch
 //                         (estep_tile with U_t = the labels of batch t, known before the launch: touched centres get +inf)
 //   launch B(t+1) for every row of batch t + 1: first arg-min over the speculative tile minima and the <= 1 000 centres of U_t at
@@ -21,7 +22,8 @@
 // checks, UpdDraws::expect_reassign) and the step behind them run the classic E-step.
 
 constexpr int kPipeThreads = 256;     // small workgroups with little LDS: they share the CUs with the other problems' kernels
-constexpr int kPipeRoles = 3;
+constexpr int kUpdParts = 4;         // workgroups sharing the centre update: each owns the centres whose label hash names it
+constexpr int kPipeRoles = kUpdParts + 2;
 constexpr int kLeanCap = 4;           // batch rows listed per touched centre; beyond, the centre's thread walks the batch
 
 struct LeanShared {
@@ -47,7 +49,7 @@ __device__ __forceinline__ bool argmin_better(double d, int j, double bd, int bj
 // c *= 1 / w -- with 256 threads and 40 KB of LDS instead of 1 024 threads and 150 KB
 __device__ __forceinline__ void lean_update(LeanShared& sh, const int p, const MbkP* __restrict__ probs, double* __restrict__ centres,
                                             double* __restrict__ weights, double* __restrict__ state, long long step,
-                                            const uint32_t* __restrict__ bkeys_cur, const int32_t* __restrict__ labels_p) {
+                                            const uint32_t* __restrict__ bkeys_cur, const int32_t* __restrict__ labels_p, const int part) {
   const int tid = threadIdx.x;
   double* st = state + p * kStateStride;
   const double st_since = st[st_slot(kStSince, step)], st_nzero = st[st_slot(kStNzero, step)];
@@ -80,7 +82,9 @@ __device__ __forceinline__ void lean_update(LeanShared& sh, const int p, const M
   for (int q = 0; q < kRows; ++q) {
     const int j = lj[q];
     if (j < 0) continue;
-    unsigned h = ((unsigned)j * 2654435761u) >> 21;     // 11 bits
+    const unsigned hh = (unsigned)j * 2654435761u;
+    if (((hh >> 19) & (kUpdParts - 1)) != (unsigned)part) continue;      // another workgroup's centre
+    unsigned h = hh >> 21;                              // 11 bits
     while (true) {
       int cur = sh.hkey[h];
       if (cur == -1) {
@@ -100,9 +104,12 @@ __device__ __forceinline__ void lean_update(LeanShared& sh, const int p, const M
 #pragma unroll
   for (int q = 0; q < kSlotsPer; ++q) {
     sj[q] = sh.hkey[tid + q * kPipeThreads];
-    const int j = sj[q] < 0 ? 0 : sj[q];
-    const double2 a = *reinterpret_cast<const double2*>(C + (size_t)j * 4);
-    c0[q] = a.x; c1[q] = a.y; c2[q] = C[(size_t)j * 4 + 2]; cw[q] = W[j];
+    c0[q] = c1[q] = c2[q] = cw[q] = 0.0;
+    if (sj[q] >= 0) {
+      const int j = sj[q];
+      const double2 a = *reinterpret_cast<const double2*>(C + (size_t)j * 4);
+      c0[q] = a.x; c1[q] = a.y; c2[q] = C[(size_t)j * 4 + 2]; cw[q] = W[j];
+    }
   }
 #pragma unroll
   for (int q = 0; q < kSlotsPer; ++q) {
@@ -134,7 +141,7 @@ __device__ __forceinline__ void lean_update(LeanShared& sh, const int p, const M
     C[(size_t)j * 4 + 3] = km64_csq(n0, n1, n2);
     W[j] = wn;
   }
-  if (tid == 0) {
+  if (tid == 0 && part == 0) {
     st[st_slot(kStSince, step + 1)] = since;
     st[st_slot(kStNzero, step + 1)] = st_nzero;            // (0: it stays 0)
   }
@@ -161,15 +168,16 @@ __global__ __launch_bounds__(kPipeThreads) void mbk_pipe_kernel(const uint32_t* 
 #ifdef RHCCQ_STAMPS
   const unsigned long long _t_pipe = clock64();
 #endif
-  if (blockIdx.x == 0) {
-    lean_update(*reinterpret_cast<LeanShared*>(smem), p, probs, centres, weights, state, step, bkeys_cur, lab_cur + (size_t)p * kBatch);
-    PIPE_ROLE_END(0);
+  if (blockIdx.x < kUpdParts) {
+    lean_update(*reinterpret_cast<LeanShared*>(smem), p, probs, centres, weights, state, step, bkeys_cur, lab_cur + (size_t)p * kBatch,
+                (int)blockIdx.x);
+    if (blockIdx.x == 0) PIPE_ROLE_END(0);
     return;
   }
   const MbkP P = probs[p];
   double* st = state + p * kStateStride;
   if (mbk_stopped(st, step, P.n)) return;
-  if (blockIdx.x == 1) {
+  if (blockIdx.x == kUpdParts) {
     // ---- the batch ahead: minibatch_indices = random_state.randint(0, n_samples, batch_size) ---------------------------------
     LeanShared& sh = *reinterpret_cast<LeanShared*>(smem);
     long long cursor = (long long)st[st_slot(kStCursor, dr.draw_first - 1)];
@@ -185,7 +193,7 @@ __global__ __launch_bounds__(kPipeThreads) void mbk_pipe_kernel(const uint32_t* 
     PIPE_ROLE_END(1);
     return;
   }
-  if (blockIdx.x == 2) {
+  if (blockIdx.x == kUpdParts + 1) {
     mbk_inertia_block(P, st, step, pper_cur + (size_t)p * kBatch, nullptr);
     PIPE_ROLE_END(2);
     return;

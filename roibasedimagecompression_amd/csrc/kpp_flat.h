@@ -1,7 +1,7 @@
 // Greedy k-means++ (sklearn _kmeans_plusplus, cluster/_kmeans.py) for SMALL sample sets: every sample lives in a register of
 // the workgroup, a pick is two barriers.  Shared by KMeans (k7_kmeans.hip: up to 10 240 points, where it replaced a pick of six
-// barriers, ~7 us -> ~3.8 us) and by the MiniBatchKMeans init (k8_minibatch.hip: automatically up to 3 072 init samples, see
-// rhccq_mbk_init for the measured crossover with the block-tree chain).
+// barriers, ~7 us -> ~3.8 us) and, on request (RHCCQ_OPT_INIT_KERNEL = 4), by the MiniBatchKMeans init (k8_minibatch.hip; see
+// rhccq_mbk_init for why the block-tree chain stays the default there).
 //
 // Same arithmetic and the same picks as the other generations of the chain (exact integers: squared distances, potentials and the
 // cumulative sums of the candidate search, so grouping and order do not matter); what differs is the schedule: no pruning, no

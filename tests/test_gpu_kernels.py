@@ -297,9 +297,9 @@ def test_minibatch_init_chain_many_cases(rh, O, path):
         rh.set_option(rh.OPT_INIT_KERNEL, 1)
     if path.startswith("second_generation"):
         rh.set_option(rh.OPT_INIT_KERNEL, 2)
-    if path == "third_generation":                         # (the default for more than 8 192 init samples; here for all sizes)
+    if path == "third_generation":                         # (option 3: the same choice as the default)
         rh.set_option(rh.OPT_INIT_KERNEL, 3)
-    if path == "register_chain":                           # kpp_flat.h: the default up to 8 192 init samples, here forced
+    if path == "register_chain":                           # kpp_flat.h (the chain KMeans uses): opt-in for the MiniBatch init
         rh.set_option(rh.OPT_INIT_KERNEL, 4)
     try:
         _init_chain_cases(rh, O, small_only=path == "register_chain")

@@ -15,6 +15,8 @@ pal = np.unique(keys[:, 1920:])
 pal = pal[pal != 0]
 if len(sys.argv) > 1 and sys.argv[1] == "bench":     # the longest chain of the bench frame: k = 30 128, 90 384 init samples
     pal = pal[:1506367]
+if len(sys.argv) > 1 and sys.argv[1] == "roi":       # shaped like the bench frame's straggler: k = 20 556
+    pal = pal[:1027790]
 k = math.ceil(len(pal) * 0.2 / 10)
 print("N", len(pal), "k", k)
 t = {}
