@@ -1383,6 +1383,7 @@ __global__ __launch_bounds__(kFlatThreads) void mbk_init_flat_kernel(const uint3
 constexpr int kBatch = 1024;        // padded batch (sklearn batch_size = 1000)
 constexpr int kTileC = 512;         // centres per workgroup in the batch E-step (16 KB of LDS; 1024 halves the partials the
                                     // update folds but leaves too few workgroups: measured 9 % slower per step)
+constexpr int kTileS = 256;         // centres per workgroup of the speculative E-step (k8_overlap.h): the partial arrays are sized for these
 constexpr int kPtChunks = kBatch / 512;   // a workgroup takes 512 / split of the batch rows (two per thread)
 
 // Per-problem state, double[16] (see rhccq_mbk_steps).  Every kernel of step `step` (the launch index, equal for all
@@ -2601,7 +2602,7 @@ extern "C" {
 int64_t rhccq_mbk_work_bytes(const rhccq_mbk_problem* probs, int32_t n_prob) {
   if (!probs || n_prob <= 0) return 0;
   size_t part = 0;
-  for (int i = 0; i < n_prob; ++i) part += (size_t)((probs[i].k + kTileC - 1) / kTileC) * kBatch;
+  for (int i = 0; i < n_prob; ++i) part += (size_t)((probs[i].k + kTileS - 1) / kTileS) * kBatch;   // (the speculative E-step's tiles are half as wide)
   size_t bytes = align256(sizeof(MbkP) * n_prob) + align256(8 * (size_t)n_prob) + align256(8 * (size_t)(n_prob + 1));
   bytes += align256(part * 8) + align256(part * 4);
   size_t ksum = 0;
@@ -2653,7 +2654,7 @@ static int layout_work(rhccq_ctx* ctx, const rhccq_mbk_problem* probs, int n_pro
     hpo[i] = (long long)part;
     const int tiles = (int)((q.k + kTileC - 1) / kTileC);
     mt = tiles > mt ? tiles : mt;
-    part += (size_t)tiles * kBatch;
+    part += (size_t)((q.k + kTileS - 1) / kTileS) * kBatch;
     hbo[i] = blocks;
     blocks += (q.n + 255) / 256;
   }
@@ -3022,6 +3023,7 @@ int rhccq_mbk_steps_overlapped(rhccq_ctx* ctx, const uint32_t* keys, const rhccq
   if (int e = layout_work(ctx, probs, n_prob, work, work_bytes, &v, &blocks, &max_tiles, false)) return e;
   const long long k = probs[0].k, bs = probs[0].n < 1000 ? probs[0].n : 1000;
   const int SS = estep_split == 0 ? 1 : estep_split;
+  const int spec_tiles = (int)((k + kTileS - 1) / kTileS);
   // which steps of this call reassign (sklearn _random_reassign with no zero-weight centre left)
   std::vector<char> R((size_t)n_steps + 2, 0);
   {
@@ -3052,7 +3054,8 @@ int rhccq_mbk_steps_overlapped(rhccq_ctx* ctx, const uint32_t* keys, const rhccq
     }
     hipLaunchKernelGGL(mbk_fix_kernel, dim3((1000 + kFixPts - 1) / kFixPts, n_prob), dim3(256), 0, ctx->stream, v.probs, (const double*)state, step,
                        (const double*)centres, bk, (const double*)v.pdist, (const int32_t*)v.pidx, v.part_off, v.pper[step & 1],
-                       have_spec ? (const int32_t*)v.lab[(step - 1) & 1] : (const int32_t*)nullptr, v.lab[step & 1]);
+                       have_spec ? (const int32_t*)v.lab[(step - 1) & 1] : (const int32_t*)nullptr, v.lab[step & 1],
+                       have_spec ? kTileS : kTileC);
     dr.expect_reassign = R[s];
     dr.draw_first = drawn + 1;
     dr.draw_count = 0;
@@ -3074,17 +3077,9 @@ int rhccq_mbk_steps_overlapped(rhccq_ctx* ctx, const uint32_t* keys, const rhccq
     const bool spec_next = drawn >= step + 1;
     const long long target = R[s + 1] ? step + 1 : step + 2;
     if (target > drawn) { dr.draw_count = (int)(target - drawn); drawn = target; }
-#define RHCCQ_PIPE_LAUNCH(S_)                                                                                                              \
-  hipLaunchKernelGGL(mbk_pipe_kernel<S_>, dim3(kPipeRoles + (spec_next ? max_tiles * kPtChunks * S_ : 0), n_prob), dim3(kPipeThreads), 0, ctx->stream,  \
-                     keys, v.probs, centres, weights, state, step, words, (long long)n_words, bk, dr, (const int32_t*)v.lab[step & 1],     \
-                     (const double*)v.pper[step & 1], (const uint32_t*)v.bkeys[(step + 1) & 3], v.pdist, v.pidx, v.part_off)
-    switch (SS) {
-      case 8: RHCCQ_PIPE_LAUNCH(8); break;
-      case 4: RHCCQ_PIPE_LAUNCH(4); break;
-      case 2: RHCCQ_PIPE_LAUNCH(2); break;
-      default: RHCCQ_PIPE_LAUNCH(1); break;
-    }
-#undef RHCCQ_PIPE_LAUNCH
+    hipLaunchKernelGGL(mbk_pipe_kernel, dim3(kPipeRoles + (spec_next ? spec_tiles * kSpecChunks : 0), n_prob), dim3(kPipeThreads), 0, ctx->stream,
+                       keys, v.probs, centres, weights, state, step, words, (long long)n_words, bk, dr, (const int32_t*)v.lab[step & 1],
+                       (const double*)v.pper[step & 1], (const uint32_t*)v.bkeys[(step + 1) & 3], v.pdist, v.pidx, v.part_off);
     have_spec = spec_next;
   }
   *carry = (drawn > step0 + n_steps ? 1 : 0) | (have_spec ? 2 : 0);

@@ -35,10 +35,12 @@ struct LeanShared {
   int ired[kPipeThreads / 64 + 1];
   long long cursor;
 };
+constexpr int kSpecPts = 2 * 64;      // batch rows per workgroup of the speculative E-step: two per lane; its four waves share the tile
+constexpr int kSpecChunks = (1000 + kSpecPts - 1) / kSpecPts;
 struct SpecShared {
-  double sc[kTileC * 4];
-  double s_bd[512];
-  int s_bj[512];
+  double bd[4][kSpecPts];
+  int bj[4][kSpecPts];
+  unsigned excl[kTileS / 32];
 };
 constexpr size_t kPipeLds = sizeof(LeanShared) > sizeof(SpecShared) ? sizeof(LeanShared) : sizeof(SpecShared);
 
@@ -147,6 +149,74 @@ __device__ __forceinline__ void lean_update(LeanShared& sh, const int p, const M
   }
 }
 
+// Speculative E-step of one (tile of 256 centres, 128 batch rows) unit: wave w walks centres 64 w .. 64 w + 63 of the tile for two
+// rows per lane.  The centre of an iteration is the same for the whole wave, so it comes through the SCALAR cache (constant address
+// space, wave-uniform index) straight into SGPR operands: no tile in LDS, no load phase in front of the loop, and the loop is float64
+// VALU only (the LDS version's two 16-byte broadcast reads per centre and wave co-limited it).  The -2 of the distance expression
+// moves from the centre to the row (x' = -2 x, exact: cs + fma(x2', c2, fma(x1', c1, x0' c0)) rounds like the tiled kernel's
+// cs + fma(x2, -2 c2, fma(x1, -2 c1, x0 * -2 c0)), a power of two commutes with every rounding); a centre the labels of the running
+// step name (its value is changing under this launch) gets the distance +inf through a 256-bit mask built in LDS.
+__device__ __forceinline__ void spec_tile(const int unit, const int p, const MbkP& P, const long long po, const double* __restrict__ centres,
+                                          const uint32_t* __restrict__ bkeys, double* __restrict__ pdist, int32_t* __restrict__ pidx,
+                                          const int32_t* __restrict__ excl_labels, SpecShared& sp) {
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const int tile = unit / kSpecChunks, chunk = unit % kSpecChunks;
+  const int j0 = tile * kTileS;
+  if ((long long)j0 >= P.k) return;
+  const int nj = (int)min((long long)kTileS, P.k - j0);
+  const int bs = (int)min((long long)1000, P.n);
+  const int b0 = chunk * kSpecPts + lane, b1 = b0 + 64;
+  int ex[kBatch / kPipeThreads];
+#pragma unroll
+  for (int q = 0; q < kBatch / kPipeThreads; ++q) ex[q] = tid + q * kPipeThreads < bs ? excl_labels[tid + q * kPipeThreads] - j0 : -1;
+  const uint32_t k0 = bkeys[(size_t)p * kBatch + min(b0, bs - 1)], k1 = bkeys[(size_t)p * kBatch + min(b1, bs - 1)];
+  if (tid < kTileS / 32) sp.excl[tid] = 0u;
+  __syncthreads();
+#pragma unroll
+  for (int q = 0; q < kBatch / kPipeThreads; ++q)
+    if (ex[q] >= 0 && ex[q] < nj) atomicOr(&sp.excl[ex[q] >> 5], 1u << (ex[q] & 31));
+  __syncthreads();
+  const unsigned long long mask = ((unsigned long long)sp.excl[2 * wave + 1] << 32) | sp.excl[2 * wave];
+  const unsigned long long um = ((unsigned long long)(unsigned)__builtin_amdgcn_readfirstlane((int)(mask >> 32)) << 32) |
+                                (unsigned)__builtin_amdgcn_readfirstlane((int)(unsigned)mask);
+  const double x0 = -2.0 * (double)key_r(k0), x1 = -2.0 * (double)key_g(k0), x2 = -2.0 * (double)key_b(k0);
+  const double y0 = -2.0 * (double)key_r(k1), y1 = -2.0 * (double)key_g(k1), y2 = -2.0 * (double)key_b(k1);
+  const int ja = __builtin_amdgcn_readfirstlane(wave * 64), jb = min(ja + 64, nj);
+  typedef double double4v __attribute__((ext_vector_type(4)));
+  typedef const double4v __attribute__((address_space(4))) * cptr;
+  cptr C = (cptr)(centres + (P.koff + j0) * 4);
+  double bd0 = INFINITY, bd1 = INFINITY;
+  int bj0 = 0, bj1 = 0;
+#pragma unroll 8
+  for (int j = ja; j < jb; ++j) {
+    const double4v cc = C[j];                                  // one 32-byte scalar load: (c0, c1, c2, csq)
+    const double c0 = cc.x, c1 = cc.y, c2 = cc.z;
+    const long long cb = ((um >> (j - ja)) & 1ull) ? 0x7ff0000000000000ll : __double_as_longlong(cc.w);
+    const double cs = __longlong_as_double(cb);
+    const double d0 = cs + km64_dot(x0, x1, x2, c0, c1, c2);
+    const double d1 = cs + km64_dot(y0, y1, y2, c0, c1, c2);
+    if (d0 < bd0) { bd0 = d0; bj0 = j; }
+    if (d1 < bd1) { bd1 = d1; bj1 = j; }
+  }
+  sp.bd[wave][lane] = bd0; sp.bd[wave][64 + lane] = bd1;
+  sp.bj[wave][lane] = bj0; sp.bj[wave][64 + lane] = bj1;
+  __syncthreads();
+  if (tid < kSpecPts) {
+    const int b = chunk * kSpecPts + tid;
+    if (b < bs) {
+      double bd = sp.bd[0][tid];
+      int bj = sp.bj[0][tid];
+#pragma unroll
+      for (int w = 1; w < 4; ++w) {                           // ascending waves = ascending centre index: strict '<'
+        const double od = sp.bd[w][tid];
+        if (od < bd) { bd = od; bj = sp.bj[w][tid]; }
+      }
+      pdist[po + (size_t)tile * kBatch + b] = bd;              // (+inf: every centre of the tile is touched)
+      pidx[po + (size_t)tile * kBatch + b] = j0 + bj;
+    }
+  }
+}
+
 #ifdef RHCCQ_STAMPS
 __device__ unsigned long long g_pipe_stamps[8];          // cycles of the update / draw / inertia role, [3] launches (problem 0)
 #define PIPE_ROLE_END(r) do { if (threadIdx.x == 0 && blockIdx.y == 0) { atomicAdd(&g_pipe_stamps[r], clock64() - _t_pipe); if ((r) == 0) atomicAdd(&g_pipe_stamps[3], 1ull); } } while (0)
@@ -154,7 +224,6 @@ __device__ unsigned long long g_pipe_stamps[8];          // cycles of the update
 #define PIPE_ROLE_END(r) do {} while (0)
 #endif
 
-template <int kSplit>
 __global__ __launch_bounds__(kPipeThreads) void mbk_pipe_kernel(const uint32_t* __restrict__ keys, const MbkP* __restrict__ probs,
                                                                 double* __restrict__ centres, double* __restrict__ weights,
                                                                 double* __restrict__ state, long long step,
@@ -199,9 +268,8 @@ __global__ __launch_bounds__(kPipeThreads) void mbk_pipe_kernel(const uint32_t* 
     return;
   }
   // ---- speculative E-step of step + 1: every centre this step's batch does not touch -----------------------------------------
-  SpecShared& sp = *reinterpret_cast<SpecShared*>(smem);
-  estep_tile<kSplit>((int)blockIdx.x - kPipeRoles, p, P, part_off[p], centres, bkeys_spec, pdist, pidx, lab_cur + (size_t)p * kBatch, sp.sc,
-                     sp.s_bd, sp.s_bj);
+  spec_tile((int)blockIdx.x - kPipeRoles, p, P, part_off[p], centres, bkeys_spec, pdist, pidx, lab_cur + (size_t)p * kBatch,
+            *reinterpret_cast<SpecShared*>(smem));
 }
 
 // launch B: labels of step `step` from the tile minima (classic E-step: all centres; speculative: the untouched ones) and, behind
@@ -212,14 +280,14 @@ __global__ __launch_bounds__(256) void mbk_fix_kernel(const MbkP* __restrict__ p
                                                       const double* __restrict__ centres, const uint32_t* __restrict__ bkeys,
                                                       const double* __restrict__ pdist, const int32_t* __restrict__ pidx,
                                                       const long long* __restrict__ part_off, double* __restrict__ pper,
-                                                      const int32_t* __restrict__ lab_prev, int32_t* __restrict__ lab_out) {
+                                                      const int32_t* __restrict__ lab_prev, int32_t* __restrict__ lab_out, int tile_c) {
   __shared__ double s_d[4][kFixPts], s_p[4][kFixPts];
   __shared__ int s_j[4][kFixPts];
   const int p = blockIdx.y;
   const MbkP P = probs[p];
   const long long po = part_off[p];
   if (mbk_stopped(state + p * 16, step, P.n)) return;
-  const int n_tiles = (int)((P.k + kTileC - 1) / kTileC);
+  const int n_tiles = (int)((P.k + tile_c - 1) / tile_c);
   const int bs = (int)min((long long)1000, P.n);
   const int tid = threadIdx.x, pt = tid & (kFixPts - 1), g = tid / kFixPts;
   const int b = min((int)blockIdx.x * kFixPts + pt, bs - 1);   // clamped lanes redo the last row
