@@ -24,14 +24,15 @@
 constexpr int kPipeThreads = 256;     // small workgroups with little LDS: they share the CUs with the other problems' kernels
 constexpr int kUpdParts = 4;         // workgroups sharing the centre update: each owns the centres whose label hash names it
 constexpr int kPipeRoles = kUpdParts + 2;
-constexpr int kLeanCap = 4;           // batch rows listed per touched centre; beyond, the centre's thread walks the batch
+constexpr int kLeanCap = 8;           // batch rows listed per touched centre; beyond, the centre's thread walks the batch
+constexpr int kLeanSlots = 1024;      // hash slots of one update workgroup: it owns a quarter of the <= 1 000 touched centres (all of them at worst)
 
 struct LeanShared {
   int lab[kBatch];                    // labels of the batch (update role); the drawn row indices (draw role)
   uint32_t bkey[kBatch];
-  int hkey[kHashSlots];
-  int hcnt[kHashSlots];
-  unsigned short hmem[kHashSlots][kLeanCap];
+  int hkey[kLeanSlots];
+  int hcnt[kLeanSlots];
+  unsigned short hmem[kLeanSlots][kLeanCap];
   int ired[kPipeThreads / 64 + 1];
   long long cursor;
 };
@@ -66,7 +67,7 @@ __device__ __forceinline__ void lean_update(LeanShared& sh, const int p, const M
   }
   double* C = centres + P.koff * 4;
   double* W = weights + P.koff;
-  constexpr int kRows = kBatch / kPipeThreads, kSlotsPer = kHashSlots / kPipeThreads;
+  constexpr int kRows = kBatch / kPipeThreads, kSlotsPer = kLeanSlots / kPipeThreads;
   int lj[kRows];
   uint32_t lk[kRows];
 #pragma unroll
@@ -86,7 +87,7 @@ __device__ __forceinline__ void lean_update(LeanShared& sh, const int p, const M
     if (j < 0) continue;
     const unsigned hh = (unsigned)j * 2654435761u;
     if (((hh >> 19) & (kUpdParts - 1)) != (unsigned)part) continue;      // another workgroup's centre
-    unsigned h = hh >> 21;                              // 11 bits
+    unsigned h = hh >> 22;                              // 10 bits
     while (true) {
       int cur = sh.hkey[h];
       if (cur == -1) {
@@ -94,7 +95,7 @@ __device__ __forceinline__ void lean_update(LeanShared& sh, const int p, const M
         cur = old == -1 ? j : old;
       }
       if (cur == j) break;
-      h = (h + 1) & (kHashSlots - 1);
+      h = (h + 1) & (kLeanSlots - 1);
     }
     const int pos = atomicAdd(&sh.hcnt[h], 1);
     if (pos < kLeanCap) sh.hmem[h][pos] = (unsigned short)(tid + q * kPipeThreads);
