@@ -54,6 +54,8 @@ const char* rhccq_last_error(const rhccq_ctx* ctx);
  *                              sizes and as cross-checks;
  *   RHCCQ_OPT_INIT_CANDS_PER_WAVE  third-generation chain: how many of a pick's candidates ONE search wave finds and descends for,
  *                              as interleaved dependency chains of one instruction stream (1, 2 or 3; same picks);
+ *   RHCCQ_OPT_REASSIGN_LDS     mini-batch steps that reassign low-count centres: 1 (default) = the five sweeps over the weights read
+ *                              a 32-bit copy in LDS when k <= 30 720, 0 = always global memory (the path of larger k; same results);
  *   RHCCQ_OPT_INIT_SHARDS      workgroups (CUs) per problem of the second-generation chain: 1 (default) = one; 2 / 4 / 8 =
  *                              up to that many, each owning a range of the draws, when every shard keeps >= 4096 init
  *                              samples and at most 64 workgroups result (they wait for each other inside the launch, so
@@ -64,6 +66,7 @@ const char* rhccq_last_error(const rhccq_ctx* ctx);
 #define RHCCQ_OPT_INIT_KERNEL 3
 #define RHCCQ_OPT_INIT_SHARDS 4
 #define RHCCQ_OPT_INIT_CANDS_PER_WAVE 5
+#define RHCCQ_OPT_REASSIGN_LDS 6
 int rhccq_ctx_set_int(rhccq_ctx* ctx, int32_t option, int64_t value);
 int rhccq_sync(rhccq_ctx* ctx);                 /* hipStreamSynchronize on the context stream */
 void* rhccq_stream(rhccq_ctx* ctx);             /* the hipStream_t in use */

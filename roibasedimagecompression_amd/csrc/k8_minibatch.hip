@@ -2053,6 +2053,7 @@ struct UpdDraws {
   uint32_t* ring[4];
   long long draw_first;
   int draw_count, reassign_draws, expect_reassign, n_prob;
+  int lds_weights;                   // RHCCQ_OPT_REASSIGN_LDS
   ReSel* resel;                      // [n_prob] what a reassigning step hands from the update kernel to mbk_reassign_apply_kernel
 };
 
@@ -2207,7 +2208,7 @@ __device__ __forceinline__ void mbk_update_body(UpdShared& sh, const int p, cons
 #ifdef RHCCQ_STAMPS
     if (tid == 0 && p == 0) atomicAdd(&g_upd_stamps[14], 1ull);
 #endif
-    if (k <= kWLds && P.n <= (1ll << 24)) reassign_select<true>(sh, W, k, bs, dr.resel + p, step, p == 0);
+    if (dr.lds_weights && k <= kWLds && P.n <= (1ll << 24)) reassign_select<true>(sh, W, k, bs, dr.resel + p, step, p == 0);
     else reassign_select<false>(sh, W, k, bs, dr.resel + p, step, p == 0);
   }
   USTAMP(4);
@@ -2988,7 +2989,7 @@ int rhccq_mbk_steps(rhccq_ctx* ctx, const uint32_t* keys, const rhccq_mbk_proble
     // arg-min over the centre tiles (tiled E-step) and every row's inertia term against the centres before the update
     hipLaunchKernelGGL(mbk_fold_tiles_kernel, dim3((1000 + 15) / 16, n_prob), dim3(64), 0, ctx->stream, v.probs, (const double*)state, step,
                        (const double*)centres, bk, v.pdist, v.pidx, v.part_off, v.pper[step & 1], use_grid ? 0 : 1);
-    const UpdDraws dr{{v.bkeys[0], v.bkeys[1], v.bkeys[2], v.bkeys[3]}, step + 1, 1, 1, no_reassign ? 0 : -1, n_prob, v.resel};
+    const UpdDraws dr{{v.bkeys[0], v.bkeys[1], v.bkeys[2], v.bkeys[3]}, step + 1, 1, 1, no_reassign ? 0 : -1, n_prob, ctx->opt_reassign_lds, v.resel};
     hipLaunchKernelGGL(mbk_update_kernel, dim3(n_prob, 2), dim3(kUpdThreads), 0, ctx->stream, keys, v.probs, centres, weights, state, step,
                        words, (long long)n_words, bk, dr, (const int32_t*)v.pidx, v.part_off, (const int32_t*)nullptr);
     if (!no_reassign)
@@ -3036,7 +3037,7 @@ int rhccq_mbk_steps_overlapped(rhccq_ctx* ctx, const uint32_t* keys, const rhccq
   }
   long long drawn = step0 + ((*carry & 1) ? 1 : 0);        // newest batch in the ring
   bool have_spec = (*carry & 2) != 0;
-  UpdDraws dr{{v.bkeys[0], v.bkeys[1], v.bkeys[2], v.bkeys[3]}, 0, 0, 0, 0, n_prob, v.resel};
+  UpdDraws dr{{v.bkeys[0], v.bkeys[1], v.bkeys[2], v.bkeys[3]}, 0, 0, 0, 0, n_prob, ctx->opt_reassign_lds, v.resel};
   for (int s = 0; s < n_steps; ++s) {
     const long long step = step0 + s;
     const uint32_t* bk = v.bkeys[step & 3];

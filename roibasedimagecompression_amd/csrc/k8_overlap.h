@@ -303,10 +303,18 @@ __global__ __launch_bounds__(256) void mbk_fix_kernel(const MbkP* __restrict__ p
   }
   double bd = INFINITY;
   int bj = 0x7fffffff;
-  for (int t = g; t < n_tiles; t += kFixGroups) {
-    const double d = pdist[po + (size_t)t * kBatch + b];
-    const int j = pidx[po + (size_t)t * kBatch + b];
-    if (argmin_better(d, j, bd, bj)) { bd = d; bj = j; }
+  for (int t = g; t < n_tiles; t += 4 * kFixGroups) {           // four tiles in flight (k = 20 000: 81 tiles of 256 centres, two per thread)
+    double d[4];
+    int j[4];
+#pragma unroll
+    for (int q = 0; q < 4; ++q) {
+      const int tq = min(t + q * kFixGroups, n_tiles - 1);       // (a repeated tile changes nothing)
+      d[q] = pdist[po + (size_t)tq * kBatch + b];
+      j[q] = pidx[po + (size_t)tq * kBatch + b];
+    }
+#pragma unroll
+    for (int q = 0; q < 4; ++q)
+      if (argmin_better(d[q], j[q], bd, bj)) { bd = d[q]; bj = j[q]; }
   }
   const double x0 = (double)key_r(kk), x1 = (double)key_g(kk), x2 = (double)key_b(kk);
   // round 2: the centres those name

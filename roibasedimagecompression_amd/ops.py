@@ -195,7 +195,7 @@ class Rhccq:
         self.mtw = MtWords()
         self._mtw_dev = None
 
-    OPT_INIT_LDS_BLOCKS, OPT_INIT_MAX_ITEMS, OPT_INIT_KERNEL, OPT_INIT_SHARDS, OPT_INIT_CANDS_PER_WAVE = 1, 2, 3, 4, 5
+    OPT_INIT_LDS_BLOCKS, OPT_INIT_MAX_ITEMS, OPT_INIT_KERNEL, OPT_INIT_SHARDS, OPT_INIT_CANDS_PER_WAVE, OPT_REASSIGN_LDS = 1, 2, 3, 4, 5, 6
 
     def _bind_stream(self):
         """kernels follow torch's current stream (see _StreamBoundLib)"""
