@@ -100,7 +100,12 @@ __device__ __forceinline__ void g3_commit_quad(bool on, int b, uint32_t ck, int 
   }
 }
 
-template <int kCW>          // candidates per search wave: 1 (one wave each), 2 or 3
+// kLdsS: the samples (both orders, 16 bytes each) live in the unused tail of the leaf table instead of global memory -- init samples
+// up to kG3LdsSamples (every problem with k <= 1 900: the level-2 palettes of a frame, the segments of a many-segment frame).  A pick
+// then makes no L2 round trip at all: 3.5 us alone on the chip either way, but INSIDE a frame, beside another problem's step
+// kernels, the global-memory version of a level-2 chain ran at 6.9 us per pick (its two dependent L2 reads waited behind their traffic).
+constexpr int kG3LdsSamples = 5760;   // 17 / 16 x padded samples <= kG3MaxLeaves table entries
+template <int kCW, bool kLdsS = false>          // candidates per search wave: 1 (one wave each), 2 or 3
 __global__ __launch_bounds__(kG3Threads) void mbk_init3_kernel(const uint32_t* __restrict__ keys, const MbkP* __restrict__ probs,
                                                                const int32_t* __restrict__ init_idx, const int32_t* __restrict__ perm,
                                                                const double* __restrict__ rand, double* __restrict__ centres,
@@ -121,7 +126,7 @@ __global__ __launch_bounds__(kG3Threads) void mbk_init3_kernel(const uint32_t* _
   const int NW = (T + kCW - 1) / kCW;                             // search waves
   const int nd = (n + 63) >> 6, np = nd << 6;                     // 64-draw blocks; padded sample count
   const int nb = np >> 4, nsb = (nb + 15) >> 4, ntop = (nd + 63) >> 6;
-  uint2* samp = reinterpret_cast<uint2*>(scratch + scratch_off[blockIdx.x]);
+  uint2* samp = kLdsS ? reinterpret_cast<uint2*>(&blk[nb]) : reinterpret_cast<uint2*>(scratch + scratch_off[blockIdx.x]);
   uint2* dsamp = samp + np;
   int32_t* cho = chosen + P.koff;
   const int rq = lane >> 4, rj = lane & 15;

@@ -2917,7 +2917,11 @@ int rhccq_mbk_init(rhccq_ctx* ctx, const uint32_t* keys, const rhccq_mbk_problem
     bool t16 = false;                                      // (more than 12 trials cannot occur below 98 304 samples; a fourth candidate per wave is not built)
     for (int i = 0; i < n_prob; ++i) t16 = t16 || probs[i].T > 12;
     if (t16) cw = 1;
-    if (cw == 3)
+    bool lds_s = cw == 1;
+    for (int i = 0; i < n_prob && lds_s; ++i) lds_s = probs[i].init_n <= kG3LdsSamples;
+    if (lds_s)
+      hipLaunchKernelGGL((mbk_init3_kernel<1, true>), dim3(n_prob), dim3(kG3Threads), 0, ctx->stream, keys, dp, init_idx, perm, rand, centres, chosen, dscr, dof, mi);
+    else if (cw == 3)
       hipLaunchKernelGGL(mbk_init3_kernel<3>, dim3(n_prob), dim3(kG3Threads), 0, ctx->stream, keys, dp, init_idx, perm, rand, centres, chosen, dscr, dof, mi);
     else if (cw == 2)
       hipLaunchKernelGGL(mbk_init3_kernel<2>, dim3(n_prob), dim3(kG3Threads), 0, ctx->stream, keys, dp, init_idx, perm, rand, centres, chosen, dscr, dof, mi);
