@@ -2860,7 +2860,7 @@ int rhccq_mbk_init(rhccq_ctx* ctx, const uint32_t* keys, const rhccq_mbk_problem
     flat = probs[i].init_n <= kFlatMaxSamples;
     flat_n = probs[i].init_n > flat_n ? probs[i].init_n : flat_n;
   }
-  if (ctx->opt_init_kernel == 4 && !flat) return rhccq_fail(ctx, RHCCQ_E_LIMIT, "mbk_init: RHCCQ_OPT_INIT_KERNEL = 4 takes at most 8192 init samples per problem");
+  if (ctx->opt_init_kernel == 4 && !flat) return rhccq_fail(ctx, RHCCQ_E_LIMIT, "mbk_init: RHCCQ_OPT_INIT_KERNEL = 4 takes at most 8192 init samples per problem and the default work-list / table / shard options");
   // sharded chain: C workgroups per problem, all resident at once (they wait for each other), so only for a handful of
   // problems; every shard must own at least one draw super-block and the pick number must fit the 24-bit granule tag
   // MEASURED (MI355X, k = 30 000, 90 000 init samples): 4.84 us per pick on one workgroup, 7.7-8.0 us on 2, 4 or 8 -- each of
