@@ -150,6 +150,18 @@ int rhccq_job_index(rhccq_ctx* ctx, const uint8_t* rgb, int32_t H, int32_t W, in
                     const int32_t* const* labels_host, const int32_t* job_base_host,
                     const uint32_t* bitmaps, const uint32_t* word_prefix, const int64_t* pal_off,
                     const uint32_t* fix_key, int32_t* idx_out, int32_t* first_pos, const int32_t* fp_lut);
+/* rhccq_job_index with first positions AND, per (class, pixel), the table entry the pixel shows (fp_lut[pal_off[job] + rank], or
+ * pal_off[job] + rank without fp_lut; -1 where the pixel has no job) in entries_out (int32[n_class][H*W]): what the final remap needs,
+ * so that it reads neither the pixels nor the rank tables again.  rhccq_frame_remap_entries: the index map from those entries --
+ * for every pixel the first class (in the order given) whose label is > 0 decides: out = lut2[entry] (lut2 may be NULL: the entry
+ * itself), default_index where no class covers the pixel (clustering.py:373-377 composed with merging.py:64-82). */
+int rhccq_job_index_entries(rhccq_ctx* ctx, const uint8_t* rgb, int32_t H, int32_t W, int32_t n_class,
+                            const int32_t* const* labels_host, const int32_t* job_base_host, const uint32_t* bitmaps,
+                            const uint32_t* word_prefix, const int64_t* pal_off, const uint32_t* fix_key, int32_t* first_pos,
+                            const int32_t* fp_lut, int32_t* entries_out);
+int rhccq_frame_remap_entries(rhccq_ctx* ctx, int32_t H, int32_t W, int32_t n_class, const int32_t* const* labels_host,
+                              const int32_t* job_base_host, const int32_t* entries, const int32_t* lut2, int32_t default_index,
+                              void* out, int32_t out_elem_bytes);
 
 /* ---- K3/K4: DBSCAN(min_samples=1) labels = eps-graph components (clustering.py:233-235) -------
  * problems p = 0..n_prob-1: keys[off[p] .. off[p]+n[p]); labels in sklearn order (rank of the

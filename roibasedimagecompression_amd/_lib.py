@@ -45,6 +45,10 @@ PROTOTYPES = {
                                      c_void_p, c_void_p]),
     "rhccq_job_index": (c_int32, [c_void_p, c_void_p, c_int32, c_int32, c_int32, C.POINTER(c_void_p), C.POINTER(c_int32),
                                   c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p]),
+    "rhccq_job_index_entries": (c_int32, [c_void_p, c_void_p, c_int32, c_int32, c_int32, C.POINTER(c_void_p), C.POINTER(c_int32), c_void_p, c_void_p,
+                                          c_void_p, c_void_p, c_void_p, c_void_p, c_void_p]),
+    "rhccq_frame_remap_entries": (c_int32, [c_void_p, c_int32, c_int32, c_int32, C.POINTER(c_void_p), C.POINTER(c_int32), c_void_p, c_void_p, c_int32,
+                                            c_void_p, c_int32]),
     "rhccq_job_stats": (c_int32, [c_void_p, c_void_p, c_int32, c_int32, c_int32, C.POINTER(c_void_p), C.POINTER(c_int32), c_void_p]),
     "rhccq_job_sort_unique_bytes": (c_int64, [c_int64]),
     "rhccq_job_sort_unique": (c_int32, [c_void_p, c_void_p, c_int32, c_int32, c_int32, C.POINTER(c_void_p), C.POINTER(c_int32), c_int32, c_void_p, c_void_p,

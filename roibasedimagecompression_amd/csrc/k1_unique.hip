@@ -357,7 +357,8 @@ __global__ __launch_bounds__(256) void job_index_kernel(const uint8_t* __restric
                                                         const uint32_t* __restrict__ bitmaps, const uint32_t* __restrict__ word_prefix,
                                                         const int64_t* __restrict__ pal_off, const uint32_t* __restrict__ fix_key,
                                                         int32_t* __restrict__ idx_out, int32_t* first_pos,
-                                                        const int32_t* __restrict__ fp_lut, const int32_t* __restrict__ rankmap) {
+                                                        const int32_t* __restrict__ fp_lut, const int32_t* __restrict__ rankmap,
+                                                        int32_t* __restrict__ entry_out) {
   const int64_t n_px = (int64_t)H * W;
   const int64_t n_quads = (n_px + 3) >> 2;
   for (int64_t q = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; q < n_quads; q += (int64_t)gridDim.x * blockDim.x) {
@@ -367,10 +368,11 @@ __global__ __launch_bounds__(256) void job_index_kernel(const uint8_t* __restric
     for (int c = 0; c < ca.n_class; ++c) {
       int32_t lab[4];
       load4lab(ca.labels[c], p0, n_px, lab);
-      int32_t res[4];
+      int32_t res[4], ent[4];
 #pragma unroll
       for (int i = 0; i < 4; ++i) {
         res[i] = -1;
+        ent[i] = -1;
         if (lab[i] <= 0 || p0 + i >= n_px) continue;
         const int job = ca.job_base[c] + lab[i] - 1;
         uint32_t rk;
@@ -385,9 +387,19 @@ __global__ __launch_bounds__(256) void job_index_kernel(const uint8_t* __restric
           // fp_lut (optional) maps (job, rank) to an entry of a smaller table, e.g. the level-1 clustered
           // palette: the table then stays cache resident and almost every pixel stops at the plain compare
           const int64_t e = pal_off[job] + rk;
-          int32_t* fp = first_pos + (fp_lut ? (int64_t)fp_lut[e] : e);
+          const int64_t te = fp_lut ? (int64_t)fp_lut[e] : e;
+          ent[i] = (int32_t)te;                          // the entry of the (clustered) table this pixel shows: kept for the final remap
+          int32_t* fp = first_pos + te;
           const int32_t p = (int32_t)(p0 + i);
           if (p < *fp) atomicMin(fp, p);
+        }
+      }
+      if (entry_out) {
+        int32_t* o = entry_out + (size_t)c * n_px + p0;
+        if (p0 + 4 <= n_px) {
+          *reinterpret_cast<int4*>(o) = make_int4(ent[0], ent[1], ent[2], ent[3]);
+        } else {
+          for (int i = 0; i < 4 && p0 + i < n_px; ++i) o[i] = ent[i];
         }
       }
       if (idx_out) {
@@ -433,6 +445,46 @@ __global__ __launch_bounds__(256) void frame_remap_kernel(const uint8_t* __restr
         int32_t v = lut[pal_off[job] + rk];
         if (lut2) v = lut2[v];                          // level-1 index -> composed levels 2/3 (small, cache resident)
         res[i] = v;
+      }
+    }
+#pragma unroll
+    for (int i = 0; i < 4; ++i)
+      if (res[i] < 0) res[i] = default_index;
+    if (p0 + 4 <= n_px) {
+      if constexpr (sizeof(OutT) == 1) {
+        *reinterpret_cast<uint32_t*>(out + p0) = (uint32_t)res[0] | ((uint32_t)res[1] << 8) | ((uint32_t)res[2] << 16) | ((uint32_t)res[3] << 24);
+      } else if constexpr (sizeof(OutT) == 2) {
+        *reinterpret_cast<uint2*>(out + p0) = make_uint2((uint32_t)res[0] | ((uint32_t)res[1] << 16), (uint32_t)res[2] | ((uint32_t)res[3] << 16));
+      } else {
+        *reinterpret_cast<int4*>(out + p0) = make_int4(res[0], res[1], res[2], res[3]);
+      }
+    } else {
+      for (int i = 0; i < 4 && p0 + i < n_px; ++i) out[p0 + i] = (OutT)res[i];
+    }
+  }
+}
+
+// K6 from stored table entries: the first-position pass of a class (job_index_kernel with entry_out) already looked every pixel's
+// colour up -- rank in its job's palette, then the level-1 clustered entry -- so the final remap needs neither the pixels nor the
+// 16 MB rank tables nor the level-1 look-up table again: labels + 4 bytes per (class, pixel) streamed, one gather into the small
+// composed table of levels 2/3.  (frame_remap_kernel fetched 681 MB for 91 MB of pixels and labels: two random gathers per pixel.)
+template <typename OutT>
+__global__ __launch_bounds__(256) void frame_remap_entries_kernel(int H, int W, ClassArgs ca, const int32_t* __restrict__ entries,
+                                                                  const int32_t* __restrict__ lut2, int32_t default_index, OutT* __restrict__ out) {
+  const int64_t n_px = (int64_t)H * W;
+  const int64_t n_quads = (n_px + 3) >> 2;
+  for (int64_t q = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; q < n_quads; q += (int64_t)gridDim.x * blockDim.x) {
+    const int64_t p0 = q << 2;
+    int32_t res[4] = {-1, -1, -1, -1};
+    for (int c = 0; c < ca.n_class; ++c) {
+      if (res[0] >= 0 && res[1] >= 0 && res[2] >= 0 && res[3] >= 0) break;
+      int32_t lab[4], ent[4];
+      load4lab(ca.labels[c], p0, n_px, lab);
+      load4lab(entries + (size_t)c * n_px, p0, n_px, ent);
+#pragma unroll
+      for (int i = 0; i < 4; ++i) {
+        if (res[i] >= 0 || lab[i] <= 0 || p0 + i >= n_px) continue;
+        res[i] = lut2 ? lut2[ent[i]] : ent[i];
       }
     }
 #pragma unroll
@@ -585,7 +637,42 @@ int rhccq_job_index(rhccq_ctx* ctx, const uint8_t* rgb, int32_t H, int32_t W, in
   if (int e = make_class_args(ctx, n_class, labels_host, job_base_host, &ca)) return e;
   const int64_t quads = ((int64_t)H * W + 3) / 4;
   hipLaunchKernelGGL(job_index_kernel, dim3(stream_grid(quads, 256)), dim3(256), 0, ctx->stream, rgb, H, W, ca, bitmaps, word_prefix,
-                     pal_off, fix_key, idx_out, first_pos, fp_lut, (const int32_t*)nullptr);
+                     pal_off, fix_key, idx_out, first_pos, fp_lut, (const int32_t*)nullptr, (int32_t*)nullptr);
+  RHCCQ_LAUNCH_CHECK(ctx);
+  return 0;
+}
+
+int rhccq_job_index_entries(rhccq_ctx* ctx, const uint8_t* rgb, int32_t H, int32_t W, int32_t n_class, const int32_t* const* labels_host,
+                            const int32_t* job_base_host, const uint32_t* bitmaps, const uint32_t* word_prefix, const int64_t* pal_off,
+                            const uint32_t* fix_key, int32_t* first_pos, const int32_t* fp_lut, int32_t* entries_out) {
+  if (!ctx || !rgb || !bitmaps || !word_prefix || !pal_off || !first_pos || !entries_out || H <= 0 || W <= 0 || (int64_t)H * W > INT32_MAX)
+    return rhccq_fail(ctx, RHCCQ_E_ARG, "job_index_entries: bad argument");
+  ClassArgs ca;
+  if (int e = make_class_args(ctx, n_class, labels_host, job_base_host, &ca)) return e;
+  const int64_t quads = ((int64_t)H * W + 3) / 4;
+  hipLaunchKernelGGL(job_index_kernel, dim3(stream_grid(quads, 256)), dim3(256), 0, ctx->stream, rgb, H, W, ca, bitmaps, word_prefix,
+                     pal_off, fix_key, (int32_t*)nullptr, first_pos, fp_lut, (const int32_t*)nullptr, entries_out);
+  RHCCQ_LAUNCH_CHECK(ctx);
+  return 0;
+}
+
+int rhccq_frame_remap_entries(rhccq_ctx* ctx, int32_t H, int32_t W, int32_t n_class, const int32_t* const* labels_host,
+                              const int32_t* job_base_host, const int32_t* entries, const int32_t* lut2, int32_t default_index, void* out,
+                              int32_t out_elem_bytes) {
+  if (!ctx || !entries || !out || H <= 0 || W <= 0 || (int64_t)H * W > INT32_MAX)
+    return rhccq_fail(ctx, RHCCQ_E_ARG, "frame_remap_entries: bad argument");
+  ClassArgs ca;
+  if (int e = make_class_args(ctx, n_class, labels_host, job_base_host, &ca)) return e;
+  const int64_t quads = ((int64_t)H * W + 3) / 4;
+  const dim3 grid(stream_grid(quads, 256));
+  if (out_elem_bytes == 1)
+    hipLaunchKernelGGL(frame_remap_entries_kernel<uint8_t>, grid, dim3(256), 0, ctx->stream, H, W, ca, entries, lut2, default_index, (uint8_t*)out);
+  else if (out_elem_bytes == 2)
+    hipLaunchKernelGGL(frame_remap_entries_kernel<uint16_t>, grid, dim3(256), 0, ctx->stream, H, W, ca, entries, lut2, default_index, (uint16_t*)out);
+  else if (out_elem_bytes == 4)
+    hipLaunchKernelGGL(frame_remap_entries_kernel<int32_t>, grid, dim3(256), 0, ctx->stream, H, W, ca, entries, lut2, default_index, (int32_t*)out);
+  else
+    return rhccq_fail(ctx, RHCCQ_E_ARG, "frame_remap_entries: out_elem_bytes must be 1, 2 or 4");
   RHCCQ_LAUNCH_CHECK(ctx);
   return 0;
 }
@@ -599,7 +686,7 @@ int rhccq_job_index_ranked(rhccq_ctx* ctx, int32_t H, int32_t W, int32_t n_class
   const int64_t quads = ((int64_t)H * W + 3) / 4;
   // (the kernel reads no pixel colour on this path: rgb is only dereferenced by load4px, harmless on any mapped address -- pass the rank map)
   hipLaunchKernelGGL(job_index_kernel, dim3(stream_grid(quads, 256)), dim3(256), 0, ctx->stream, (const uint8_t*)rankmap, H, W, ca, (const uint32_t*)nullptr,
-                     (const uint32_t*)nullptr, pal_off, (const uint32_t*)nullptr, (int32_t*)nullptr, first_pos, fp_lut, rankmap);
+                     (const uint32_t*)nullptr, pal_off, (const uint32_t*)nullptr, (int32_t*)nullptr, first_pos, fp_lut, rankmap, (int32_t*)nullptr);
   RHCCQ_LAUNCH_CHECK(ctx);
   return 0;
 }

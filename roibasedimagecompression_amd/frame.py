@@ -137,11 +137,16 @@ class FrameEncoder:
         if S.get("rankmap") is not None:
             rm = S["rankmap"] if ci is None else S["rankmap"][ci:ci + 1]
             rh.job_index_ranked(S["H"], S["W"], labels, job_base, rm, S["d_pal_off"], fp, fp_lut)
+        elif ci is not None and S.get("e1map") is not None:
+            # (pipelined classes: keep every pixel's level-1 entry for the final remap -- it then needs no colour, rank or lut1 gather)
+            rh.job_index_entries(S["rgb"], labels, job_base, S["bitmaps"], S["prefix"], S["d_pal_off"], S["fix_key"], fp, fp_lut, S["e1map"][ci])
         else:
             rh.job_index(S["rgb"], labels, job_base, S["bitmaps"], S["prefix"], S["d_pal_off"], S["fix_key"], want_idx=False, first_pos=fp, fp_lut=fp_lut)
 
     def _remap_pass(self, S, lut1, default_index, out_dtype, d_lut2):
         rh = self.rh
+        if S.get("e1map") is not None and S.get("e1map_complete"):
+            return rh.frame_remap_entries(S["H"], S["W"], S["labels"], S["job_base"][:-1], S["e1map"], default_index, out_dtype, lut2=d_lut2)
         if S.get("rankmap") is not None:
             return rh.frame_remap_ranked(S["H"], S["W"], S["labels"], S["job_base"][:-1], S["rankmap"], S["d_pal_off"], lut1, default_index, out_dtype, lut2=d_lut2)
         return rh.frame_remap(S["rgb"], S["labels"], S["job_base"][:-1], S["bitmaps"], S["prefix"], S["d_pal_off"], S["fix_key"], lut1, default_index,
@@ -453,6 +458,8 @@ class FrameEncoder:
         total = int(bound.sum())
         lut1 = torch.zeros((max(S["total"], 1),), dtype=torch.int32, device=rh.device)
         fp_all = torch.full((max(total, 1),), INT_MAX, dtype=torch.int32, device=rh.device)
+        if S.get("rankmap") is None:
+            S["e1map"] = torch.empty((len(classes), S["H"] * S["W"]), dtype=torch.int32, device=rh.device)
         here = torch.cuda.current_stream(rh.device)
         ready = torch.cuda.Event()
         ready.record(here)
@@ -480,6 +487,7 @@ class FrameEncoder:
             torch.cuda.synchronize(rh.device)                     # (the other class may still be writing the shared tables)
             raise errors[0]
         S["lut1"], S["k1_off"], S["k1_total"] = lut1, {}, total
+        S["e1map_complete"] = S.get("e1map") is not None       # every class has stored its pixels' level-1 entries
         per_class, comps3, q2s = [], [], []
         for k1_off, regs, comp3, q2, done in out:
             here.wait_event(done)

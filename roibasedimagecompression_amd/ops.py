@@ -386,6 +386,21 @@ class Rhccq:
                     "job_index")
         return idx
 
+    def job_index_entries(self, rgb, labels, job_base, bitmaps, prefix, pal_off, fix_key, first_pos, fp_lut, entries_out):
+        """first positions as job_index + the table entry every pixel shows, into entries_out (int32[len(labels)][H*W] view)"""
+        H, W = rgb.shape[0], rgb.shape[1]
+        n, ptrs, bases = self._class_args(labels, job_base)
+        assert entries_out.dtype == torch.int32 and entries_out.is_contiguous() and entries_out.numel() == n * H * W
+        self._check(self.lib.rhccq_job_index_entries(self.ctx, self._p(rgb), H, W, n, ptrs, bases, self._p(bitmaps), self._p(prefix), self._p(pal_off),
+                                                     self._p(fix_key), self._p(first_pos), self._p(fp_lut), self._p(entries_out)), "job_index_entries")
+
+    def frame_remap_entries(self, H, W, labels, job_base, entries, default_index, out_dtype, lut2=None):
+        n, ptrs, bases = self._class_args(labels, job_base)
+        out = self.empty((int(H), int(W)), out_dtype)
+        self._check(self.lib.rhccq_frame_remap_entries(self.ctx, int(H), int(W), n, ptrs, bases, self._p(entries), self._p(lut2), int(default_index),
+                                                       self._p(out), out.element_size()), "frame_remap_entries")
+        return out
+
     def frame_remap(self, rgb, labels, job_base, bitmaps, prefix, pal_off, fix_key, lut, default_index, out_dtype, lut2=None):
         H, W = rgb.shape[0], rgb.shape[1]
         n, ptrs, bases = self._class_args(labels, job_base)
