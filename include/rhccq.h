@@ -219,6 +219,15 @@ typedef struct rhccq_mbk_problem {
 int64_t rhccq_mbk_order_bytes(int64_t total_samples);
 int rhccq_mbk_order(rhccq_ctx* ctx, const uint32_t* keys, const rhccq_mbk_problem* probs_host,
                     int32_t n_prob, const int32_t* init_idx, int32_t* perm, void* tmp, int64_t tmp_bytes);
+/* out[idx[i]] = min(out[idx[i]], val[i]), i < count: the first raster position of a palette entry that several entries of the level
+ * below map to (merging.py:77-79 carried through clustering.py:373-377).  Host code; RHCCQ_E_ARG for an index outside [0, n_out). */
+int rhccq_scatter_min_host(int64_t n_out, const int32_t* idx, const int64_t* val, int64_t count, int64_t* out);
+/* The bookkeeping behind one clustered palette whose clusters need no split (clustering.py:296-377), host code: from the member
+ * sums of the k clusters (rhccq_cluster_sums layout) the floor-mean colour of every non-empty cluster in label order behind
+ * `nblack` black rows (new_keys: room for nblack + k) and lut[label] = new palette index (uint16-valued like the reference's
+ * mapping_array; empty clusters map to the first row).  Returns the number of non-empty clusters, -1 when a cluster holds more
+ * than mc colours (it takes the KMeans split instead), -2 for a bad argument. */
+int64_t rhccq_cluster_plan_host(const unsigned long long* sums, int64_t k, int64_t mc, int32_t nblack, uint32_t* new_keys, int32_t* lut);
 /* merge_region_components_simple in palette space (encoder/compression/merging.py:8-120), host code: the components are painted
  * in REVERSED order, every component's entries in the order of their first raster positions fp; a colour gets the index of its
  * first appearance in that sequence (index 0 = canvas black) and the smallest first position of its members.  Entries with key

@@ -66,6 +66,8 @@ PROTOTYPES = {
     "rhccq_mbk_steps_overlapped": (c_int32, [c_void_p, c_void_p, C.POINTER(MbkProblem), c_int32, c_int64, c_int32, c_void_p, c_int64, c_void_p,
                                              c_void_p, c_void_p, c_void_p, c_int64, c_int32, c_int64, C.POINTER(c_int32)]),
     "rhccq_mt_randint_host": (c_int64, [c_void_p, c_int64, c_int64, c_int64, c_int64, c_void_p]),
+    "rhccq_scatter_min_host": (c_int32, [c_int64, c_void_p, c_void_p, c_int64, c_void_p]),
+    "rhccq_cluster_plan_host": (c_int64, [c_void_p, c_int64, c_int64, c_int32, c_void_p, c_void_p]),
     "rhccq_merge_palettes_host": (c_int32, [c_int32, c_void_p, c_void_p, c_void_p, c_int64, c_void_p, c_void_p, c_void_p, c_void_p]),
     "rhccq_mbk_work_bytes": (c_int64, [C.POINTER(MbkProblem), c_int32]),
     "rhccq_px_neighbours": (c_int32, [c_void_p, c_void_p, c_int32, c_int32, c_int32, C.c_float, C.c_float, c_int32, c_void_p, c_void_p, c_void_p]),

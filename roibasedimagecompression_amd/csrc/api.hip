@@ -212,4 +212,40 @@ int rhccq_merge_palettes_host(int32_t n_comp, const uint32_t* const* keys, const
   return 0;
 }
 
+// out[idx[i]] = min(out[idx[i]], val[i]) for i < count (first positions of the entries a clustering maps together: the smallest
+// survives, merging.py:77-79 / clustering.py:373-377 carried through the levels).  numpy has no fast scatter-min (ufunc.at is slow,
+// sort + reduceat costs a sort): one loop on the host.  Returns 0, or RHCCQ_E_ARG for an index outside [0, n_out).
+int rhccq_scatter_min_host(int64_t n_out, const int32_t* idx, const int64_t* val, int64_t count, int64_t* out) {
+  if (n_out < 0 || count < 0 || (count > 0 && (!idx || !val || !out))) return RHCCQ_E_ARG;
+  for (int64_t i = 0; i < count; ++i) {
+    const int64_t t = idx[i];
+    if (t < 0 || t >= n_out) return RHCCQ_E_ARG;
+    if (val[i] < out[t]) out[t] = val[i];
+  }
+  return 0;
+}
+
+// The bookkeeping behind one clustered palette (clustering.py:296-377 for clusters that need no split): from the member sums of
+// the k clusters (uint64 r, g, b, count each) the floor-mean colour of every non-empty cluster in label order behind `nblack`
+// black rows, and the label -> new palette index table (uint16-valued like the reference's mapping_array).  Returns the
+// number of non-empty clusters, or -1 when a cluster holds more than `mc` colours (it needs the k-means split: host path).
+// A dozen numpy passes per palette between level 1 and level 2 of a frame (~0.5 ms each) as one loop.  Pure host code.
+int64_t rhccq_cluster_plan_host(const unsigned long long* sums, int64_t k, int64_t mc, int32_t nblack, uint32_t* new_keys, int32_t* lut) {
+  if (!sums || k < 0 || nblack < 0 || !new_keys || !lut) return -2;
+  for (int64_t j = 0; j < k; ++j)
+    if ((int64_t)sums[4 * j + 3] > mc) return -1;
+  for (int32_t b = 0; b < nblack; ++b) new_keys[b] = 0u;
+  int64_t n = 0;
+  for (int64_t j = 0; j < k; ++j) {
+    const unsigned long long c = sums[4 * j + 3];
+    int64_t leaf = 0;
+    if (c) {
+      new_keys[nblack + n] = ((uint32_t)(sums[4 * j] / c) << 16) | ((uint32_t)(sums[4 * j + 1] / c) << 8) | (uint32_t)(sums[4 * j + 2] / c);
+      leaf = n++;
+    }
+    lut[j] = (int32_t)((nblack + leaf) & 0xFFFF);
+  }
+  return n;
+}
+
 }  // extern "C"

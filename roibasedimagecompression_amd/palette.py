@@ -58,28 +58,27 @@ def _cluster_resident(rh, jobs, idxs, results):
     else:
         all_keys, all_lab = parts[0], labs[0]
     _, sums_dev = rh.cluster_means(all_keys, all_lab, int(koff[-1]))
-    sums_all = sums_dev.cpu().numpy().astype(np.int64)
+    sums_all = np.ascontiguousarray(sums_dev.cpu().numpy())
     luts, plans = [], []
     for i, (s, nbk, k, lab) in enumerate(zip(idxs, parts, ks, labs)):
         jb = jobs[s]
         sums = sums_all[koff[i]:koff[i + 1]]
-        cnt = sums[:, 3]
-        if (cnt > jb["mc"]).any():                         # needs k-means splitting: host path
+        nblack = 1 if jb["has_black"] else 0
+        new_keys = np.empty(nblack + k, np.uint32)
+        lut = np.empty(k, np.int32)
+        # floor means of the non-empty clusters in label order + the uint16 mapping_array (clustering.py:373): one native pass
+        n_present = int(rh.lib.rhccq_cluster_plan_host(sums.ctypes.data, k, int(jb["mc"]), nblack, new_keys.ctypes.data, lut.ctypes.data))
+        if n_present == -1:                                # a cluster needs k-means splitting: host path
             jb["keys"] = jb["keys_dev"].cpu().numpy().view(np.uint32)
             jb["_labels"] = lab.cpu().numpy()
             fallback.append(s)
             luts.append(np.zeros(k, np.int32))
             plans.append(None)
             continue
-        present = cnt > 0
-        nblack = 1 if jb["has_black"] else 0
-        leaf = np.full(k, 0, np.int64)
-        leaf[present] = np.arange(int(present.sum()))
-        c = np.maximum(cnt[present], 1)
-        means = ((sums[present, 0] // c) << 16) | ((sums[present, 1] // c) << 8) | (sums[present, 2] // c)
-        new_keys = np.concatenate([np.zeros(nblack, np.uint32), means.astype(np.uint32)])
-        luts.append(((nblack + leaf) & 0xFFFF).astype(np.int32))    # uint16 mapping_array (clustering.py:373)
-        plans.append((new_keys, nblack, int(present.sum())))
+        if n_present < 0:
+            raise RuntimeError("rhccq_cluster_plan_host: bad argument")
+        luts.append(lut)
+        plans.append((new_keys[:nblack + n_present].copy(), nblack, n_present))
     # label -> new palette index of every job in one gather
     mapped_all = rh.remap(all_lab, rh.dev(np.concatenate(luts)))
     offs = np.concatenate([[0], np.cumsum([int(p.numel()) for p in parts])]).astype(np.int64)

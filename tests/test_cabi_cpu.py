@@ -289,6 +289,56 @@ def test_native_palette_merge_equals_the_numpy_statement():
         assert set(got.maps) == set(maps) and all(np.array_equal(got.maps[j], maps[j]) for j in maps)
 
 
+def test_native_cluster_plan_equals_the_numpy_statement():
+    """rhccq_cluster_plan_host (palette._cluster_resident) against the numpy passes it replaced: floor means of the non-empty
+    clusters in label order behind the black rows, the uint16-valued label -> index table, -1 when a cluster needs the split."""
+    from roibasedimagecompression_amd import _lib
+    lib = _lib.load()
+    rng = np.random.default_rng(3)
+    seen_split = seen_plan = 0
+    for trial in range(40):
+        k = int(rng.integers(1, 5000))
+        nblack = int(rng.integers(0, 2))
+        mc = int(rng.integers(5, 400))
+        cnt = rng.integers(0, 60, k).astype(np.uint64) * (rng.random(k) < 0.8)
+        sums = np.zeros((k, 4), np.uint64)
+        sums[:, 3] = cnt
+        for ch in range(3):
+            sums[:, ch] = np.minimum(rng.integers(0, 256, k).astype(np.uint64) * cnt + rng.integers(0, 50, k).astype(np.uint64) % np.maximum(cnt, 1), 255 * cnt)
+        s64, c = sums.astype(np.int64), sums[:, 3].astype(np.int64)
+        nk, lut = np.empty(nblack + k, np.uint32), np.empty(k, np.int32)
+        got = lib.rhccq_cluster_plan_host(sums.ctypes.data, k, mc, nblack, nk.ctypes.data, lut.ctypes.data)
+        if (c > mc).any():
+            assert got == -1
+            seen_split += 1
+            continue
+        present = c > 0
+        leaf = np.zeros(k, np.int64)
+        leaf[present] = np.arange(int(present.sum()))
+        cc = np.maximum(c[present], 1)
+        means = ((s64[present, 0] // cc) << 16) | ((s64[present, 1] // cc) << 8) | (s64[present, 2] // cc)
+        assert got == int(present.sum())
+        assert np.array_equal(nk[:nblack + got], np.concatenate([np.zeros(nblack, np.uint32), means.astype(np.uint32)]))
+        assert np.array_equal(lut, ((nblack + leaf) & 0xFFFF).astype(np.int32))
+        seen_plan += 1
+    assert seen_split and seen_plan
+    assert lib.rhccq_cluster_plan_host(None, 3, 5, 0, nk.ctypes.data, lut.ctypes.data) == -2
+
+
+def test_native_scatter_min_equals_numpy():
+    """rhccq_scatter_min_host (frame._scatter_min: first positions carried through a clustering) against np.minimum.at"""
+    from roibasedimagecompression_amd import frame
+    rng = np.random.default_rng(2)
+    for _ in range(10):
+        n, m = int(rng.integers(1, 3000)), int(rng.integers(0, 9000))
+        idx, val = rng.integers(0, n, m), rng.integers(0, 1 << 22, m)
+        want = np.full(n, int(frame._FP_NONE), np.int64)
+        np.minimum.at(want, idx, val)
+        assert np.array_equal(frame._scatter_min(n, idx, val), want)
+    with pytest.raises(IndexError):
+        frame._scatter_min(3, np.array([0, 3]), np.array([1, 2]))
+
+
 def test_hostsort_helpers_equal_numpy():
     """hostsort._stable_order / _unique_first_inverse (one unstable sort of key<<32|position composites) against
     np.argsort(kind="stable") / np.unique(return_index, return_inverse), duplicates included"""
