@@ -67,6 +67,13 @@ const char* rhccq_last_error(const rhccq_ctx* ctx);
 #define RHCCQ_OPT_INIT_SHARDS 4
 #define RHCCQ_OPT_INIT_CANDS_PER_WAVE 5
 #define RHCCQ_OPT_REASSIGN_LDS 6
+/*   RHCCQ_OPT_REASSIGN_ORDER   THE ONE OPTION THAT CHANGES RESULTS.  Which tied low-count centres a capped reassignment of a mini-batch
+ *                              step takes (sklearn _mini_batch_step: np.argsort(weight_sums)[:batch / 2], an unstable sort):
+ *                              1 (default) = the slots numpy's scalar aquicksort_<double> fills (csrc/k8_npysort.h; the whole fit then
+ *                              equals scikit-learn's untouched fit_predict under NPY_DISABLE_CPU_FEATURES = <AVX512 family> AVX2
+ *                              FMA3, the host setting of record), 0 = the stable order (weight, index) of rounds 1-3 (= sklearn
+ *                              with that call forced to kind='stable'). */
+#define RHCCQ_OPT_REASSIGN_ORDER 7
 int rhccq_ctx_set_int(rhccq_ctx* ctx, int32_t option, int64_t value);
 int rhccq_sync(rhccq_ctx* ctx);                 /* hipStreamSynchronize on the context stream */
 void* rhccq_stream(rhccq_ctx* ctx);             /* the hipStream_t in use */
@@ -250,6 +257,12 @@ int rhccq_mt_uniforms(rhccq_ctx* ctx, const uint32_t* words, int64_t pos, int64_
 int rhccq_mbk_init(rhccq_ctx* ctx, const uint32_t* keys, const rhccq_mbk_problem* probs_host,
                    int32_t n_prob, const int32_t* init_idx, const int32_t* perm, const double* rand,
                    double* centres, int32_t* chosen);
+/* np.argsort(w)[:cap] AS A SET under numpy's scalar sort kernel (numpy/_core/src/npysort/quicksort.cpp aquicksort_<double>,
+ * heapsort.cpp behind its depth limit) -- the selection inside a capped reassignment of rhccq_mbk_steps, exposed for tests.
+ * w: double[k] on the device, non-negative integers < 2^32; 0 < cap < k; depth0 < 0 = numpy's depth limit 2 floor(log2 k)
+ * (tests lower it to drive the heapsort branch); scratch: 16 k bytes; mask_out: uint32[(k + 31) / 32], bit j set <=> j is
+ * among the first cap entries. */
+int rhccq_npysort_head(rhccq_ctx* ctx, const double* w, int32_t k, int32_t cap, int32_t depth0, void* scratch, uint32_t* mask_out);
 /* run mini-batch steps step0 .. step0 + n_steps - 1 for every problem that has not stopped (call with step0 = 0 first -- that
  * call writes the problem tables at the head of `work`, later calls only queue kernels -- then with the number of steps launched so far; all problems of a call sequence share the step index).  state:
  * double[n_prob][16] = {[0] ewa, [1] ewa_min, [2] no_improvement, [3] samples since the last reassignment, [4] why the

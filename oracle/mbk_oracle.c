@@ -15,8 +15,9 @@
  *   sklearn/cluster/_kmeans.py: MiniBatchKMeans.fit, _init_centroids, _kmeans_plusplus, _mini_batch_step,
  *     _mini_batch_convergence; _k_means_minibatch.pyx: update_center_dense; _k_means_lloyd.pyx: _update_chunk_dense (E-step
  *     expression, see km64_estep.c); _k_means_common.pyx: _inertia_dense / _euclidean_dense_dense.
- *   ONE canonical choice: np.argsort(weight_sums) in _mini_batch_step is unstable over tied counts; the stable order
- *     (weight, index) is used here (and by the HIP kernels).
+ *   np.argsort(weight_sums) in _mini_batch_step is unstable over tied counts: `argsort_kind` selects the tie order --
+ *     1 = numpy's scalar aquicksort (npy_argsort.c: what numpy runs under the host setting of record, the default of the
+ *     build), 0 = the stable order (weight, index) (rounds 1-3; kept for the G11 "stable" records).
  *
  * Build: gcc -O3 -mavx2 -mfma -ffp-contract=off -fopenmp -shared -fPIC (together with km64_estep.c; the compiler never
  * fuses on its own, the only fused operations are the explicit fma() calls of the E-step).  n_threads only changes how the
@@ -214,15 +215,17 @@ static int cmp_wj(const void* a, const void* b) {
   const wj_t* x = (const wj_t*)a; const wj_t* y = (const wj_t*)b;
   if (x->w < y->w) return -1;
   if (x->w > y->w) return 1;
-  return x->j < y->j ? -1 : (x->j > y->j ? 1 : 0);                         /* canonical: stable (weight, index) */
+  return x->j < y->j ? -1 : (x->j > y->j ? 1 : 0);                         /* argsort_kind 0: stable (weight, index) */
 }
 
 /* MiniBatchKMeans(k, batch_size=1000, random_state=seed, n_init='auto').fit_predict on n integer colours (rgb: n x 3).
  * Outputs: centres_out k x 3, labels_out n (may be NULL: skip the final E-step), picks_out k (k-means++ picks, positions
  * in the init sample), init_idx_out (may be NULL) init_size rows, info_out[8] = {n_steps, init_size, words_consumed,
  * n_reassigned, 0...}.  max_steps < 0: sklearn's own limit.  Returns 0. */
-int mbk_fit(const uint8_t* rgb, int64_t n, int32_t k, uint32_t seed, int64_t max_steps, int32_t n_threads, double* centres_out,
-            int32_t* labels_out, int32_t* picks_out, int64_t* init_idx_out, int64_t* info_out) {
+void npy_argsort_f64(const double* v, int64_t n, int64_t* order);
+
+int mbk_fit(const uint8_t* rgb, int64_t n, int32_t k, uint32_t seed, int64_t max_steps, int32_t n_threads, int32_t argsort_kind,
+            double* centres_out, int32_t* labels_out, int32_t* picks_out, int64_t* init_idx_out, int64_t* info_out) {
 #ifdef _OPENMP
   if (n_threads > 0) omp_set_num_threads(n_threads);
 #endif
@@ -254,6 +257,7 @@ int mbk_fit(const uint8_t* rgb, int64_t n, int32_t k, uint32_t seed, int64_t max
   int32_t* newc = (int32_t*)malloc(sizeof(int32_t) * (size_t)bs);
   uint8_t* to_re = (uint8_t*)malloc((size_t)k);
   wj_t* order = (wj_t*)malloc(sizeof(wj_t) * (size_t)k);
+  int64_t* norder = (int64_t*)malloc(sizeof(int64_t) * (size_t)k);
   int64_t n_steps = (100 * n) / bs;
   if (max_steps >= 0 && max_steps < n_steps) n_steps = max_steps;
   double ewa = 0.0, ewa_min = 0.0;
@@ -306,9 +310,14 @@ int mbk_fit(const uint8_t* rgb, int64_t n, int32_t k, uint32_t seed, int64_t max
       int64_t cnt = 0;
       for (int j = 0; j < k; ++j) { to_re[j] = W[j] < thr; cnt += to_re[j]; }
       if ((double)cnt > 0.5 * (double)bs) {
-        for (int j = 0; j < k; ++j) { order[j].w = W[j]; order[j].j = j; }
-        qsort(order, (size_t)k, sizeof(wj_t), cmp_wj);
-        for (int64_t r = (int64_t)(0.5 * (double)bs); r < k; ++r) to_re[order[r].j] = 0;
+        if (argsort_kind == 1) {
+          npy_argsort_f64(W, k, norder);
+          for (int64_t r = (int64_t)(0.5 * (double)bs); r < k; ++r) to_re[norder[r]] = 0;
+        } else {
+          for (int j = 0; j < k; ++j) { order[j].w = W[j]; order[j].j = j; }
+          qsort(order, (size_t)k, sizeof(wj_t), cmp_wj);
+          for (int64_t r = (int64_t)(0.5 * (double)bs); r < k; ++r) to_re[order[r].j] = 0;
+        }
       }
       int nre = 0;
       for (int j = 0; j < k; ++j) nre += to_re[j];
@@ -349,7 +358,7 @@ int mbk_fit(const uint8_t* rgb, int64_t n, int32_t k, uint32_t seed, int64_t max
     info_out[0] = steps_done; info_out[1] = init_size; info_out[2] = rs.consumed; info_out[3] = n_reassigned;
     info_out[4] = info_out[5] = info_out[6] = info_out[7] = 0;
   }
-  free(idx); free(C); free(Cn); free(csq); free(W); free(bidx); free(Xb); free(lab); free(newc); free(to_re); free(order);
+  free(idx); free(C); free(Cn); free(csq); free(W); free(bidx); free(Xb); free(lab); free(newc); free(to_re); free(order); free(norder);
   return 0;
 }
 

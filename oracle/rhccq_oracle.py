@@ -65,7 +65,7 @@ import numpy as np
 __all__ = [
     "pack_rgb", "unpack_rgb", "unique_colors", "clustering_params", "eps_threshold",
     "eps_components", "kmeanspp_int", "kmeans_labels", "split_large_cluster",
-    "minibatch_kmeans_labels", "minibatch_kmeans_native", "kmeanspp_picks_native", "cluster_palette", "merge_components", "segment_crop",
+    "minibatch_kmeans_labels", "minibatch_kmeans_native", "npy_argsort_scalar", "kmeanspp_picks_native", "cluster_palette", "merge_components", "segment_crop",
     "level1_region", "region_quantization", "quantize_image", "optimal_index_dtype",
     "encode_frame", "pack_container", "container_bytes", "load_container", "decode_container",
     "dct_quant_blocks", "adaptive_quality_metrics", "split_score", "normalize_result", "enhanced_slic", "slic_masked", "slic_sweeps", "slic_enforce_connectivity",
@@ -87,7 +87,7 @@ def _km64_lib():
     import os
     import subprocess
     here = os.path.dirname(os.path.abspath(__file__))
-    srcs = [os.path.join(here, "km64_estep.c"), os.path.join(here, "mbk_oracle.c")]
+    srcs = [os.path.join(here, "km64_estep.c"), os.path.join(here, "mbk_oracle.c"), os.path.join(here, "npy_argsort.c")]
     out = os.path.join(here, "_build", "libkm64.so")
     if not os.path.exists(out) or os.path.getmtime(out) < max(os.path.getmtime(f) for f in srcs):
         os.makedirs(os.path.dirname(out), exist_ok=True)
@@ -96,8 +96,12 @@ def _km64_lib():
     lib.km64_estep.argtypes = [ctypes.c_void_p, ctypes.c_int64, ctypes.c_void_p, ctypes.c_int64, ctypes.c_void_p, ctypes.c_void_p]
     lib.km64_estep.restype = None
     lib.mbk_fit.argtypes = [ctypes.c_void_p, ctypes.c_int64, ctypes.c_int32, ctypes.c_uint32, ctypes.c_int64, ctypes.c_int32,
-                            ctypes.c_void_p, ctypes.c_void_p, ctypes.c_void_p, ctypes.c_void_p, ctypes.c_void_p]
+                            ctypes.c_int32, ctypes.c_void_p, ctypes.c_void_p, ctypes.c_void_p, ctypes.c_void_p, ctypes.c_void_p]
     lib.mbk_fit.restype = ctypes.c_int
+    lib.npy_argsort_f64.argtypes = [ctypes.c_void_p, ctypes.c_int64, ctypes.c_void_p]
+    lib.npy_argsort_f64.restype = None
+    lib.npy_argsort_f64_depth.argtypes = [ctypes.c_void_p, ctypes.c_int64, ctypes.c_void_p, ctypes.c_int]
+    lib.npy_argsort_f64_depth.restype = None
     lib.mbk_init_picks.argtypes = [ctypes.c_void_p, ctypes.c_int64, ctypes.c_int32, ctypes.c_uint32, ctypes.c_int32, ctypes.c_void_p,
                                    ctypes.c_void_p]
     lib.mbk_init_picks.restype = ctypes.c_int
@@ -113,7 +117,20 @@ def _mbk_init_size(n, k, batch_size=1000):
     return min(init_size, n)
 
 
-def minibatch_kmeans_native(points, k, seed=42, max_steps=None, threads=0, want_labels=True):
+ARGSORT_KINDS = {"stable": 0, "npysort": 1}
+DEFAULT_ARGSORT = "npysort"      # numpy's scalar aquicksort: the host setting of record (npy_argsort.c)
+
+
+def npy_argsort_scalar(w, depth0=-1):
+    """np.argsort(w) as numpy's scalar (non-SIMD) aquicksort_<double> orders it (oracle/npy_argsort.c); depth0 >= 0 lowers
+    the introsort depth limit (numpy's: 2 floor(log2 n)) so that ordinary inputs reach the heapsort branch"""
+    w = np.ascontiguousarray(w, dtype=np.float64)
+    out = np.empty(len(w), np.int64)
+    _km64_lib().npy_argsort_f64_depth(w.ctypes.data, len(w), out.ctypes.data, int(depth0))
+    return out
+
+
+def minibatch_kmeans_native(points, k, seed=42, max_steps=None, threads=0, want_labels=True, argsort=None):
     """oracle/mbk_oracle.c: the same restatement as minibatch_kmeans_labels() in C (OpenMP over `threads` host cores,
     0 = all).  Returns (labels int32[n] or None, info) with info keys n_steps, centers, picks, init_indices, mt_words."""
     P = np.ascontiguousarray(np.asarray(points).reshape(-1, 3).astype(np.uint8))
@@ -125,7 +142,7 @@ def minibatch_kmeans_native(points, k, seed=42, max_steps=None, threads=0, want_
     init_idx = np.empty(isz, np.int64)
     info = np.zeros(8, np.int64)
     rc = _km64_lib().mbk_fit(P.ctypes.data, n, int(k), int(seed), -1 if max_steps is None else int(max_steps), int(threads),
-                             C.ctypes.data, lab.ctypes.data if want_labels else None, picks.ctypes.data, init_idx.ctypes.data,
+                             ARGSORT_KINDS[argsort or DEFAULT_ARGSORT], C.ctypes.data, lab.ctypes.data if want_labels else None, picks.ctypes.data, init_idx.ctypes.data,
                              info.ctypes.data)
     if rc:
         raise ValueError("mbk_fit: bad arguments")
@@ -413,7 +430,7 @@ def _mb_dist(Xb, C):
 
 def minibatch_kmeans_labels(points, k, seed=42, batch_size=1000, max_iter=100,
                             max_no_improvement=10, reassignment_ratio=0.01, return_info=False,
-                            assign=None, max_steps=None):
+                            assign=None, max_steps=None, argsort=None):
     """Restatement of sklearn 1.7.2 MiniBatchKMeans(k, batch_size=1000, random_state=42, n_init='auto').fit
     (cluster/_kmeans.py; reference call site clustering.py:207-218), operation for operation, on integer colours:
 
@@ -431,10 +448,11 @@ def minibatch_kmeans_labels(points, k, seed=42, batch_size=1000, max_iter=100,
       * centre update (_minibatch_update_dense / update_center_dense): per touched centre c*w, then += x for its batch
         members in batch order, w += count, c *= 1/w -- each operation rounded once, in that order;
       * reassignment (_mini_batch_step): to_reassign = w < ratio*max(w); when more than batch/2 qualify sklearn keeps
-        np.argsort(w)[:batch/2] -- an UNSTABLE sort over massively tied counts whose tie order depends on numpy's
-        SIMD sort kernel for the host CPU.  CANONICAL CHOICE (the only one left in this function): the stable order
-        (w asc, index asc).  tests/golden/make_golden.py pins everything else bit for bit by running sklearn itself with
-        that one np.argsort call forced to kind='stable';
+        np.argsort(w)[:batch/2] -- an UNSTABLE sort over massively tied counts whose tie order depends on which of
+        numpy's three argsort kernels the host runs (AVX-512, AVX2, scalar).  `argsort` = "npysort" (default since round
+        4): numpy's scalar aquicksort restated (npy_argsort.c) -- the whole fit then equals scikit-learn's UNTOUCHED
+        fit_predict under NPY_DISABLE_CPU_FEATURES = <AVX512 family> AVX2 FMA3, the host setting of record (G11 "scalar");
+        "stable" (rounds 1-3): the order (w asc, index asc) = sklearn with that one call forced to kind='stable';
       * early stopping: sklearn's EWA rule verbatim (tol = 0 => no centre-shift test).
     Returns labels int32[n] from a full E-step over all points (first arg-min)."""
     P = np.asarray(points, dtype=np.int64).reshape(-1, 3)
@@ -492,7 +510,10 @@ def minibatch_kmeans_labels(points, k, seed=42, batch_size=1000, max_iter=100,
         if do_reassign and reassignment_ratio > 0:
             to_re = W < reassignment_ratio * W.max()
             if to_re.sum() > 0.5 * bs:
-                keep = np.argsort(W, kind="stable")[int(0.5 * bs):]     # canonical: stable (sklearn: default quicksort)
+                if (argsort or DEFAULT_ARGSORT) == "stable":
+                    keep = np.argsort(W, kind="stable")[int(0.5 * bs):]
+                else:                                                   # sklearn: np.argsort(W), numpy's scalar aquicksort
+                    keep = npy_argsort_scalar(W)[int(0.5 * bs):]
                 to_re[keep] = False
             nre = int(to_re.sum())
             if nre:

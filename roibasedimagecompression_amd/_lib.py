@@ -61,6 +61,7 @@ PROTOTYPES = {
     "rhccq_cluster_means": (c_int32, [c_void_p, c_void_p, c_int64, c_void_p]),
     "rhccq_kmeans": (c_int32, [c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_int32, c_int32, c_void_p, c_void_p, c_void_p]),
     "rhccq_mbk_init": (c_int32, [c_void_p, c_void_p, C.POINTER(MbkProblem), c_int32, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p]),
+    "rhccq_npysort_head": (c_int32, [c_void_p, c_void_p, c_int32, c_int32, c_int32, c_void_p, c_void_p]),
     "rhccq_mbk_steps": (c_int32, [c_void_p, c_void_p, C.POINTER(MbkProblem), c_int32, c_int64, c_int32, c_void_p, c_int64, c_void_p,
                                   c_void_p, c_void_p, c_void_p, c_int64, c_int32, c_int32]),
     "rhccq_mbk_steps_overlapped": (c_int32, [c_void_p, c_void_p, C.POINTER(MbkProblem), c_int32, c_int64, c_int32, c_void_p, c_int64, c_void_p,

@@ -63,6 +63,10 @@ int rhccq_ctx_set_int(rhccq_ctx* ctx, int32_t option, int64_t value) {
       if (value != 0 && value != 1) return rhccq_fail(ctx, RHCCQ_E_ARG, "RHCCQ_OPT_REASSIGN_LDS: 0 or 1");
       ctx->opt_reassign_lds = (int)value;
       return 0;
+    case RHCCQ_OPT_REASSIGN_ORDER:
+      if (value != 0 && value != 1) return rhccq_fail(ctx, RHCCQ_E_ARG, "RHCCQ_OPT_REASSIGN_ORDER: 0 or 1");
+      ctx->opt_reassign_order = (int)value;
+      return 0;
     case RHCCQ_OPT_INIT_SHARDS:
       if (value != 1 && value != 2 && value != 4 && value != 8) return rhccq_fail(ctx, RHCCQ_E_ARG, "RHCCQ_OPT_INIT_SHARDS: 1, 2, 4 or 8");
       ctx->opt_init_shards = (int)value;

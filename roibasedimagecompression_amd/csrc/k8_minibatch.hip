@@ -1913,11 +1913,12 @@ __device__ unsigned long long g_upd_stamps[16];
 // while role 1 replays choice() (the shuffle's stream position does not depend on the selection); launch 2
 // (mbk_reassign_apply_kernel) moves the selected centres and, beside that, draws the next batch.  What travels between the
 // launches is a ReSel record per problem.
+#include "k8_npysort.h"
 struct ReSel {
   double thr, sel_w, wmin;
   long long cursor_choice;          // MT cursor behind the shuffle (-1: word table exhausted)
   int tag_sel, tag_choice;          // step + 1 of the step the two halves belong to
-  int capped, take, n_re, pad;
+  int capped, take, n_re, use_mask; // use_mask: a capped selection is the bit mask of npysort_head (numpy's order), not (sel_w, take, rank)
   int eq_base[kUpdWaves], rbase[kUpdWaves];
   int perm[kBatch / 2];             // permutation(batch)[:batch / 2]: more rows are never reassigned
 };
@@ -1925,7 +1926,7 @@ constexpr size_t kWLdsOff = offsetof(UpdShared, per);
 constexpr int kWLds = (int)((offsetof(UpdShared, perm) - offsetof(UpdShared, per)) / 4);
 template <bool kLds>
 __device__ __forceinline__ void reassign_select(UpdShared& sh, const double* __restrict__ W, const int k, const int bs, ReSel* __restrict__ rs,
-                                                const long long step, const bool stamp) {
+                                                const long long step, const bool stamp, const QsScratch* __restrict__ qs) {
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
 #ifdef RHCCQ_STAMPS
   unsigned long long _rl = clock64();
@@ -1970,12 +1971,16 @@ __device__ __forceinline__ void reassign_select(UpdShared& sh, const double* __r
   c1 = block_sum_i(c1, sh);
   if (tid == 0 && use_hist) { sh.hist[0] = c0; if (kHistBins > 1 && thr > 1.0) sh.hist[1] = c1; }
   __syncthreads();
-  // more than batch/2 candidates: sklearn keeps np.argsort(weights)[:batch/2] -- an unstable sort over tied counts;
-  // CANONICAL: the stable order (weight, index), the one choice of this path that is not sklearn's own
+  // more than batch/2 candidates: sklearn keeps np.argsort(weights)[:batch/2] -- an unstable sort over tied counts.
+  // qs != nullptr (RHCCQ_OPT_REASSIGN_ORDER = 1, the default): the slots numpy's scalar quicksort fills (k8_npysort.h), as a bit
+  // mask; otherwise the stable order (weight, index) of rounds 1-3: a threshold weight + index-ordered ranks among its ties
   const bool capped = cnt > 0.5 * (double)bs;
+  const bool use_mask = capped && qs != nullptr;
   double sel_w = thr;
   int take = 0;
-  if (capped) {
+  if (use_mask) {
+    npysort_head(sh, W, k, cap, *qs, -1);
+  } else if (capped) {
     if (use_hist) {
       if (tid == 0) {                                 // smallest weight v with #(W <= v) >= cap
         int below = 0, v = 0;
@@ -2008,7 +2013,7 @@ __device__ __forceinline__ void reassign_select(UpdShared& sh, const double* __r
   }
   // index-ordered ranks inside the wave's range, 64 at a time
   int eq_base = 0;
-  if (capped) {
+  if (capped && !use_mask) {
     int eq = 0;
     RHCCQ_WSWEEP({ eq += (w < thr) && (w == sel_w); })
     eq = (int)wave_sum((unsigned long long)eq);
@@ -2024,7 +2029,7 @@ __device__ __forceinline__ void reassign_select(UpdShared& sh, const double* __r
     const bool is_eq = capped && (w < thr) && (w == sel_w);
     const unsigned long long meq = __ballot(is_eq);
     const int rank = eq_run + __popcll(meq & ((1ull << lane) - 1ull));
-    const bool sel = j < j1 && reassign_sel(w, thr, capped, sel_w, take, rank);
+    const bool sel = j < j1 && (use_mask ? (w < thr && ((qs->mask[j >> 5] >> (j & 31)) & 1u) != 0u) : reassign_sel(w, thr, capped, sel_w, take, rank));
     nsel += __popcll(__ballot(sel));
     if (j < j1 && !sel) wmin = fmin(wmin, w);
     eq_run += __popcll(meq);
@@ -2037,7 +2042,7 @@ __device__ __forceinline__ void reassign_select(UpdShared& sh, const double* __r
   if (lane == 0) { rs->eq_base[wave] = eq_base; rs->rbase[wave] = rbase; }
   if (tid == 0) {
     rs->thr = thr; rs->sel_w = sel_w; rs->wmin = wmin;
-    rs->capped = capped ? 1 : 0; rs->take = take; rs->n_re = n_re;
+    rs->capped = capped ? 1 : 0; rs->take = take; rs->n_re = n_re; rs->use_mask = use_mask ? 1 : 0;
     rs->tag_sel = (int)(step + 1);
   }
 #undef RHCCQ_WSWEEP
@@ -2055,7 +2060,14 @@ struct UpdDraws {
   int draw_count, reassign_draws, expect_reassign, n_prob;
   int lds_weights;                   // RHCCQ_OPT_REASSIGN_LDS
   ReSel* resel;                      // [n_prob] what a reassigning step hands from the update kernel to mbk_reassign_apply_kernel
+  unsigned long long* qs_e;          // RHCCQ_OPT_REASSIGN_ORDER = 1: scratch of npysort_head, indexed by koff ([sum k] each); nullptr = stable order
+  int* qs_l;
+  int* qs_r;
+  unsigned* qs_mask;                 // [sum k / 32 + n_prob + 1]: problem p's words start at koff / 32 + p
 };
+__device__ __forceinline__ QsScratch qs_of(const UpdDraws& dr, const MbkP& P, int p) {
+  return QsScratch{dr.qs_e + P.koff, dr.qs_l + P.koff, dr.qs_r + P.koff, dr.qs_mask + (P.koff >> 5) + p};
+}
 
 __device__ __forceinline__ void mbk_update_body(UpdShared& sh, const int p, const int role, const uint32_t* __restrict__ keys,
                                                 const MbkP* __restrict__ probs, double* __restrict__ centres, double* __restrict__ weights,
@@ -2208,8 +2220,10 @@ __device__ __forceinline__ void mbk_update_body(UpdShared& sh, const int p, cons
 #ifdef RHCCQ_STAMPS
     if (tid == 0 && p == 0) atomicAdd(&g_upd_stamps[14], 1ull);
 #endif
-    if (dr.lds_weights && k <= kWLds && P.n <= (1ll << 24)) reassign_select<true>(sh, W, k, bs, dr.resel + p, step, p == 0);
-    else reassign_select<false>(sh, W, k, bs, dr.resel + p, step, p == 0);
+    const QsScratch qsv = qs_of(dr, P, p);
+    const QsScratch* qs = dr.qs_e != nullptr ? &qsv : nullptr;
+    if (dr.lds_weights && k <= kWLds && P.n <= (1ll << 24)) reassign_select<true>(sh, W, k, bs, dr.resel + p, step, p == 0, qs);
+    else reassign_select<false>(sh, W, k, bs, dr.resel + p, step, p == 0, qs);
   }
   USTAMP(4);
   // ---- a step that reassigned draws the next batch itself (role 2 stood back) -------------------------------------
@@ -2279,8 +2293,9 @@ __global__ __launch_bounds__(kUpdThreads) void mbk_reassign_apply_kernel(const u
   double* C = centres + P.koff * 4;
   double* W = weights + P.koff;
   const double thr = rs->thr, sel_w = rs->sel_w, wmin = rs->wmin;
-  const bool capped = rs->capped != 0;
+  const bool capped = rs->capped != 0, use_mask = rs->use_mask != 0;
   const int take = rs->take;
+  const unsigned* qmask = dr.qs_mask + (P.koff >> 5) + p;
   if (tid < bs / 2) sh.perm[tid] = n_re > 0 ? rs->perm[tid] : 0;
   if (tid < bs) sh.bkey[tid] = bkeys_cur[(size_t)p * kBatch + tid];
   __syncthreads();
@@ -2293,7 +2308,7 @@ __global__ __launch_bounds__(kUpdThreads) void mbk_reassign_apply_kernel(const u
     const bool is_eq = capped && (w < thr) && (w == sel_w);
     const unsigned long long meq = __ballot(is_eq);
     const int rank = eq_run + __popcll(meq & ((1ull << lane) - 1ull));
-    const bool sel = j < j1 && reassign_sel(w, thr, capped, sel_w, take, rank);
+    const bool sel = j < j1 && (use_mask ? (w < thr && ((qmask[j >> 5] >> (j & 31)) & 1u) != 0u) : reassign_sel(w, thr, capped, sel_w, take, rank));
     const unsigned long long msel = __ballot(sel);
     double wf = w;
     if (sel) {
@@ -2314,6 +2329,12 @@ __global__ __launch_bounds__(kUpdThreads) void mbk_reassign_apply_kernel(const u
 }
 
 #include "k8_overlap.h"
+
+__global__ __launch_bounds__(kUpdThreads) void npysort_head_kernel(const double* __restrict__ w, int k, int cap, int depth0, unsigned long long* e,
+                                                                   int* lpos, int* rpos, unsigned* mask) {
+  __shared__ UpdShared sh;
+  npysort_head(sh, w, k, cap, QsScratch{e, lpos, rpos, mask}, depth0);
+}
 
 // ------------------------------------------------------------------------------------------------
 // final E-step over all points
@@ -2612,6 +2633,7 @@ int64_t rhccq_mbk_work_bytes(const rhccq_mbk_problem* probs, int32_t n_prob) {
   bytes += 2 * align256((size_t)n_prob * kBatch * 4) + 2 * align256((size_t)n_prob * kBatch * 8);
   bytes += 4 * align256((size_t)n_prob * kBatch * 4);     // batches 2, 3 of the ring; the labels of even / odd steps
   bytes += align256((size_t)n_prob * sizeof(ReSel));        // what a reassigning step hands to its second launch
+  bytes += align256(ksum * 8) + 2 * align256(ksum * 4) + align256((ksum / 32 + (size_t)n_prob + 1) * 4);   // npysort_head (k8_npysort.h)
   return (int64_t)bytes;
 }
 
@@ -2628,6 +2650,10 @@ struct WorkView {
   double* pper[2];        // [n_prob][1024] the rows' inertia terms of even / odd steps (fold kernel -> mbk_inertia_block)
   int32_t* lab[2];        // [n_prob][1024] labels of even / odd steps (overlapped sequence: mbk_fix_kernel)
   ReSel* resel;           // [n_prob]
+  unsigned long long* qs_e;   // [sum k] scratch of npysort_head
+  int* qs_l;              // [sum k]
+  int* qs_r;              // [sum k]
+  unsigned* qs_mask;      // [sum k / 32 + n_prob + 1]
   long long max_k;
 };
 
@@ -2678,7 +2704,15 @@ static int layout_work(rhccq_ctx* ctx, const rhccq_mbk_problem* probs, int n_pro
   v->bkeys[3] = (uint32_t*)base; base += align256((size_t)n_prob * kBatch * 4);
   v->lab[0] = (int32_t*)base; base += align256((size_t)n_prob * kBatch * 4);
   v->lab[1] = (int32_t*)base; base += align256((size_t)n_prob * kBatch * 4);
-  v->resel = (ReSel*)base;
+  v->resel = (ReSel*)base; base += align256((size_t)n_prob * sizeof(ReSel));
+  {
+    size_t ksum = 0;
+    for (int i = 0; i < n_prob; ++i) ksum += (size_t)probs[i].k;
+    v->qs_e = (unsigned long long*)base; base += align256(ksum * 8);
+    v->qs_l = (int*)base; base += align256(ksum * 4);
+    v->qs_r = (int*)base; base += align256(ksum * 4);
+    v->qs_mask = (unsigned*)base;
+  }
   v->max_k = 0;
   for (int i = 0; i < n_prob; ++i) v->max_k = probs[i].k > v->max_k ? probs[i].k : v->max_k;
   if (upload) {
@@ -2941,6 +2975,15 @@ int rhccq_mbk_init(rhccq_ctx* ctx, const uint32_t* keys, const rhccq_mbk_problem
   return 0;
 }
 
+int rhccq_npysort_head(rhccq_ctx* ctx, const double* w, int32_t k, int32_t cap, int32_t depth0, void* scratch, uint32_t* mask_out) {
+  if (!ctx || !w || !scratch || !mask_out || k < 2 || cap < 1 || cap >= k) return rhccq_fail(ctx, RHCCQ_E_ARG, "npysort_head: bad argument");
+  unsigned long long* e = (unsigned long long*)scratch;
+  int* lpos = (int*)(e + k);
+  hipLaunchKernelGGL(npysort_head_kernel, dim3(1), dim3(kUpdThreads), 0, ctx->stream, w, (int)k, (int)cap, (int)depth0, e, lpos, lpos + k, mask_out);
+  RHCCQ_LAUNCH_CHECK(ctx);
+  return 0;
+}
+
 int rhccq_mbk_steps(rhccq_ctx* ctx, const uint32_t* keys, const rhccq_mbk_problem* probs, int32_t n_prob, int64_t step0, int32_t n_steps,
                     const uint32_t* words, int64_t n_words, double* centres, double* weights, double* state, void* work,
                     int64_t work_bytes, int32_t estep_mode, int32_t estep_split) {
@@ -2993,7 +3036,8 @@ int rhccq_mbk_steps(rhccq_ctx* ctx, const uint32_t* keys, const rhccq_mbk_proble
     // arg-min over the centre tiles (tiled E-step) and every row's inertia term against the centres before the update
     hipLaunchKernelGGL(mbk_fold_tiles_kernel, dim3((1000 + 15) / 16, n_prob), dim3(64), 0, ctx->stream, v.probs, (const double*)state, step,
                        (const double*)centres, bk, v.pdist, v.pidx, v.part_off, v.pper[step & 1], use_grid ? 0 : 1);
-    const UpdDraws dr{{v.bkeys[0], v.bkeys[1], v.bkeys[2], v.bkeys[3]}, step + 1, 1, 1, no_reassign ? 0 : -1, n_prob, ctx->opt_reassign_lds, v.resel};
+    const UpdDraws dr{{v.bkeys[0], v.bkeys[1], v.bkeys[2], v.bkeys[3]}, step + 1, 1, 1, no_reassign ? 0 : -1, n_prob, ctx->opt_reassign_lds, v.resel,
+                      ctx->opt_reassign_order == 1 ? v.qs_e : nullptr, v.qs_l, v.qs_r, v.qs_mask};
     hipLaunchKernelGGL(mbk_update_kernel, dim3(n_prob, 2), dim3(kUpdThreads), 0, ctx->stream, keys, v.probs, centres, weights, state, step,
                        words, (long long)n_words, bk, dr, (const int32_t*)v.pidx, v.part_off, (const int32_t*)nullptr);
     if (!no_reassign)
@@ -3041,7 +3085,8 @@ int rhccq_mbk_steps_overlapped(rhccq_ctx* ctx, const uint32_t* keys, const rhccq
   }
   long long drawn = step0 + ((*carry & 1) ? 1 : 0);        // newest batch in the ring
   bool have_spec = (*carry & 2) != 0;
-  UpdDraws dr{{v.bkeys[0], v.bkeys[1], v.bkeys[2], v.bkeys[3]}, 0, 0, 0, 0, n_prob, ctx->opt_reassign_lds, v.resel};
+  UpdDraws dr{{v.bkeys[0], v.bkeys[1], v.bkeys[2], v.bkeys[3]}, 0, 0, 0, 0, n_prob, ctx->opt_reassign_lds, v.resel,
+              ctx->opt_reassign_order == 1 ? v.qs_e : nullptr, v.qs_l, v.qs_r, v.qs_mask};
   for (int s = 0; s < n_steps; ++s) {
     const long long step = step0 + s;
     const uint32_t* bk = v.bkeys[step & 3];

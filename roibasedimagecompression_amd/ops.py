@@ -196,6 +196,7 @@ class Rhccq:
         self._mtw_dev = None
 
     OPT_INIT_LDS_BLOCKS, OPT_INIT_MAX_ITEMS, OPT_INIT_KERNEL, OPT_INIT_SHARDS, OPT_INIT_CANDS_PER_WAVE, OPT_REASSIGN_LDS = 1, 2, 3, 4, 5, 6
+    OPT_REASSIGN_ORDER = 7           # 1 (default): numpy's scalar-quicksort tie order of the capped reassignment; 0: stable (rounds 1-3)
 
     def _bind_stream(self):
         """kernels follow torch's current stream (see _StreamBoundLib)"""
@@ -228,10 +229,19 @@ class Rhccq:
                     w = owner.mtw.ensure(max(n, 2 * have, 1 << 22))
                     t = torch.from_numpy(w.view(np.int32)).to(self.device)      # blocking copy: complete on return
                     torch.cuda.current_stream(self.device).synchronize()
-                    # a superseded table may still be read by kernels another lane has queued on ITS stream: keep it alive
-                    # (a few MB each, log2(n) of them at most) instead of handing its block back to the caching allocator
+                    # a superseded table may still be read by kernels another lane has queued on ITS stream: keep it alive until
+                    # every stream of the family has passed an event recorded now, then hand its block back to the allocator
+                    retired = owner.__dict__.setdefault("_mtw_retired", [])
+                    retired[:] = [(tab, evs) for tab, evs in retired if not all(e.query() for e in evs)]
                     if owner._mtw_dev is not None:
-                        owner.__dict__.setdefault("_mtw_retired", []).append(owner._mtw_dev)
+                        streams = [torch.cuda.current_stream(self.device), torch.cuda.default_stream(self.device)]
+                        streams += [ls for ls, _ in owner.__dict__.get("_lanes", {}).values()]
+                        evs = []
+                        for ls in streams:
+                            e = torch.cuda.Event()
+                            e.record(ls)
+                            evs.append(e)
+                        retired.append((owner._mtw_dev, evs))
                     owner._mtw_dev = t
         t.record_stream(torch.cuda.current_stream(self.device))                 # (allocated on whichever lane grew it, used on this one)
         return t
@@ -607,10 +617,12 @@ class Rhccq:
         par = step & 1
         since = int(st[0, 12 if par else 3])
         split = estep_split or next((sp for sp in (1, 2, 4, 8) if ((k + 511) // 512) * 2 * sp >= 1536), 8)
-        # MT19937 words for ALL remaining steps (no regrowth mid-run): a draw of 1000 rows consumes < 2000 words on average even at
-        # the worst acceptance (1/2), a reassigning step (at most one in 10 k / 1000 + the first steps) another ~1400 for its shuffle;
-        # twice that plus the kernels' own end-of-table margins
-        words = self._mt_words_dev(cur_max + (limit - step + 4) * 4200 + 8 * words_per_step)
+        # MT19937 words for a BOUNDED horizon -- the chunks in flight plus the one being queued, counted from the last cursor the host
+        # has seen -- regrown between chunks (a superseded table stays alive for the kernels already queued on it, _mt_words_dev):
+        # a draw of 1000 rows consumes < 2000 words on average even at the worst acceptance (1/2), a reassigning step (at most one in
+        # 10 k / 1000 + the first steps) another ~1400 for its shuffle; twice that plus the kernels' own end-of-table margins.  (Sizing
+        # for all 100 n / 1000 possible steps asked for ~2.5 GB per 1.5 M-colour problem that then stopped after tens of steps.)
+        cur_known, steps_known = int(cur_max), int(step)
         carry = C.c_int32(0)
         stream = torch.cuda.current_stream(self.device)
         pending = []                                         # (pinned copy of the state, event) per chunk in flight
@@ -621,6 +633,7 @@ class Rhccq:
         while True:
             if step < limit:
                 ns = int(min(chunk, limit - step))
+                words = self._mt_words_dev(cur_known + (step - steps_known + ns + 4) * 4200 + 8 * words_per_step)
                 self._check(self.lib.rhccq_mbk_steps_overlapped(self.ctx, self._p(keys), probs, 1, step, ns, self._p(words), words.numel(),
                                                                 self._p(centres), self._p(weights), self._p(state), self._p(work), wbytes,
                                                                 split, since, C.byref(carry)), "mbk_steps_overlapped")
@@ -640,6 +653,7 @@ class Rhccq:
                 host, ev = pending.pop(0)
                 ev.synchronize()
                 st = host.numpy().copy()
+                cur_known, steps_known = int(max(st[0, 9], st[0, 14])), int(st[0, 5])
                 if st[0, 4] >= 3 or st[0, 11] != 0 or st[0, 5] >= limit:
                     break
                 if not pending and step >= limit:
@@ -649,12 +663,23 @@ class Rhccq:
             st = pending[-1][0].numpy().copy()
         return step, st, n_ov
 
+    def npysort_head(self, w, cap, depth0=-1):
+        """the SET np.argsort(w)[:cap] under numpy's scalar sort kernel (rhccq_npysort_head; w: non-negative integer counts as a
+        float64 device tensor or numpy array): bool[k] numpy mask.  The selection inside a capped mini-batch reassignment."""
+        w = w if torch.is_tensor(w) else self.dev(np.ascontiguousarray(w, dtype=np.float64))
+        k = int(w.numel())
+        scratch = self.empty((16 * k,), torch.uint8)
+        mask = self.empty(((k + 31) // 32,), torch.int32)
+        self._check(self.lib.rhccq_npysort_head(self.ctx, self._p(w), k, int(cap), int(depth0), self._p(scratch), self._p(mask)), "npysort_head")
+        bits = np.unpackbits(mask.cpu().numpy().view(np.uint8), bitorder="little")[:k]
+        return bits.astype(bool)
+
     def minibatch_kmeans(self, key_list, k_list, return_info=False, poll_steps=64, return_device=False, timing=None, estep="auto", estep_split=0,
                          lanes=None):
         """Batched MiniBatchKMeans(k, batch_size=1000, random_state=42).fit_predict labels: sklearn's fit operation
         for operation (RandomState(42) replayed from its raw MT19937 words, k-means++ in draw order, batch-ordered
-        centre updates; the one canonical choice is the stable tie order of the reassignment argsort -- see
-        oracle.minibatch_kmeans_labels).  key_list items are numpy arrays or
+        centre updates, the reassignment's np.argsort in the tie order of numpy's scalar quicksort -- csrc/k8_npysort.h;
+        OPT_REASSIGN_ORDER = 0 gives the stable order of rounds 1-3).  key_list items are numpy arrays or
         device int32 tensors (kept resident); labels come back as numpy arrays, or as device tensors
         with return_device=True.  `timing` (a dict) receives the HIP-event duration of the k-means++ launch
         (events on the launch stream).  `estep`: "auto" | "tiles" | "grid" -- how the batch E-step searches the

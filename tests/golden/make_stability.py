@@ -8,11 +8,13 @@ results depend on the host in two places: the summation order of OpenBLAS' kerne
 that tie exactly in integer arithmetic are told apart by rounding noise) and the tie order of numpy's unstable SIMD
 argsort (the low-count reassignment of MiniBatchKMeans).  This script re-runs the reference on the INPUTS of the committed
 fixtures (G4, G6, G9, G10, G13 through the reference's own functions; G11 through scikit-learn at the reference's call
-site) in child processes under four host settings
+site) in child processes under five host settings
 
-    default | OPENBLAS_CORETYPE=Sandybridge | NPY_DISABLE_CPU_FEATURES=<AVX512 family> | both
+    default | OPENBLAS_CORETYPE=Sandybridge | NPY_DISABLE_CPU_FEATURES=<AVX512 family> | both |
+    NPY_DISABLE_CPU_FEATURES=<AVX512 family> AVX2 FMA3   (numpy's scalar sort kernels: the setting of record since round 4,
+                                                          restated in oracle/npy_argsort.c -- make_golden_npysort.py)
 
-and records per case a hash of the output under each setting, whether all four agree (`reference_stable`) and whether the
+and records per case a hash of the output under each setting, whether all of them agree (`reference_stable`) and whether the
 default run equals the committed fixture (`default_equals_fixture`: the fixtures are genuine).  The tests then demand
 bit-exactness (Tier A, or A' = same pixels under a permuted palette, the reference's own thread-completion order) on every
 reference-stable case and report Tier-B deltas only where the reference itself is not reproducible.
@@ -39,6 +41,7 @@ SETTINGS = {
     "openblas_sandybridge": {"OPENBLAS_CORETYPE": "Sandybridge"},
     "numpy_no_avx512": {"NPY_DISABLE_CPU_FEATURES": AVX512},
     "both": {"OPENBLAS_CORETYPE": "Sandybridge", "NPY_DISABLE_CPU_FEATURES": AVX512},
+    "numpy_scalar": {"NPY_DISABLE_CPU_FEATURES": AVX512 + " AVX2 FMA3"},
 }
 
 
@@ -189,8 +192,9 @@ def worker():
         k = math.ceil(len(P) * (q / 100) / 10)
         m = MiniBatchKMeans(n_clusters=k, batch_size=1000, random_state=42, n_init="auto")
         lab = m.fit_predict(P.astype(np.float64)).astype(np.int32)
+        err = P.astype(np.float64) - m.cluster_centers_[lab]
         res[f"g11/{name}"] = {"exact": sha(lab, m.cluster_centers_), "pixels": sha(lab), "colours": int((np.bincount(lab, minlength=k) > 0).sum()),
-                              "n_steps": int(m.n_steps_), "k": int(k)}
+                              "n_steps": int(m.n_steps_), "k": int(k), "psnr": 10 * math.log10(255.0 ** 2 / float(np.mean(err * err)))}
         keep[name] = lab
     if want_labels:
         np.savez_compressed(want_labels, **keep)
@@ -225,6 +229,7 @@ def main():
             c["default_equals_fixture_pixels"] = d["pixels"] == d["fixture"]["pixels"]
         if "n_steps" in d:
             c["n_steps"] = {s: per[s]["n_steps"] for s in SETTINGS}
+            c["psnr"] = {s: per[s]["psnr"] for s in SETTINGS}
             c["k"] = d["k"]
         cases[key] = c
     # G11: where the untouched fit is the same under every setting, keep its labels (sha + step count in the json, arrays in the npz)

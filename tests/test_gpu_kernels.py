@@ -144,23 +144,65 @@ def test_minibatch_vs_oracle_bit_exact(rh, O, estep):
         assert np.array_equal(l, ol), (l == ol).mean()
 
 
-def test_minibatch_equals_sklearn_golden(rh, O):
-    """HIP MiniBatchKMeans against scikit-learn ITSELF (tests/golden/g11_mbk_sklearn.*: sklearn 1.7.2 fits with the one
-    np.argsort of _mini_batch_step forced stable, generated by make_golden_mbk.py): k-means++ picks, step count, centres
-    bit for bit and labels (hash) on 8 inputs up to 790 421 colours / k = 15 809 -- whole Lenna and whole Kodak frames as
-    one segment, the bench generator's 1 Mpx photo.  No oracle in between.  For the 4 cases with k < 500 this is the
-    reference's untouched result."""
-    from test_oracle_golden import check_against_g11, g11_cases, g11_palette
+def test_npysort_head_equals_numpy_scalar_argsort(rh, O):
+    """csrc/k8_npysort.h (the parallel emulation of numpy's scalar aquicksort_<double>, restricted to the partitions that straddle
+    slot `cap`) against np.argsort ITSELF under the scalar setting (g15_npysort.npz, generated by numpy) and, for other caps,
+    depth limits and sizes beyond 30 720, against the CPU restatement of the same sort (oracle/npy_argsort.c, itself pinned by
+    g15): the SET of the first `cap` entries must be identical."""
+    g = load("g15_npysort.npz")
+    n_checked = 0
+    for i in range(int(g["n"])):
+        w = g[f"w{i}"].astype(np.float64)
+        k = len(w)
+        if k < 3 or w.min() < 0 or not np.array_equal(w, np.floor(w)):
+            continue                                            # (the kernel takes the path's weights: integer counts)
+        order = g[f"o{i}"].astype(np.int64)
+        for cap in sorted({1, 2, k // 3, min(500, k - 1), k - 1} - {0}):
+            want = np.zeros(k, bool)
+            want[order[:cap]] = True
+            assert np.array_equal(rh.npysort_head(w, cap), want), (i, k, cap)
+            n_checked += 1
+    assert n_checked >= 300, n_checked
+    rng = np.random.default_rng(15)
+    for k, draws, depth0 in ((100, 30, 0), (5000, 700, 1), (30128, 1000, 2), (30128, 29000, 3), (70001, 2000, -1), (70001, 150000, 4),
+                             (200003, 1000, -1), (20771, 3000, 0), (4097, 4097, 2)):
+        w = np.zeros(k)
+        np.add.at(w, rng.integers(0, k, draws), 1.0)
+        order = O.npy_argsort_scalar(w, depth0)
+        for cap in (500 if k > 501 else 17, k // 2):
+            want = np.zeros(k, bool)
+            want[order[:cap]] = True
+            assert np.array_equal(rh.npysort_head(w, cap, depth0), want), (k, draws, depth0, cap)
+
+
+@pytest.mark.parametrize("order", ["npysort", "stable"])
+def test_minibatch_equals_sklearn_golden(rh, O, order):
+    """HIP MiniBatchKMeans against scikit-learn ITSELF on 8 inputs up to 790 421 colours / k = 15 809 -- whole Lenna and whole
+    Kodak frames as one segment, the bench generator's 1 Mpx photo: k-means++ picks, step count, centres bit for bit and labels
+    (hash).  No oracle in between.
+      npysort (the default, RHCCQ_OPT_REASSIGN_ORDER = 1): scikit-learn's UNTOUCHED fit_predict under numpy's scalar sort kernels
+        (g11_scalar.*, make_golden_npysort.py) -- the reference's own result on such a host, at every k;
+      stable (rounds 1-3): the fit with the one np.argsort of _mini_batch_step forced stable (g11_mbk_sklearn.*).
+    For the cases with k < 500 (no capped reassignment) both are the reference's untouched result on every host."""
+    from test_oracle_golden import check_against_g11, g11_cases, g11_palette, g11_scalar
     cases = g11_cases()
     g = load("g11_mbk_sklearn.npz")
+    scases, sg = g11_scalar()
     names = list(cases)
     pals = [g11_palette(n, cases[n]) for n in names]
-    labs, info = rh.minibatch_kmeans([O.pack_rgb(P) for P in pals], [cases[n]["k"] for n in names], return_info=True)
+    rh.set_option(rh.OPT_REASSIGN_ORDER, 1 if order == "npysort" else 0)
+    try:
+        labs, info = rh.minibatch_kmeans([O.pack_rgb(P) for P in pals], [cases[n]["k"] for n in names], return_info=True)
+    finally:
+        rh.set_option(rh.OPT_REASSIGN_ORDER, 1)
     untouched = load("g11_untouched.npz")          # sklearn's untouched fit where it is identical under every host setting (make_stability.py)
     assert len(untouched.files) >= 3
     for i, n in enumerate(names):
         a, b = info["koff"][i], info["koff"][i + 1]
-        check_against_g11(n, cases[n], g, info["chosen"][a:b], info["state"][i][5], info["centres"][a:b, :3], labs[i])
+        if order == "npysort":
+            check_against_g11(n, scases[n], sg, info["chosen"][a:b], info["state"][i][5], info["centres"][a:b, :3], labs[i], record="scalar")
+        else:
+            check_against_g11(n, cases[n], g, info["chosen"][a:b], info["state"][i][5], info["centres"][a:b, :3], labs[i])
         if n in untouched.files:
             assert np.array_equal(labs[i], untouched[n]), (n, "HIP labels vs the untouched scikit-learn fit")
 
@@ -203,19 +245,28 @@ def test_minibatch_overlapped_steps_equal_the_classic_sequence(rh, O):
     assert total >= 300, total                                # the overlapped sequence did run
 
 
-def test_minibatch_overlapped_equals_sklearn_golden(rh, O):
+@pytest.mark.parametrize("order", ["npysort", "stable"])
+def test_minibatch_overlapped_equals_sklearn_golden(rh, O, order):
     """The overlapped sequence against scikit-learn itself: the g11 fixtures with every problem on a lane of its own (a lone
-    problem is what rhccq_mbk_steps_overlapped takes)."""
-    from test_oracle_golden import check_against_g11, g11_cases, g11_palette
+    problem is what rhccq_mbk_steps_overlapped takes), under both tie orders of the reassignment (see above)."""
+    from test_oracle_golden import check_against_g11, g11_cases, g11_palette, g11_scalar
     cases = g11_cases()
     g = load("g11_mbk_sklearn.npz")
+    scases, sg = g11_scalar()
     names = list(cases)
     pals = [g11_palette(n, cases[n]) for n in names]
-    labs, info = rh.minibatch_kmeans([O.pack_rgb(P) for P in pals], [cases[n]["k"] for n in names], return_info=True, lanes=len(names))
+    rh.set_option(rh.OPT_REASSIGN_ORDER, 1 if order == "npysort" else 0)
+    try:
+        labs, info = rh.minibatch_kmeans([O.pack_rgb(P) for P in pals], [cases[n]["k"] for n in names], return_info=True, lanes=len(names))
+    finally:
+        rh.set_option(rh.OPT_REASSIGN_ORDER, 1)
     assert info["overlapped_launches"] > 0
     for i, n in enumerate(names):
         a, b = info["koff"][i], info["koff"][i + 1]
-        check_against_g11(n, cases[n], g, info["chosen"][a:b], info["state"][i][5], info["centres"][a:b, :3], labs[i])
+        if order == "npysort":
+            check_against_g11(n, scases[n], sg, info["chosen"][a:b], info["state"][i][5], info["centres"][a:b, :3], labs[i], record="scalar")
+        else:
+            check_against_g11(n, cases[n], g, info["chosen"][a:b], info["state"][i][5], info["centres"][a:b, :3], labs[i])
 
 
 def test_minibatch_more_than_256_problems(rh, O):

@@ -226,16 +226,65 @@ def g11_palette(name, case):
     return u
 
 
-def check_against_g11(name, case, g, picks, n_steps, centres, labels):
-    """Tier A against scikit-learn itself (stable-argsort fit, tests/golden/make_golden_mbk.py): k-means++ picks, step
-    count, centres bit for bit, labels by hash"""
+def g11_scalar():
+    """G11 under numpy's scalar sort kernels (make_golden_npysort.py): scikit-learn's UNTOUCHED fit_predict, the records of
+    record since round 4"""
+    import json
+    return json.load(open(os.path.join(G, "g11_scalar.json")))["cases"], load("g11_scalar.npz")
+
+
+def check_against_g11(name, case, g, picks, n_steps, centres, labels, record="stable"):
+    """Tier A against scikit-learn itself: k-means++ picks, step count, centres bit for bit, labels by hash.
+    record = "scalar": the UNTOUCHED fit under NPY_DISABLE_CPU_FEATURES = <AVX512 family> AVX2 FMA3 (g11_scalar.*; `case` and `g`
+    from g11_scalar()); record = "stable": the fit with np.argsort forced stable (g11_mbk_sklearn.*, make_golden_mbk.py)"""
     import hashlib
+    rec = case["stable"] if record == "stable" else case
     assert np.array_equal(np.asarray(picks, np.int64), g[f"{name}_picks"].astype(np.int64)), (name, "k-means++ picks")
-    assert int(n_steps) == case["stable"]["n_steps"], (name, n_steps, case["stable"]["n_steps"])
+    assert int(n_steps) == rec["n_steps"], (name, n_steps, rec["n_steps"])
     assert np.array_equal(np.asarray(centres, np.float64), g[f"{name}_centres"]), (name, "centres")
     lab = np.ascontiguousarray(np.asarray(labels, np.int32))
     assert np.array_equal(np.bincount(lab, minlength=case["k"]), g[f"{name}_sizes"]), (name, "cluster sizes")
-    assert hashlib.sha256(lab.tobytes()).hexdigest() == case["stable"]["labels_sha256"], (name, "labels")
+    assert hashlib.sha256(lab.tobytes()).hexdigest() == rec["labels_sha256"], (name, "labels")
+
+
+def test_g15_numpy_scalar_argsort():
+    """oracle/npy_argsort.c (numpy's aquicksort_<double> + aheapsort_ restated) against np.argsort ITSELF run under the scalar
+    setting (make_golden_npysort.py): 140 vectors -- tied counts like the path's weight sums, random doubles, organ-pipe /
+    sawtooth / constant inputs, sizes 2 .. 30 128 -- identical permutations"""
+    g = load("g15_npysort.npz")
+    n = int(g["n"])
+    assert n >= 140
+    for i in range(n):
+        w = g[f"w{i}"].astype(np.float64)
+        assert np.array_equal(O.npy_argsort_scalar(w), g[f"o{i}"].astype(np.int64)), (i, len(w))
+
+
+def test_numpy_scalar_argsort_live():
+    """the same against the numpy of THIS machine, in a child process under the scalar setting, on fresh vectors (skipped
+    where numpy cannot be put into that setting)"""
+    import subprocess
+    code = ("import sys, numpy as np\n"
+            "from numpy._core._multiarray_umath import __cpu_features__ as f\n"
+            "assert not f.get('AVX2') and not f.get('AVX512F')\n"
+            "rng = np.random.default_rng(int(sys.argv[1]))\n"
+            "out = []\n"
+            "for n in (33, 700, 5000, 23000):\n"
+            "    w = np.zeros(n); np.add.at(w, rng.integers(0, n, n // 3 + 1), 1.0)\n"
+            "    out.append(np.argsort(w))\n"
+            "sys.stdout.buffer.write(np.concatenate(out).astype(np.int64).tobytes())\n")
+    env = dict(os.environ, NPY_DISABLE_CPU_FEATURES="AVX512F AVX512CD AVX512_SKX AVX512_CLX AVX512_CNL AVX512_ICL AVX512_SPR AVX2 FMA3")
+    r = subprocess.run([sys.executable, "-c", code, "99"], env=env, stdout=subprocess.PIPE, stderr=subprocess.PIPE)
+    if r.returncode != 0 and b"AssertionError" in r.stderr:
+        pytest.skip("numpy does not take the scalar setting here")
+    assert r.returncode == 0, r.stderr.decode()[-400:]
+    got = np.frombuffer(r.stdout, np.int64)
+    rng = np.random.default_rng(99)
+    want = []
+    for n in (33, 700, 5000, 23000):
+        w = np.zeros(n)
+        np.add.at(w, rng.integers(0, n, n // 3 + 1), 1.0)
+        want.append(O.npy_argsort_scalar(w))
+    assert np.array_equal(got, np.concatenate(want))
 
 
 @pytest.mark.parametrize("name", ["lenna192_q20", "lenna192_q10", "lenna_full_q20", "kodak1_q20", "kodak13_q10", "kodak23_q20",
@@ -251,12 +300,20 @@ def test_g11_minibatch_equals_sklearn(name):
     case = cases[name]
     g = load("g11_mbk_sklearn.npz")
     P = g11_palette(name, case)
-    lab, info = O.minibatch_kmeans_native(P, case["k"])
+    # (1) the restatement with numpy's scalar argsort (the default) == scikit-learn's UNTOUCHED fit under that host setting
+    scases, sg = g11_scalar()
+    assert scases[name]["k"] == case["k"] and scases[name]["img_sha256"] == case["img_sha256"]
+    lab_s, info_s = O.minibatch_kmeans_native(P, case["k"])
+    check_against_g11(name, scases[name], sg, info_s["picks"], info_s["n_steps"], info_s["centers"], lab_s, record="scalar")
+    # (2) with the stable order == scikit-learn with that one np.argsort forced stable (rounds 1-3)
+    lab, info = O.minibatch_kmeans_native(P, case["k"], argsort="stable")
     check_against_g11(name, case, g, info["picks"], info["n_steps"], info["centers"], lab)
     if case["k"] <= 700:
-        lab2, info2 = O.minibatch_kmeans_labels(P, case["k"], return_info=True)
-        check_against_g11(name, case, g, info2["picks"], info2["n_steps"], info2["centers"], lab2)
+        for kind, cc, gg, rec in (("npysort", scases[name], sg, "scalar"), ("stable", case, g, "stable")):
+            lab2, info2 = O.minibatch_kmeans_labels(P, case["k"], return_info=True, argsort=kind)
+            check_against_g11(name, cc, gg, info2["picks"], info2["n_steps"], info2["centers"], lab2, record=rec)
     if case["k"] < 500:
+        assert np.array_equal(lab, lab_s), "below the cap no argsort runs: both orders give the same fit"
         assert case["default"]["equals_stable"], "below the cap the reference's own fit is the stable one"
     # sklearn's UNTOUCHED fit (no forced argsort order), wherever it is the same under all four host settings of
     # make_stability.py: its labels themselves (g11_untouched.npz) must come out of the restatement
