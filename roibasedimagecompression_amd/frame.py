@@ -386,6 +386,7 @@ class FrameEncoder:
     # class runs as a pipeline of its own -- host thread, HIP stream, sibling context -- and its merge bookkeeping and level 2
     # disappear behind the slower class's level 1.
     PIPELINE_CLASSES = True       # (the tiled multi-GPU encoder turns it off: its collectives must stay in one order on every rank)
+    TABLE_BOUND = (2, 64)         # room reserved per MiniBatch-branch job in the frame-wide tables: a * (clusters + black) + b entries
 
     def _class_pipeline(self, S, ci, rhc, table_base, table_room, lut1, fp_all):
         """level 1 -> merge per region -> merge per class -> level 2 of class `ci` on context `rhc` (current stream: its own)"""
@@ -441,7 +442,6 @@ class FrameEncoder:
         return k1_off, regs, comp3, q2
 
     def _encode_pipelined(self, S):
-        import threading
         rh = self.rh
         classes = S["classes"]
         nblk = S["has_black"].astype(np.int64)
@@ -451,7 +451,8 @@ class FrameEncoder:
         for j in np.nonzero(S["present"])[0]:
             n_col = int(S["P"][j] - nblk[j])
             q = classes[S["job_class"][j]].quality
-            bound[j] = min(int(S["P"][j]), 2 * (-(-n_col * q // 1000) + int(nblk[j])) + 64) if n_col >= 10000 else int(S["P"][j])
+            bound[j] = (min(int(S["P"][j]), self.TABLE_BOUND[0] * (-(-n_col * q // 1000) + int(nblk[j])) + self.TABLE_BOUND[1])
+                        if n_col >= 10000 else int(S["P"][j]))
         base = [int(bound[:S["job_base"][ci]].sum()) for ci in range(len(classes))]
         room = [int(bound[S["job_base"][ci]:S["job_base"][ci + 1]].sum()) for ci in range(len(classes))]
         total = int(bound.sum())
@@ -495,8 +496,8 @@ class FrameEncoder:
             q2s.append(q2)
             if comp3 is not None:
                 comps3.append(comp3)
-        for t in (lut1, fp_all):
-            t.record_stream(here)
+        # (lut1, fp_all and e1map were allocated on `here` and written on the class streams: every later use or free on `here`
+        # is ordered behind those writes by the wait_event(done) above -- no record_stream needed)
         return per_class, comps3, q2s
 
     def encode(self, rgb, classes, want_levels=False, profile=False):
@@ -511,7 +512,12 @@ class FrameEncoder:
             try:
                 per_class, comps3, q2s = self._encode_pipelined(S)
             except _TableOverflow:
+                # a class's k-means splits outgrew its slice of the tables (the bound is a heuristic): both pipelines have
+                # finished (or been drained), their half-written tables are dropped and the serial path redoes the levels
                 per_class = None
+                for key in ("e1map", "e1map_complete", "lut1", "k1_off", "k1_total"):
+                    S.pop(key, None)
+                self.table_overflows = getattr(self, "table_overflows", 0) + 1
             if per_class is not None:
                 self._t("levels_1_2_per_class", t0)
                 levels = {"level1": per_class, "level2": comps3} if want_levels else None

@@ -9,6 +9,7 @@ completion order), each contributing its k-means children depth-first; old->new 
 children through the first equal palette row (find_color_index, clustering.py:803-808); mapping
 table stored as uint16 (clustering.py:373).
 """
+import logging
 import math
 
 import numpy as np
@@ -18,6 +19,19 @@ from .hostsort import _stable_order
 from .ops import MINIBATCH_THRESHOLD, clustering_params, pack_rgb, unpack_rgb
 
 __all__ = ["cluster_palettes", "cluster_palette", "merge_components", "clustering_params"]
+
+log = logging.getLogger("rhccq")
+MAPPING_ENTRIES = 1 << 16     # the reference's mapping_array is uint16 (clustering.py:373): new indices beyond 65 535 wrap
+
+
+def _flag_wrap(info, n_new):
+    """a clustered palette of more than 65 536 entries does not fit the reference's uint16 mapping_array --
+    its indices wrap modulo 65 536 there, and here (bit parity); the deviation a caller may want to know about is flagged"""
+    if n_new > MAPPING_ENTRIES:
+        info["mapping_wrapped"] = True
+        log.warning("clustered palette has %d entries: indices above 65535 wrap as in the reference's uint16 mapping_array "
+                    "(encoder/compression/clustering.py:373)", n_new)
+    return info
 
 
 class _Node:
@@ -88,7 +102,8 @@ def _cluster_resident(rh, jobs, idxs, results):
         new_keys, nblack, n_present = plans[i]
         mapped = mapped_all[offs[i]:offs[i + 1]]
         mapping_dev = torch.cat([torch.zeros(1, dtype=torch.int32, device=rh.device), mapped]) if nblack else mapped
-        results[s] = (new_keys, None, {"branch": "minibatch", "n_clusters": n_present, "n_large": 0, "mapping_dev": mapping_dev})
+        results[s] = (new_keys, None, _flag_wrap({"branch": "minibatch", "n_clusters": n_present, "n_large": 0, "mapping_dev": mapping_dev},
+                                                 nblack + n_present))
     return fallback
 
 
@@ -259,7 +274,7 @@ def cluster_palettes(rh, jobs):
                 mapping[tgt[first != tgt]] = 0
         info = {"branch": "minibatch" if len(nb) >= MINIBATCH_THRESHOLD else "dbscan",
                 "n_clusters": n_small[s] - len(noise_of[s]) + len(larges[s]), "n_large": len(larges[s]), "n_noise": int(len(noise_of[s]))}
-        results.append((new_keys, mapping, info))
+        results.append((new_keys, mapping, _flag_wrap(info, len(new_keys))))
     return results
 
 

@@ -97,3 +97,44 @@ def test_frame_with_black_single_colour_and_tiny_segments():
     idx = idx.view(np.uint16) if out["indices_dtype"] == "uint16" else idx
     assert np.array_equal(out["palette"], np.asarray(ref["palette"]).reshape(-1, 3))
     assert np.array_equal(idx.astype(np.int64).reshape(-1), np.asarray(ref["indices"]).reshape(-1))
+
+
+def test_more_than_65536_clusters_wrap_like_the_reference_and_say_so(caplog):
+    """SURVEY Appendix A-7 / VERDICT r3 item 8: the reference stores the old -> new index table as uint16 (clustering.py:373), so a
+    clustered palette of more than 65 536 entries wraps.  740 000 colours at q = 99 -> k = 73 260 clusters, none above mc: the
+    build reproduces the wrap (indices = true index mod 65 536, decoded colours follow the wrapped index) and flags it
+    (info["mapping_wrapped"], a warning on the `rhccq` logger).  The wrapped table is checked against its own definition here
+    (the CPU oracle needs minutes for a 73 000-pick k-means++ over 220 000 init samples); the unwrapped arithmetic it is made
+    of is what every other test compares with the oracle."""
+    import logging
+    import torch
+    from oracle import rhccq_oracle as O
+    from roibasedimagecompression_amd.ops import Rhccq
+    from roibasedimagecompression_amd import palette
+    rng = np.random.default_rng(65536)
+    P = np.unique(rng.integers(0, 256, (760000, 3)).astype(np.uint8), axis=0)[:740000]
+    keys = np.sort(O.pack_rgb(P))
+    keys = keys[keys != 0]
+    n = len(keys)
+    q = 99
+    eps, _, mc = O.clustering_params(n, q)
+    rh = Rhccq(0)
+    with caplog.at_level(logging.WARNING, logger="rhccq"):
+        new_keys, mapping, info = palette.cluster_palette(rh, q, keys, eps, mc)
+    assert info["branch"] == "minibatch" and info.get("mapping_wrapped") is True, info
+    assert len(new_keys) > 65536 and info["n_large"] == 0
+    assert any("clustering.py:373" in r.getMessage() for r in caplog.records)
+    mapping = np.asarray(mapping)
+    assert mapping.min() >= 0 and mapping.max() == 65535
+    # the wrapped table against its definition: the labels of the fit -> rank among the non-empty clusters -> & 0xFFFF
+    labs = rh.minibatch_kmeans([keys], [int(np.ceil(n * (q / 100) / 10))])[0]
+    present = np.zeros(labs.max() + 1, bool)
+    present[labs] = True
+    rank = np.cumsum(present) - 1
+    assert int(present.sum()) == len(new_keys)
+    assert np.array_equal(mapping, (rank[labs] & 0xFFFF).astype(mapping.dtype))
+    # a resident (device) palette takes the native plan (rhccq_cluster_plan_host): same table, same flag
+    job = {"keys_dev": torch.from_numpy(keys.view(np.int32)).to(rh.device), "has_black": False, "quality": q, "eps": eps, "mc": mc}
+    nk2, _, info2 = palette.cluster_palettes(rh, [job])[0]
+    assert info2.get("mapping_wrapped") is True and np.array_equal(nk2, new_keys)
+    assert np.array_equal(info2["mapping_dev"].cpu().numpy(), mapping)
