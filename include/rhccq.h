@@ -205,8 +205,9 @@ int rhccq_kmeans(rhccq_ctx* ctx, const uint32_t* keys, const int32_t* desc, cons
  * The fit is sklearn's, operation for operation: the RandomState(42) stream is replayed from its raw MT19937 words
  * (`words`, resident on the device), k-means++ runs over the init sample in draw order, batches are
  * randint(0, n, 1000), centre updates add the batch members in batch order, reassigned centres take the rows
- * choice(1000, replace=False) names.  One canonical choice: where sklearn keeps np.argsort(counts)[:500] (an unstable
- * sort over tied counts) the stable order (count, index) is used.  oracle.minibatch_kmeans_labels states the same. */
+ * choice(1000, replace=False) names.  Where sklearn keeps np.argsort(counts)[:500] -- an unstable sort over tied counts --
+ * the slots numpy's scalar quicksort fills are taken (RHCCQ_OPT_REASSIGN_ORDER, csrc/k8_npysort.h): the fit equals
+ * scikit-learn's untouched fit_predict under numpy's scalar sort kernels.  oracle.minibatch_kmeans_labels states the same. */
 typedef struct rhccq_mbk_problem {
   int64_t off;        /* first key of the problem in keys[] */
   int64_t n;          /* number of points */
@@ -311,6 +312,42 @@ int rhccq_mbk_steps_overlapped(rhccq_ctx* ctx, const uint32_t* keys, const rhccq
 int rhccq_mbk_assign(rhccq_ctx* ctx, const uint32_t* keys, const rhccq_mbk_problem* probs_host,
                      int32_t n_prob, const double* centres, void* work, int64_t work_bytes,
                      int32_t* labels_out);
+
+/* ---- the fused frame encoder as ONE native entry ----------------------------------------------------------
+ * rhccq.ipynb:978-1039 for one frame whose ROI / non-ROI segment label maps are given: per segment crop + black fix + unique colours
+ * (subregions.py:315-449), cluster(q) per segment and merge per region (:634-679), per class merge on the frame canvas + cluster(2q)
+ * (regions.py:9-70), merge of the classes + cluster(q3) + index dtype (image.py:243-286, compression.py:360-372) -- the ordering rules
+ * of clustering.py:249-377 and merging.py:52-82 as native host code (csrc/encode_frame.hip), the kernels above underneath.  The region
+ * classes run as host threads with HIP streams of their own, the MiniBatchKMeans problems of a class side by side on further streams;
+ * nothing of the interpreter is on the path.  Result identical to roibasedimagecompression_amd.frame.FrameEncoder.encode (tests).
+ *   classes[c]: labels = DEVICE int32[H*W] (0 = pixel not in the class, s >= 1 = segment id, ids global within the class and ascending
+ *     inside each region); seg_region = HOST int32[n_seg] (region of segment id s at [s - 1]); region_bbox = HOST int32[n_region][4]
+ *     (minr, minc, maxr, maxc); quality = the class's level-1 quality.  Classes in precedence order (ROI first).
+ *   palette_out: HOST uint8[pal_cap][3]; indices_out: DEVICE buffer of H * W * 4 bytes, written as uint8 / uint16 / uint32 [H][W]
+ *     (res->index_bytes) on the context's stream, complete when the call returns; n_unique_out (HOST int64[n_jobs], may be NULL):
+ *     unique colours per segment.  At most 2048 segments per frame (beyond: the sort-based path of the Python FrameEncoder).
+ * Returns 0, RHCCQ_E_ARG, RHCCQ_E_HIP or RHCCQ_E_LIMIT (too many segments, or pal_cap too small: res->n_colours says how many). */
+typedef struct rhccq_class_desc {
+  const int32_t* labels;
+  int32_t n_seg;
+  int32_t n_region;
+  const int32_t* seg_region;
+  const int32_t* region_bbox;
+  int32_t quality;
+  int32_t reserved;
+} rhccq_class_desc;
+typedef struct rhccq_frame_result {
+  int32_t n_colours;       /* palette entries */
+  int32_t index_bytes;     /* 1, 2 or 4 */
+  int32_t shape[2];        /* (H, W), or the single component's box when only one component reaches level 3 (merging.py:16-21) */
+  int32_t top_left[2];
+  int32_t quality3;
+  int32_t n_jobs;
+  double ms[8];            /* host clocks: [0] scan [1] unique [2] levels 1-2 (slowest class) [3] level 3 [4] compose [5] remap [6] total */
+  double class_ms[4][4];   /* per class (first four): level-1 clustering, first positions + merges, level-2 clustering, level-2 finish */
+} rhccq_frame_result;
+int rhccq_encode_frame(rhccq_ctx* ctx, const uint8_t* rgb, int32_t H, int32_t W, const rhccq_class_desc* classes, int32_t n_classes,
+                       uint8_t* palette_out, int32_t pal_cap, void* indices_out, int64_t* n_unique_out, rhccq_frame_result* res);
 
 /* ---- K6: index remap gather (clustering.py:373-377) ------------------------------------------ */
 int rhccq_remap(rhccq_ctx* ctx, const int32_t* idx, int64_t n, const int32_t* lut, int64_t lut_n,

@@ -20,6 +20,18 @@ class MbkProblem(C.Structure):
                 ("init_n", c_int64), ("rand_off", c_int64), ("first", c_int32), ("T", c_int32)]
 
 
+class ClassDesc(C.Structure):
+    """struct rhccq_class_desc (include/rhccq.h): one region class of a frame for rhccq_encode_frame"""
+    _fields_ = [("labels", c_void_p), ("n_seg", c_int32), ("n_region", c_int32), ("seg_region", c_void_p), ("region_bbox", c_void_p),
+                ("quality", c_int32), ("reserved", c_int32)]
+
+
+class FrameResult(C.Structure):
+    """struct rhccq_frame_result (include/rhccq.h)"""
+    _fields_ = [("n_colours", c_int32), ("index_bytes", c_int32), ("shape", c_int32 * 2), ("top_left", c_int32 * 2), ("quality3", c_int32),
+                ("n_jobs", c_int32), ("ms", c_double * 8), ("class_ms", (c_double * 4) * 4)]
+
+
 # name -> (restype, argtypes).  Every symbol include/rhccq.h declares is listed here; the CPU test
 # suite checks that the library exports all of them.
 PROTOTYPES = {
@@ -61,6 +73,8 @@ PROTOTYPES = {
     "rhccq_cluster_means": (c_int32, [c_void_p, c_void_p, c_int64, c_void_p]),
     "rhccq_kmeans": (c_int32, [c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_int32, c_int32, c_void_p, c_void_p, c_void_p]),
     "rhccq_mbk_init": (c_int32, [c_void_p, c_void_p, C.POINTER(MbkProblem), c_int32, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p]),
+    "rhccq_encode_frame": (c_int32, [c_void_p, c_void_p, c_int32, c_int32, C.POINTER(ClassDesc), c_int32, c_void_p, c_int32, c_void_p, c_void_p,
+                                     C.POINTER(FrameResult)]),
     "rhccq_npysort_head": (c_int32, [c_void_p, c_void_p, c_int32, c_int32, c_int32, c_void_p, c_void_p]),
     "rhccq_mbk_steps": (c_int32, [c_void_p, c_void_p, C.POINTER(MbkProblem), c_int32, c_int64, c_int32, c_void_p, c_int64, c_void_p,
                                   c_void_p, c_void_p, c_void_p, c_int64, c_int32, c_int32]),

@@ -7,7 +7,7 @@ import sys
 HERE = os.path.dirname(os.path.abspath(__file__))
 CSRC = os.path.join(HERE, "csrc")
 LIB = os.path.join(HERE, "librhccq_hip.so")
-SOURCES = ["api.hip", "k1_unique.hip", "k3_epscomp.hip", "k7_kmeans.hip", "k8_minibatch.hip", "k5_merge.hip", "dct_ext.hip", "metrics.hip", "px_dbscan_ext.hip", "split_score.hip", "slic.hip", "ccl.hip", "edges.hip", "morph.hip"]
+SOURCES = ["api.hip", "k1_unique.hip", "k3_epscomp.hip", "k7_kmeans.hip", "k8_minibatch.hip", "k5_merge.hip", "dct_ext.hip", "metrics.hip", "px_dbscan_ext.hip", "split_score.hip", "slic.hip", "ccl.hip", "edges.hip", "morph.hip", "encode_frame.hip"]
 # -ffp-contract=off: the KM64 float64 arithmetic and the eps boundary test must round every
 # operation separately (bit-exact against the oracle / the reference's non-FMA x86 arithmetic)
 FLAGS = ["--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC", "-ffp-contract=off", "-Wall", "-Wno-unused-function"]

@@ -33,6 +33,7 @@ int rhccq_ctx_create(int device, void* hip_stream, rhccq_ctx** out) {
 
 void rhccq_ctx_destroy(rhccq_ctx* ctx) {
   if (!ctx) return;
+  if (ctx->frame_state && ctx->frame_state_free) ctx->frame_state_free(ctx->frame_state);
   if (ctx->scratch) (void)hipFree(ctx->scratch);
   if (ctx->own_stream && ctx->stream) (void)hipStreamDestroy(ctx->stream);
   delete ctx;

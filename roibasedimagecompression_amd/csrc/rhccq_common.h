@@ -22,6 +22,9 @@ struct rhccq_ctx {
   int opt_init_cands_per_wave = 1;   // third-generation chain: candidates one search wave finds and descends for (1, 2 or 3)
   int opt_reassign_lds = 1;          // mini-batch reassignment sweeps read an LDS copy of the weights when it fits (0: always global memory)
   int opt_reassign_order = 1;        // capped reassignment takes numpy's scalar-quicksort slots (1, default) or the stable order (0)
+  // the lanes of rhccq_encode_frame (csrc/encode_frame.hip): sibling contexts with streams and arenas of their own, kept between frames
+  void* frame_state = nullptr;
+  void (*frame_state_free)(void*) = nullptr;
   int opt_init_shards = 1;   // workgroups per problem of the second-generation chain: 1 = one (default), 2 / 4 / 8 = at most that many
 };
 

@@ -540,6 +540,50 @@ class FrameEncoder:
         self._t("level3", t0)
         return self.finish(S, comps3, m3c, q3, res3, want_levels, levels, profile)
 
+    def encode_native(self, rgb, classes):
+        """The same frame through rhccq_encode_frame: frame.py + palette.py + the MiniBatchKMeans driver as native host code behind ONE C
+        entry (csrc/encode_frame.hip; SURVEY 8b) -- region classes and MiniBatchKMeans problems on std::threads with HIP streams of
+        their own, no interpreter on the path.  Same result dict as encode() (bit-identical: tests/test_gpu_frame.py); `timings` /
+        `class_timings` receive the entry's own host clocks."""
+        import ctypes as C
+        from ._lib import ClassDesc, FrameResult
+        rh = self.rh
+        H, W = int(rgb.shape[0]), int(rgb.shape[1])
+        assert rgb.dtype == torch.uint8 and rgb.is_contiguous()
+        descs = (ClassDesc * len(classes))()
+        keep = []
+        for d, c in zip(descs, classes):
+            assert c.labels.dtype == torch.int32 and c.labels.is_contiguous() and c.labels.numel() == H * W
+            sr = np.ascontiguousarray(c.seg_region, dtype=np.int32)
+            rb = np.ascontiguousarray(c.region_bbox, dtype=np.int32).reshape(-1, 4)
+            keep += [sr, rb]
+            d.labels, d.n_seg, d.n_region = c.labels.data_ptr(), int(c.n_seg), int(len(rb))
+            d.seg_region, d.region_bbox, d.quality = sr.ctypes.data, rb.ctypes.data, int(c.quality)
+        n_jobs = sum(int(c.n_seg) for c in classes)
+        out = torch.empty((H * W,), dtype=torch.int32, device=rh.device)
+        n_unique = np.zeros(max(n_jobs, 1), np.int64)
+        res = FrameResult()
+        pal_cap = 1 << 16
+        while True:
+            pal = np.empty((pal_cap, 3), np.uint8)
+            rc = rh.lib.rhccq_encode_frame(rh.ctx, rh._p(rgb), H, W, descs, len(classes), pal.ctypes.data, pal_cap, rh._p(out), n_unique.ctypes.data,
+                                           C.byref(res))
+            if rc == -3 and res.n_colours > pal_cap:             # RHCCQ_E_LIMIT: the palette is larger than the buffer
+                pal_cap = int(res.n_colours)
+                continue
+            rh._check(rc, "encode_frame")
+            break
+        eb = int(res.index_bytes)
+        dt = {1: torch.uint8, 2: torch.int16, 4: torch.int32}[eb]
+        idx = out.view(torch.uint8)[:H * W * eb].view(dt).reshape(H, W)
+        names = ("scan", "unique", "levels_1_2_per_class", "level3", "compose", "remap", "total")
+        self.timings = {n: res.ms[i] * 1e-3 for i, n in enumerate(names)}
+        cn = ("level1_cluster", "first_positions_merge", "level2_cluster", "level2_finish")
+        self.class_timings = {ci: {n: res.class_ms[ci][i] * 1e-3 for i, n in enumerate(cn)} for ci in range(min(len(classes), 4))}
+        return {"palette": pal[:int(res.n_colours)].copy(), "indices": idx, "indices_dtype": {1: "uint8", 2: "uint16", 4: "uint32"}[eb],
+                "shape": (int(res.shape[0]), int(res.shape[1])), "top_left": (int(res.top_left[0]), int(res.top_left[1])),
+                "quality3": int(res.quality3), "n_unique": n_unique[:n_jobs]}
+
     def encode_batch(self, frames):
         """frames: [(rgb, classes)].  Same results as encode() frame by frame, but the palettes of all frames
         go through ONE batched clustering call per level: the sequential k-means++ chains of all segments of

@@ -31,13 +31,24 @@ def specs_from_labels(rh, lab_list, qualities):
     return specs, oracle_classes
 
 
+def same_result(a, b):
+    import torch
+    return (np.array_equal(a["palette"], b["palette"]) and a["indices_dtype"] == b["indices_dtype"] and torch.equal(a["indices"], b["indices"])
+            and tuple(a["shape"]) == tuple(b["shape"]) and tuple(a["top_left"]) == tuple(b["top_left"]) and np.array_equal(a["n_unique"], b["n_unique"]))
+
+
 def run_both(rh, img, lab_list, qualities):
+    """the Python host (FrameEncoder.encode) against the oracle's chain; the NATIVE host (rhccq_encode_frame, csrc/encode_frame.hip) must
+    give the Python host's result bit for bit on every frame that comes through here (all 32 fuzz frames among them)"""
     import torch
     from oracle import rhccq_oracle as O
     from roibasedimagecompression_amd.frame import FrameEncoder
     specs, oc = specs_from_labels(rh, lab_list, qualities)
     enc = FrameEncoder(rh)
-    out = enc.encode(torch.from_numpy(img.copy()).to(rh.device), specs)
+    rgb = torch.from_numpy(img.copy()).to(rh.device)
+    out = enc.encode(rgb, specs)
+    nat = enc.encode_native(rgb, specs)
+    assert same_result(out, nat), "rhccq_encode_frame differs from FrameEncoder.encode"
     ref = O.encode_frame(img, oc, qualities)
     return out, ref
 
