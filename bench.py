@@ -57,6 +57,8 @@ def parse():
     ap.add_argument("--block", type=int, default=None, help="DCT extension block (8; 16 in stream mode)")
     ap.add_argument("--cpu-sample", type=int, default=1280, help="edge of the CPU-baseline crop (0 = skip)")
     ap.add_argument("--no-probes", action="store_true")
+    ap.add_argument("--host", choices=["native", "python"], default="native",
+                    help="frame mode: host side of the encoder -- rhccq_encode_frame (C++, csrc/encode_frame.hip) or the Python FrameEncoder")
     ap.add_argument("--frames-per-step", type=int, default=None,
                     help="frames encoded together per step and GPU (frame mode: 1 = configs[1]; stream mode: 24)")
     ap.add_argument("--lanes", type=int, default=None, help="stream mode: batches in flight on this many host threads (5)")
@@ -126,12 +128,14 @@ def dct_ext(rh, rgb, roi_mask, block):
     return rh.dct_quant(luma, block, qstep, want_coef=False)
 
 
-def one_step(rh, enc, rgb, specs, roi_mask, block, stage_acc=None, extra=()):
+def one_step(rh, enc, rgb, specs, roi_mask, block, stage_acc=None, extra=(), native=False):
     """one pass of the hot path over one batch: the frame (plus `extra` further frames when the step is a
     batch, --frames-per-step) and the DCT/quantisation extension of every frame"""
     import torch
     if extra:
         out = enc.encode_batch([(rgb, specs)] + [(r, sp) for r, sp, _ in extra])[0]
+    elif native:
+        out = enc.encode_native(rgb, specs)
     else:
         out = enc.encode(rgb, specs)
     t0 = time.perf_counter()
@@ -531,16 +535,29 @@ def main():
         for i in range(1, B):
             _, r_i, sp_i, m_i, _ = build_inputs(rh, H, W, 1234 + rank * B + i, (2, 1), q_roi, q_bg, args.sigma)
             extra.append((r_i, sp_i, m_i))
+        native = args.host == "native" and B == 1
         for _ in range(args.warmup):
-            one_step(rh, enc, rgb, specs, roi_mask, block, extra=extra)
+            one_step(rh, enc, rgb, specs, roi_mask, block, extra=extra, native=native)
         barrier()
         t0 = time.perf_counter()
         for _ in range(args.steps):
-            out = one_step(rh, enc, rgb, specs, roi_mask, block, extra=extra)
+            out = one_step(rh, enc, rgb, specs, roi_mask, block, extra=extra, native=native)
         barrier()
         dt = time.perf_counter() - t0
         if rank == 0:
-            one_step(rh, enc, rgb, specs, roi_mask, block, stage_acc=stages, extra=extra)
+            one_step(rh, enc, rgb, specs, roi_mask, block, stage_acc=stages, extra=extra, native=native)
+        other_host = None
+        if rank == 0 and B == 1 and world == 1 and not args.no_probes:
+            # the other host side on the same frame (same kernels, same result): how much of the step is the host language
+            for _ in range(2):
+                one_step(rh, enc, rgb, specs, roi_mask, block, native=not native)
+            torch.cuda.synchronize()
+            t1 = time.perf_counter()
+            for _ in range(args.steps):
+                one_step(rh, enc, rgb, specs, roi_mask, block, native=not native)
+            torch.cuda.synchronize()
+            other_host = {"host": "python (FrameEncoder.encode)" if native else "native (rhccq_encode_frame)",
+                          "ms_per_step": (time.perf_counter() - t1) / args.steps * 1e3}
         px = H * W * args.steps * world * B
         workload = ((f"configs[1]: single {W}x{H} RGB synthetic 'photo' frame per GPU (seed 1234+rank, sigma={args.sigma}), " if B == 1 else
                      ("configs[2]: " if batch_mode else "") +
@@ -559,13 +576,15 @@ def main():
         "value": px / dt / 1e6, "unit": "Mpixels/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
         "ms_per_step": dt / args.steps * 1e3, "higher_is_better": True, "scaling": scaling, "vs_baseline": None,
         "dtype": "u8 keys / int32 exact k-means++ / f64 Lloyd+mini-batch", "data": "synthetic" + (" (REHEARSAL: ranks share one GPU)" if rehearsal else ""),
-        "config": {"workload": workload, "mode": args.mode, "frames_per_step_per_gpu": B * L if mode == "stream" else B, "lanes": L, "parallelism": par},
+        "config": {"workload": workload, "mode": args.mode, "host": ("native C++ (rhccq_encode_frame)" if (mode == "frame" and B == 1 and args.host == "native") else "python"), "frames_per_step_per_gpu": B * L if mode == "stream" else B, "lanes": L, "parallelism": par},
     }
     if rank == 0:
         if stages:
             line["stages_ms"] = {k: round(v * 1e3, 3) for k, v in stages.items()}
             if getattr(enc, "class_timings", None):        # the two class pipelines run side by side: their own stage clocks
                 line["stages_ms"]["per_class"] = {str(ci): {k: round(v * 1e3, 3) for k, v in tm.items()} for ci, tm in sorted(enc.class_timings.items())}
+        if mode == "frame" and B == 1 and other_host is not None:
+            line["other_host"] = other_host
         line["final_colours"] = int(len(out["palette"]))
         line["unique_colours_per_segment"] = [int(v) for v in out["n_unique"]]
         probes = not args.no_probes and world == 1 and mode == "frame" and B == 1

@@ -16,6 +16,8 @@
 #include <algorithm>
 #include <chrono>
 #include <cmath>
+#include <cstdio>
+#include <cstdlib>
 #include <cstring>
 #include <map>
 #include <memory>
@@ -46,6 +48,12 @@ struct Err {
     const hipError_t e_ = (expr);                                                                      \
     if (e_ != hipSuccess) throw Err{RHCCQ_E_HIP, std::string(#expr) + ": " + hipGetErrorString(e_)};   \
   } while (0)
+
+// RHCCQ_TRACE=1: per-phase host clocks of every MiniBatchKMeans fit on stderr (diagnostic: adds stream synchronisations)
+bool trace_on() {
+  static const bool on = [] { const char* e = getenv("RHCCQ_TRACE"); return e && e[0] == '1'; }();
+  return on;
+}
 
 double now_ms() { return std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now().time_since_epoch()).count(); }
 
@@ -295,6 +303,8 @@ void free_frame_state(void* p) { delete (FrameState*)p; }
 void mbk_fit(Lane& L, const uint32_t* keys, int64_t n, int64_t k, int32_t* labels_out) {
   rhccq_ctx* c = L.ctx;
   MtTable& mt = MtTable::get();
+  const bool tr = trace_on();
+  double tt[6] = {now_ms(), 0, 0, 0, 0, 0};
   const int64_t bs = std::min<int64_t>(1000, n);
   int64_t init_size = 3 * bs;
   if (init_size < k) init_size = 3 * k;
@@ -324,7 +334,9 @@ void mbk_fit(Lane& L, const uint32_t* keys, int64_t n, int64_t k, int32_t* label
   EF_RC(c, rhccq_mbk_order(c, keys, &prob, 1, d_init, d_perm, otmp, obytes));
   double* centres = L.dzeros<double>((size_t)k * 4);
   int32_t* chosen = L.dzeros<int32_t>((size_t)k);
+  if (tr) { L.sync(); tt[1] = now_ms(); }
   EF_RC(c, rhccq_mbk_init(c, keys, &prob, 1, d_init, d_perm, d_rand, centres, chosen));
+  if (tr) { L.sync(); tt[2] = now_ms(); }
   double* weights = L.dzeros<double>((size_t)k);
   double st[16] = {0};
   st[8] = (double)k;                                                     // every centre starts with zero weight
@@ -405,7 +417,14 @@ void mbk_fit(Lane& L, const uint32_t* keys, int64_t n, int64_t k, int32_t* label
     check(st);
     running = st[11] == 0.0 && st[5] < (double)limit;
   }
+  if (tr) { L.sync(); tt[3] = now_ms(); }
   EF_RC(c, rhccq_mbk_assign(c, keys, &prob, 1, centres, work, wbytes, labels_out));
+  if (tr) {
+    L.sync();
+    tt[4] = now_ms();
+    fprintf(stderr, "[rhccq] mbk n=%lld k=%lld: draws+order %.2f ms, chain %.2f ms (%.2f us/pick), %lld steps %.2f ms, assign %.2f ms\n", (long long)n,
+            (long long)k, tt[1] - tt[0], tt[2] - tt[1], (tt[2] - tt[1]) * 1e3 / (double)k, (long long)st[5], tt[3] - tt[2], tt[4] - tt[3]);
+  }
 }
 
 // ---- cluster_palette_colors_parallel for a list of palettes (palette.py::cluster_palettes) ------------------------------------
@@ -953,16 +972,22 @@ void class_pipeline(FrameCtx& F, int ci, Lane& L, ClassOut& out) {
   // pixel's entry for the final remap (merging.py:77-79)
   const int64_t class_entries = F.pal_off[(size_t)jb1] - F.pal_off[(size_t)jb0];
   int32_t* fp = L.dalloc<int32_t>((size_t)std::max<int64_t>(class_entries, 1));
-  {
-    // INT_MAX everywhere: a 32-bit pattern fill
-    EF_HIP(hipMemsetD32Async((hipDeviceptr_t)fp, (int)kIntMax, (size_t)std::max<int64_t>(class_entries, 1), L.stream));
-  }
+  for (size_t i = 0; i < ids.size(); ++i)               // INT_MAX over the entries in use (a 32-bit pattern fill per job)
+    if (!jobs[i].new_keys.empty())
+      EF_HIP(hipMemsetD32Async((hipDeviceptr_t)(fp + (F.pal_off[(size_t)ids[i]] - F.pal_off[(size_t)jb0])), (int)kIntMax, jobs[i].new_keys.size(), L.stream));
   const int32_t* lab_ptr[1] = {cls.labels};
   const int32_t jbase[1] = {jb0};
   EF_RC(c, rhccq_job_index_entries(c, F.rgb, F.H, F.W, 1, lab_ptr, jbase, F.bitmaps, F.prefix, F.d_pal_off, F.fix_key,
                                     fp - F.ebase[(size_t)ci], F.lut1, F.e1map + (size_t)ci * (size_t)F.H * (size_t)F.W));
-  std::vector<int32_t> fp_host((size_t)std::max<int64_t>(class_entries, 1));
-  L.download(fp_host.data(), fp, (size_t)class_entries);
+  // (only the clustered entries come back: a job's slice is as long as its palette, its clustered palette ~100x shorter)
+  std::vector<std::vector<int32_t>> fp_host(ids.size());
+  for (size_t i = 0; i < ids.size(); ++i) {
+    const int64_t lo = F.pal_off[(size_t)ids[i]] - F.pal_off[(size_t)jb0];
+    fp_host[i].resize(jobs[i].new_keys.size());
+    if (!jobs[i].new_keys.empty())
+      EF_HIP(hipMemcpyAsync(fp_host[i].data(), fp + lo, jobs[i].new_keys.size() * 4, hipMemcpyDeviceToHost, L.stream));
+  }
+  L.sync();
   std::map<int, std::shared_ptr<Comp>> seg_comp;
   for (size_t i = 0; i < ids.size(); ++i) {
     const int j = ids[i];
@@ -971,7 +996,7 @@ void class_pipeline(FrameCtx& F, int ci, Lane& L, ClassOut& out) {
     cp->keys = jb.new_keys;
     const int64_t lo = F.pal_off[(size_t)j] - F.pal_off[(size_t)jb0];
     cp->fp.resize(jb.new_keys.size());
-    for (size_t t = 0; t < cp->fp.size(); ++t) cp->fp[t] = fp_host[(size_t)lo + t];
+    for (size_t t = 0; t < cp->fp.size(); ++t) cp->fp[t] = fp_host[i][t];
     cp->top_left[0] = (int32_t)F.r0[(size_t)j]; cp->top_left[1] = (int32_t)F.c0[(size_t)j];
     cp->shape[0] = (int32_t)(F.r1[(size_t)j] - F.r0[(size_t)j] + 1); cp->shape[1] = (int32_t)(F.c1[(size_t)j] - F.c0[(size_t)j] + 1);
     std::vector<int32_t> id(jb.new_keys.size());

@@ -37,6 +37,11 @@ def test_4k_frame_properties(rh):
     a = enc.encode(rgb, specs)
     b = enc.encode(rgb, specs)
     assert np.array_equal(a["palette"], b["palette"]) and torch.equal(a["indices"], b["indices"])      # deterministic
+    # the native host (rhccq_encode_frame) == the Python host, configs[1] at full size, twice (warm lanes, reused arenas)
+    for _ in range(2):
+        n = enc.encode_native(rgb, specs)
+        assert np.array_equal(a["palette"], n["palette"]) and a["indices_dtype"] == n["indices_dtype"] and torch.equal(a["indices"], n["indices"])
+        assert np.array_equal(a["n_unique"], n["n_unique"]) and tuple(a["shape"]) == tuple(n["shape"])
     pal, idx = np.asarray(a["palette"]), _idx(a).reshape(H, W)
     assert idx.min() >= 0 and idx.max() < len(pal)
     used = np.bincount(idx.ravel(), minlength=len(pal)) > 0
