@@ -33,11 +33,22 @@ SEED = 42                            # random_state=42 at every sklearn call sit
 _DRAW_POOL = None
 
 
+def host_thread_budget():
+    """host threads ONE rank may keep busy: the cores this process may use, shared out over the ranks of the node (LOCAL_WORLD_SIZE under
+    torch.distributed.run: 8 ranks on one host must not start 8 x (8 draw + 16 lane + 16 class) workers on each other's cores)"""
+    try:
+        cores = len(os.sched_getaffinity(0))
+    except Exception:
+        cores = os.cpu_count() or 1
+    ranks = max(1, int(os.environ.get("LOCAL_WORLD_SIZE", "1") or 1))
+    return max(2, cores // ranks)
+
+
 def _draw_pool():
     global _DRAW_POOL
     if _DRAW_POOL is None:
         from concurrent.futures import ThreadPoolExecutor
-        _DRAW_POOL = ThreadPoolExecutor(max_workers=min(8, os.cpu_count() or 1), thread_name_prefix="rhccq-draw")
+        _DRAW_POOL = ThreadPoolExecutor(max_workers=min(8, host_thread_budget()), thread_name_prefix="rhccq-draw")
     return _DRAW_POOL
 
 
@@ -54,7 +65,8 @@ def lane_pool(kind):
             pool = _LANE_POOLS.get(kind)
             if pool is None:
                 from concurrent.futures import ThreadPoolExecutor
-                pool = _LANE_POOLS[kind] = ThreadPoolExecutor(max_workers=16, thread_name_prefix=f"rhccq-{kind}")
+                # (the workers mostly wait for the GPU: more of them than cores is fine, but not an unbounded multiple per rank)
+                pool = _LANE_POOLS[kind] = ThreadPoolExecutor(max_workers=min(16, 2 * host_thread_budget()), thread_name_prefix=f"rhccq-{kind}")
     return pool
 
 

@@ -22,7 +22,8 @@ import torch.distributed as dist
 from .frame import FrameEncoder, _Comp, _merge, _scatter_min          # noqa: F401
 from .ops import INT_MAX
 
-__all__ = ["shard_frames", "all_gather_stack", "all_reduce_min_", "TiledFrameEncoder", "tile_grid", "tiled_ccl", "stitch_tiles"]
+__all__ = ["shard_frames", "all_gather_stack", "all_reduce_min_", "TiledFrameEncoder", "tile_grid", "tiled_ccl", "stitch_tiles",
+           "exchange_segment_tables", "reduce_black_fix", "reduce_first_positions"]
 
 
 def shard_frames(n_frames, rank, world):
@@ -65,6 +66,53 @@ def all_reduce_min_(t, group=None):
     return t
 
 
+# ---- the three exchanges of the tile-parallel frame encoder, as functions of tensors (CPU tensors under gloo in the tests, device tensors
+# under RCCL): what crosses the ranks, in which order, and how it is combined -- tests/test_distributed_cpu.py runs them at world 8 ------
+def exchange_segment_tables(bitmaps, stats, origins, group=None):
+    """THE data-path collective: ONE all-gather of every tile's {segment colour bitmaps (int32[n_jobs][words]), segment statistics
+    (int32[n_jobs][6], tile coordinates)}.  -> (OR of the bitmaps over the tiles: the segments' colour sets of the whole frame, a
+    tensor like `bitmaps`; st int64[n_jobs][6] = (min row, max row, min col, max col, pixels, black pixels) in FRAME coordinates).
+    origins: int64[world][2] top-left corner of every rank's tile."""
+    n_jobs = int(bitmaps.shape[0])
+    payload = torch.cat([bitmaps.reshape(-1), stats.reshape(-1)])
+    allp = all_gather_stack(payload, group)
+    nb = bitmaps.numel()
+    allb = allp[:, :nb].reshape(allp.shape[0], n_jobs, -1)
+    merged = allb[0].clone()
+    for i in range(1, allb.shape[0]):
+        merged |= allb[i]
+    alls = allp[:, nb:].reshape(allp.shape[0], n_jobs, 6).cpu().numpy().astype(np.int64)
+    st = np.zeros((n_jobs, 6), np.int64)
+    cnt = alls[:, :, 4]
+    big = np.int64(INT_MAX)
+    st[:, 0] = np.where(cnt > 0, alls[:, :, 0] + origins[:, None, 0], big).min(0)
+    st[:, 1] = np.where(cnt > 0, alls[:, :, 1] + origins[:, None, 0], -1).max(0)
+    st[:, 2] = np.where(cnt > 0, alls[:, :, 2] + origins[:, None, 1], big).min(0)
+    st[:, 3] = np.where(cnt > 0, alls[:, :, 3] + origins[:, None, 1], -1).max(0)
+    st[:, 4], st[:, 5] = cnt.sum(0), alls[:, :, 5].sum(0)
+    return merged.reshape(bitmaps.shape), st
+
+
+def reduce_black_fix(has, norm, pos_global, key, needs_fix, device, group=None):
+    """The black-in-segment fix across tiles (subregions.py:393-421: the in-mask non-black pixel with the smallest R^2 + G^2 + B^2, first in
+    raster order): lexicographic MIN over the ranks of (norm2, frame raster position) -- one 8-byte-per-segment MIN all-reduce --, then the
+    winner's colour rides in a second one.  has / norm / pos_global / key: this tile's candidate per job.  -> uint32[n_jobs] fix keys."""
+    packed = np.where(has, (norm.astype(np.int64) << 40) | pos_global.astype(np.int64), np.int64(2 ** 62))
+    red = all_reduce_min_(torch.from_numpy(packed.copy()).to(device), group).cpu().numpy()
+    mine = has & (packed == red)
+    keyred = all_reduce_min_(torch.from_numpy(np.where(mine, key.astype(np.int64), np.int64(2 ** 62))).to(device), group).cpu().numpy()
+    return np.where(needs_fix, keyred, 0).astype(np.uint32)
+
+
+def reduce_first_positions(p_local, tile, frame_w, group=None):
+    """tile-local first raster positions (int64 tensor, INT_MAX = the entry has no pixel in this tile) -> frame raster positions -> MIN over
+    the ranks (one palette-sized all-reduce, reduced in place on the device under RCCL).  -> numpy int64"""
+    r0, c0, h, w = tile
+    g = torch.where(p_local >= INT_MAX, torch.full_like(p_local, INT_MAX),
+                    (torch.div(p_local, w, rounding_mode="floor") + r0) * frame_w + (p_local % w + c0))
+    return all_reduce_min_(g, group).cpu().numpy().astype(np.int64)
+
+
 class TiledFrameEncoder(FrameEncoder):
     """FrameEncoder whose per-pixel passes see one tile of the frame; `prepare` is the only stage that
     differs (exchange after the scan, global positions); levels 1-3 are inherited unchanged and run
@@ -97,24 +145,7 @@ class TiledFrameEncoder(FrameEncoder):
         bitmaps, stats = rh.new_job_state(n_jobs)
         rh.job_scan(rgb, labels, job_base[:-1], bitmaps, stats, black_is_colour=False)
         # ---- the one data-path collective: bitmaps + stats of every tile -----------------------------
-        payload = torch.cat([bitmaps.reshape(-1), stats.reshape(-1)])
-        allp = all_gather_stack(payload, self.group)
-        nb = bitmaps.numel()
-        allb = allp[:, :nb].reshape(allp.shape[0], n_jobs, -1)
-        bitmaps = allb[0].clone()
-        for i in range(1, allb.shape[0]):
-            bitmaps |= allb[i]
-        alls = allp[:, nb:].reshape(allp.shape[0], n_jobs, 6).cpu().numpy().astype(np.int64)
-        origins = self.tile_origins
-        st = np.zeros((n_jobs, 6), np.int64)
-        cnt = alls[:, :, 4]
-        big = np.int64(INT_MAX)
-        rmin = np.where(cnt > 0, alls[:, :, 0] + origins[:, None, 0], big).min(0)
-        rmax = np.where(cnt > 0, alls[:, :, 1] + origins[:, None, 0], -1).max(0)
-        cmin = np.where(cnt > 0, alls[:, :, 2] + origins[:, None, 1], big).min(0)
-        cmax = np.where(cnt > 0, alls[:, :, 3] + origins[:, None, 1], -1).max(0)
-        st[:, 0], st[:, 1], st[:, 2], st[:, 3] = rmin, rmax, cmin, cmax
-        st[:, 4], st[:, 5] = cnt.sum(0), alls[:, :, 5].sum(0)
+        bitmaps, st = exchange_segment_tables(bitmaps, stats, self.tile_origins, self.group)
         count, n_black = st[:, 4], st[:, 5]
         present = count > 0
         job_class = np.repeat(np.arange(len(classes)), [c.n_seg for c in classes])
@@ -140,14 +171,7 @@ class TiledFrameEncoder(FrameEncoder):
             has = b != np.uint64(2 ** 64 - 1)
             px = rgb.reshape(-1, 3)[torch.from_numpy(np.where(has, lp, 0)).to(rh.device)].cpu().numpy().astype(np.int64)
             key = (px[:, 0] << 16) | (px[:, 1] << 8) | px[:, 2]
-            # lexicographic MIN over ranks of (norm2, global position); the colour rides in a second reduction
-            packed = np.where(has, (norm << 40) | pos, np.int64(2 ** 62))
-            red = torch.from_numpy(packed.copy())
-            red = all_reduce_min_(red.to(rh.device), self.group).cpu().numpy()
-            mine = has & (packed == red)
-            keyred = torch.from_numpy(np.where(mine, key, np.int64(2 ** 62)))
-            keyred = all_reduce_min_(keyred.to(rh.device), self.group).cpu().numpy()
-            fk = np.where(needs_fix, keyred, 0).astype(np.uint32)
+            fk = reduce_black_fix(has, norm, pos, key, needs_fix, rh.device, self.group)
             fix_key = rh.dev(fk.view(np.int32))
         rh.job_set_black(bitmaps, np.nonzero(has_bg | all_black)[0])
         chunk, counts = rh.bitmap_count(bitmaps)
@@ -165,10 +189,7 @@ class TiledFrameEncoder(FrameEncoder):
         """tile-local first positions -> frame raster positions -> MIN over ranks: the only other exchange of
         the tiled path, the size of the clustered palettes (a few 10^4 int64 per segment at 4K)."""
         p = self.first_positions_dev(S, fp_lut, n_entries).to(torch.int64)      # stays on the device up to the collective (RCCL reduces it in place)
-        r0, c0, h, w = self.tile
-        W = self.frame_shape[1]
-        g = torch.where(p >= INT_MAX, torch.full_like(p, INT_MAX), (torch.div(p, w, rounding_mode="floor") + r0) * W + (p % w + c0))
-        return all_reduce_min_(g, self.group).cpu().numpy().astype(np.int64)
+        return reduce_first_positions(p, self.tile, self.frame_shape[1], self.group)
 
     @property
     def tile_origins(self):

@@ -185,3 +185,102 @@ def test_tiled_connected_components_two_ranks_gloo():
         assert ng + 1 == num and np.array_equal(stats, wstats)
         full[r0:r0 + h, c0:c0 + w] = lab
     assert np.array_equal(full, want)
+
+
+def _tiled8_worker(rank, world, port, ret):
+    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), LOCAL_WORLD_SIZE=str(world))
+    torch.set_num_threads(1)
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    try:
+        from roibasedimagecompression_amd import synth
+        from roibasedimagecompression_amd.ops import INT_MAX, host_thread_budget
+        from roibasedimagecompression_amd.parallel import exchange_segment_tables, reduce_black_fix, reduce_first_positions, tile_grid
+        H, W = 66, 100                                              # (not divisible by the grid: the edge tiles absorb the remainder)
+        img = synth.photo(H, W, 11).copy()
+        img[5:9, 30:64] = 0                                         # black inside segments 1 and 2, across tile seams
+        img[40:44, 70:90] = 0
+        lab = np.zeros((H, W), np.int32)                            # 3 segments straddling the seams; a strip belongs to none
+        lab[:, :40] = 1
+        lab[:, 40:82] = 2
+        lab[30:, 82:96] = 3
+        tiles = tile_grid(H, W, 2, 4)
+        assert len(tiles) == world
+        origins = np.array([[t[0], t[1]] for t in tiles], np.int64)
+        r0, c0, h, w = tiles[rank]
+        tile, ltile = img[r0:r0 + h, c0:c0 + w], lab[r0:r0 + h, c0:c0 + w]
+        keys = (tile[..., 0].astype(np.int64) << 16) | (tile[..., 1].astype(np.int64) << 8) | tile[..., 2]
+        n_jobs, words = 3, 1 << 19
+        # ---- stand-in for this tile's scan (K0 + K1a: csrc/k1_unique.hip, covered by the GPU tests)
+        bm = np.zeros((n_jobs, words), np.int32)
+        st = np.tile(np.array([2 ** 31 - 1, -1, 2 ** 31 - 1, -1, 0, 0], np.int32), (n_jobs, 1))
+        for j in range(n_jobs):
+            m = ltile == j + 1
+            k = keys[m]
+            k = k[k != 0].astype(np.uint32)
+            np.bitwise_or.at(bm[j].view(np.uint32), k >> 5, np.uint32(1) << (k & 31))
+            rr, cc = np.where(m)
+            if len(rr):
+                st[j] = (rr.min(), rr.max(), cc.min(), cc.max(), m.sum(), (keys[m] == 0).sum())
+        merged, gst = exchange_segment_tables(torch.from_numpy(bm), torch.from_numpy(st), origins)
+        # == the whole frame's tables, on every rank
+        fk_full = (img[..., 0].astype(np.int64) << 16) | (img[..., 1].astype(np.int64) << 8) | img[..., 2]
+        for j in range(n_jobs):
+            m = lab == j + 1
+            want = np.unique(fk_full[m])
+            want = want[want != 0]
+            got = np.nonzero(np.unpackbits(merged[j].numpy().view(np.uint8), bitorder="little"))[0]
+            assert np.array_equal(got, want), j
+            rr, cc = np.where(m)
+            assert gst[j].tolist() == [rr.min(), rr.max(), cc.min(), cc.max(), int(m.sum()), int((fk_full[m] == 0).sum())], (j, gst[j])
+        # ---- black fix: this tile's candidate per job = in-mask non-black pixel with the smallest norm2, first in the tile's raster
+        needs_fix = (gst[:, 5] > 0) & (gst[:, 4] > gst[:, 5])
+        assert needs_fix.tolist() == [True, True, True]
+        n2 = (tile.astype(np.int64) ** 2).sum(-1)
+        has = np.zeros(n_jobs, bool)
+        norm, posg, key = np.zeros(n_jobs, np.int64), np.full(n_jobs, INT_MAX, np.int64), np.zeros(n_jobs, np.int64)
+        for j in range(n_jobs):
+            m = (ltile == j + 1) & (keys != 0)
+            if needs_fix[j] and m.any():
+                cand = np.flatnonzero(m.ravel())
+                best = cand[np.argmin(n2.ravel()[cand])]             # first minimum in tile raster order
+                has[j], norm[j], key[j] = True, n2.ravel()[best], keys.ravel()[best]
+                posg[j] = (best // w + r0) * W + (best % w + c0)
+        fk = reduce_black_fix(has, norm, posg, key, needs_fix, torch.device("cpu"))
+        n2f = (img.astype(np.int64) ** 2).sum(-1)
+        for j in range(n_jobs):
+            if needs_fix[j]:
+                cand = np.flatnonzero(((lab == j + 1) & (fk_full != 0)).ravel())
+                best = cand[np.argmin(n2f.ravel()[cand])]            # whole frame: smallest norm2, first in raster order
+                assert int(fk[j]) == int(fk_full.ravel()[best]), j
+            else:
+                assert fk[j] == 0
+        # ---- first positions of 11 "clustered entries" (stand-in: the key modulo 11 of a pixel of segment 1 or 2)
+        ent = np.where((ltile == 1) | (ltile == 2), keys % 11, -1)
+        p = np.full(11, INT_MAX, np.int64)
+        for e in range(11):
+            hit = np.flatnonzero((ent == e).ravel())
+            if len(hit):
+                p[e] = hit[0]
+        fp = reduce_first_positions(torch.from_numpy(p), tiles[rank], W)
+        entf = np.where((lab == 1) | (lab == 2), fk_full % 11, -1).ravel()
+        for e in range(11):
+            hit = np.flatnonzero(entf == e)
+            assert fp[e] == (hit[0] if len(hit) else INT_MAX), e
+        ret[rank] = ("ok", host_thread_budget())
+    finally:
+        dist.destroy_process_group()
+
+
+def test_tiled_exchange_world8_2x4():
+    """configs[3]'s decomposition at its stated rank count, on the CPU: 8 gloo ranks, one tile each of a 2 x 4 tiling (edge tiles of other
+    sizes, segments and black patches across the seams) run the three exchanges of TiledFrameEncoder -- the all-gather + OR of the
+    segment tables, the lexicographic MIN of the black fix, the MIN of the first positions -- through the product functions
+    (parallel.exchange_segment_tables / reduce_black_fix / reduce_first_positions); every rank must end with the whole frame's
+    tables.  The per-tile kernels are stood in by numpy (they are covered at world 2 on the GPU: tests/test_gpu_tiled.py).  Also: the
+    per-rank host thread budget divides the cores by LOCAL_WORLD_SIZE."""
+    world = 8
+    ret = mp.Manager().dict()
+    mp.spawn(_tiled8_worker, args=(world, _free_port(), ret), nprocs=world, join=True)
+    assert [ret[r][0] for r in range(world)] == ["ok"] * world
+    cores = len(os.sched_getaffinity(0))
+    assert all(ret[r][1] == max(2, cores // world) for r in range(world))
