@@ -62,7 +62,7 @@ def connected_components_with_stats(mask, connectivity=8, numbering="opencv", rh
     rh = rh or default_context()
     m = np.ascontiguousarray(np.asarray(mask) != 0).view(np.uint8)
     n, labels, stats = rh.ccl(torch.from_numpy(m).to(rh.device), connectivity, numbering=numbering)
-    return n + 1, labels.cpu().numpy(), stats
+    return n + 1, rh.to_host(labels), stats
 
 
 def _region_dicts(mask, original_image, numbering):
@@ -155,8 +155,9 @@ def process_regions_with_reassignment(image_rgb, roi_mask, nonroi_mask):
     return new_roi, new_non
 
 
-def extract_roi_nonroi(original_image, region_map, buffer_size=3, rh=None):
-    """roi.py:685-718 -> (roi_image, nonroi_image, roi_mask, nonroi_mask) as numpy arrays"""
+def extract_roi_nonroi(original_image, region_map, buffer_size=3, rh=None, rgb_dev=None, region_dev=None):
+    """roi.py:685-718 -> (roi_image, nonroi_image, roi_mask, nonroi_mask) as numpy arrays.  rgb_dev / region_dev: the image / a 0-1 region
+    map already on the device (the resident chain hands them over instead of uploading the frame a second time)"""
     import torch
     rh = rh or default_context()
     original_image = np.ascontiguousarray(original_image, dtype=np.uint8)
@@ -172,6 +173,10 @@ def extract_roi_nonroi(original_image, region_map, buffer_size=3, rh=None):
         roi_image[~roi_mask] = 0
         non_image[~non_mask] = 0
         return roi_image, non_image, roi_mask, non_mask
-    rm = np.where(region_map == 1, 1, np.where(region_map == 0, 0, 2)).astype(np.uint8)
-    ri, ni, m1, m0 = rh.roi_buffer(torch.from_numpy(rm).to(rh.device), torch.from_numpy(np.array(original_image, dtype=np.uint8, order="C")).to(rh.device), buffer_size)
-    return ri.cpu().numpy(), ni.cpu().numpy(), m1.cpu().numpy(), m0.cpu().numpy()
+    if region_dev is None:
+        rm = np.where(region_map == 1, 1, np.where(region_map == 0, 0, 2)).astype(np.uint8)
+        region_dev = torch.from_numpy(rm).to(rh.device)
+    if rgb_dev is None:
+        rgb_dev = torch.from_numpy(np.array(original_image, dtype=np.uint8, order="C")).to(rh.device)
+    ri, ni, m1, m0 = rh.roi_buffer(region_dev, rgb_dev, buffer_size)
+    return tuple(rh.to_host(ri, ni, m1, m0))

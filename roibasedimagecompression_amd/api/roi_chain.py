@@ -314,14 +314,23 @@ def directional_region_unification(binary_image, border_sensitivity=0.3, min_reg
     return cleaned, (cleaned > 0).astype(np.uint8)
 
 
-def _unify_borders(d, borders_dev, original_image):
+def _unify_borders(d, borders_dev, original_image, rgb_dev=None):
+    import torch
     m = d.remove_thin(borders_dev, 0.10, 25)
     m = d.remove_small_noise(m, 75)
     m = d.rh.morph_close(m, ellipse_half_widths(11))
     m = d.bridge(m, 100, 0.2, 15, 25)
-    unified = _u8(d.unify(m))
-    region_map = (unified > 0).astype(np.uint8)
-    return (unified, region_map) + tuple(_roi.extract_roi_nonroi(original_image, region_map, rh=d.rh))
+    u_dev = d.unify(m)
+    if u_dev.dtype == torch.bool:
+        u_dev = u_dev.view(torch.uint8)
+    # the region map goes on to the buffer-zone kernel on the device; the six arrays of the reference's tuple come back together
+    # through page-locked buffers
+    region_dev = (u_dev != 0).to(torch.uint8)
+    if rgb_dev is None:
+        rgb_dev = torch.from_numpy(np.array(original_image, dtype=np.uint8, order="C")).to(d.rh.device)
+    ri, ni, m1, m0 = d.rh.roi_buffer(region_dev, rgb_dev, 3)
+    unified, region_map, roi_image, non_image, roi_mask, non_mask = d.rh.to_host(u_dev, region_dev, ri, ni, m1, m0)
+    return unified, region_map, roi_image, non_image, roi_mask, non_mask
 
 
 def process_and_unify_borders(edge_map, edge_density, original_image, density_threshold=0.3, border_sensitivity=0.3, min_region_size=30,
@@ -340,7 +349,7 @@ def get_regions(image_rgb):
     values, the smallest non-zero one is 1/9, the threshold a few thousandths: its last bits cannot move the mask)."""
     image_rgb = np.asarray(image_rgb)
     d = _Dev()
-    _, edge = _edges.edge_map_resident(image_rgb, d.rh)
+    a, edge = _edges.edge_map_resident(image_rgb, d.rh)
     counts = d.rh.box_count(edge, 3)
     hist = d.rh.masked_hist(edge, counts, 10)
     table = _density_table(3)
@@ -348,4 +357,4 @@ def get_regions(image_rgb):
     threshold = (float(np.dot(hist, table.astype(np.float64))) / n_edge if n_edge else 0.1) / 100
     above = np.flatnonzero(table > np.float32(threshold))
     borders = d.rh.value_mask(counts, int(above[0]) if len(above) else 10, edge)
-    return _unify_borders(d, borders, image_rgb)
+    return _unify_borders(d, borders, image_rgb, rgb_dev=a.rgb if image_rgb.ndim == 3 else None)

@@ -285,6 +285,19 @@ class Rhccq:
             t = t.to(dtype)
         return t.to(self.device, non_blocking=False)
 
+    def to_host(self, *tensors):
+        """device tensors -> numpy arrays through page-locked landing buffers (torch's caching host allocator), all copies in flight
+        together and ONE synchronisation: a 25 MB frame comes back in ~1 ms instead of ~4 through pageable memory.  The arrays own
+        their buffers (freed with them)."""
+        outs = []
+        for t in tensors:
+            h = torch.empty(t.shape, dtype=t.dtype, pin_memory=True)
+            h.copy_(t, non_blocking=True)
+            outs.append(h)
+        torch.cuda.current_stream(self.device).synchronize()
+        res = [h.numpy() for h in outs]
+        return res[0] if len(res) == 1 else res
+
     def zeros(self, shape, dtype):
         return torch.zeros(shape, dtype=dtype, device=self.device)
 
