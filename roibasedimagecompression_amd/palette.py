@@ -321,5 +321,5 @@ def merge_components(rh, comps, bbox):
         rh.merge_paint(idx, h, w, top, left, canvas, torch.from_numpy(lut).to(rh.device), len(pal))
     out = {"top_left": (minr, minc), "shape": (H, W), "palette": unpack_rgb(np.array(colors, dtype=np.uint32)),
            "indices_dev": canvas.reshape(-1), "single": False}
-    out["indices"] = out["indices_dev"].cpu().numpy()
+    out["indices"] = rh.to_host(out["indices_dev"])        # (33 MB at 4K: through a page-locked buffer)
     return out

@@ -17,7 +17,8 @@ class IndexList(Sequence):
     # -- materialisation ---------------------------------------------------------------------------
     def numpy(self):
         if self._np is None:
-            a = self._dev.cpu().numpy().reshape(-1)
+            from .ops import default_context
+            a = default_context(self._dev.device.index).to_host(self._dev).reshape(-1) if self._dev.numel() >= (1 << 16) else self._dev.cpu().numpy().reshape(-1)
             if a.dtype == np.int16:                      # uint16 storage of the device kernels
                 a = a.view(np.uint16)
             self._np = a
