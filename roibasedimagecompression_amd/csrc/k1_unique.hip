@@ -284,8 +284,9 @@ __global__ __launch_bounds__(256) void job_blackfix_kernel(const uint8_t* __rest
 // 4K frame is cut into, 12 GB at 2 048 jobs, impossible for a fine grid.  Here every masked pixel of every class becomes one
 // 64-bit key (job << 24 | colour), one radix sort (rocPRIM through hipCUB) puts equal (job, colour) pairs next to each other in
 // (job, R, G, B) order = np.unique order per job, a head flag + exclusive scan numbers the distinct pairs, and every pixel's rank
-// inside its job's palette is STORED (int32 per pixel and class) instead of being recomputed from a bitmap.  Memory: 16 B per
-// (pixel, class) of scratch + 4 B of rank, whatever the number of jobs.
+// inside its job's palette is STORED (int32 per pixel and class) instead of being recomputed from a bitmap.  Memory, whatever the
+// number of jobs: ~40 B of scratch per (pixel, class) entry (keys in / out 2 x 8 B, values in / out 2 x 4 B, head flags + their scan
+// 2 x 4 B, the radix sort's own scratch ~8 B: rhccq_job_sort_unique_bytes -- 0.66 GB for a 4K frame with two classes) + 4 B of rank.
 __global__ __launch_bounds__(256) void sort_keys_kernel(const uint8_t* __restrict__ rgb, int H, int W, ClassArgs ca, const uint32_t* __restrict__ fix_key,
                                                         const int32_t* __restrict__ black_jobs, int n_black, int invalid_shift,
                                                         unsigned long long* __restrict__ keys, uint32_t* __restrict__ vals) {
@@ -363,8 +364,8 @@ __global__ __launch_bounds__(256) void job_index_kernel(const uint8_t* __restric
   const int64_t n_quads = (n_px + 3) >> 2;
   for (int64_t q = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; q < n_quads; q += (int64_t)gridDim.x * blockDim.x) {
     const int64_t p0 = q << 2;
-    uint32_t key[4];
-    load4px(rgb, p0, n_px, key);
+    uint32_t key[4] = {0u, 0u, 0u, 0u};
+    if (rgb) load4px(rgb, p0, n_px, key);                  // (ranked path: no pixel colour is read at all -- rgb == nullptr, uniform branch)
     for (int c = 0; c < ca.n_class; ++c) {
       int32_t lab[4];
       load4lab(ca.labels[c], p0, n_px, lab);
@@ -424,8 +425,8 @@ __global__ __launch_bounds__(256) void frame_remap_kernel(const uint8_t* __restr
   const int64_t n_quads = (n_px + 3) >> 2;
   for (int64_t q = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; q < n_quads; q += (int64_t)gridDim.x * blockDim.x) {
     const int64_t p0 = q << 2;
-    uint32_t key[4];
-    load4px(rgb, p0, n_px, key);
+    uint32_t key[4] = {0u, 0u, 0u, 0u};
+    if (rgb) load4px(rgb, p0, n_px, key);                  // (ranked path: no pixel colour is read at all -- rgb == nullptr, uniform branch)
     int32_t res[4] = {-1, -1, -1, -1};
     for (int c = 0; c < ca.n_class; ++c) {
       if (res[0] >= 0 && res[1] >= 0 && res[2] >= 0 && res[3] >= 0) break;
@@ -684,8 +685,8 @@ int rhccq_job_index_ranked(rhccq_ctx* ctx, int32_t H, int32_t W, int32_t n_class
   ClassArgs ca;
   if (int e = make_class_args(ctx, n_class, labels_host, job_base_host, &ca)) return e;
   const int64_t quads = ((int64_t)H * W + 3) / 4;
-  // (the kernel reads no pixel colour on this path: rgb is only dereferenced by load4px, harmless on any mapped address -- pass the rank map)
-  hipLaunchKernelGGL(job_index_kernel, dim3(stream_grid(quads, 256)), dim3(256), 0, ctx->stream, (const uint8_t*)rankmap, H, W, ca, (const uint32_t*)nullptr,
+  // (the kernel reads no pixel colour on this path: rgb == nullptr skips the pixel load)
+  hipLaunchKernelGGL(job_index_kernel, dim3(stream_grid(quads, 256)), dim3(256), 0, ctx->stream, (const uint8_t*)nullptr, H, W, ca, (const uint32_t*)nullptr,
                      (const uint32_t*)nullptr, pal_off, (const uint32_t*)nullptr, (int32_t*)nullptr, first_pos, fp_lut, rankmap, (int32_t*)nullptr);
   RHCCQ_LAUNCH_CHECK(ctx);
   return 0;
@@ -777,7 +778,7 @@ int rhccq_frame_remap_ranked(rhccq_ctx* ctx, int32_t H, int32_t W, int32_t n_cla
                              const int32_t* rankmap, const int64_t* pal_off, const int32_t* lut, const int32_t* lut2, int32_t default_index, void* out,
                              int32_t out_elem_bytes) {
   if (!ctx || !rankmap || !pal_off || !lut || !out || H <= 0 || W <= 0) return rhccq_fail(ctx, RHCCQ_E_ARG, "frame_remap_ranked: bad argument");
-  return frame_remap_impl(ctx, (const uint8_t*)rankmap, H, W, n_class, labels_host, job_base_host, nullptr, nullptr, pal_off, nullptr, lut, lut2,
+  return frame_remap_impl(ctx, (const uint8_t*)nullptr, H, W, n_class, labels_host, job_base_host, nullptr, nullptr, pal_off, nullptr, lut, lut2,
                           default_index, out, out_elem_bytes, rankmap);
 }
 

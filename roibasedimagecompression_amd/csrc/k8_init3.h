@@ -28,11 +28,18 @@ constexpr int kG3Waves = kG3Threads / 64;
 constexpr int kG3MaxLeaves = 6144;                      // leaf table in LDS: 96 KB = 98 304 init samples
 constexpr int kG3MaxSamples = kG3MaxLeaves * 16;
 constexpr int kG3MaxSup = kG3MaxLeaves / 16;            // 384
+constexpr int kG3MaxHyp = kG3MaxSup / 16;               // 24 hypers of 16 supers = 4 096 samples
 constexpr int kG3MaxDsum = kG3MaxSamples / 64;          // 64-draw sums: 1 536
 constexpr int kG3MaxTop = kG3MaxDsum / 64;              // 4 096-draw sums: 24
 constexpr int kG3MaxItems = 4096;                       // (candidate, leaf) items per pick
 constexpr int kG3WList = kG3MaxSup;                     // hit supers one candidate keeps: room for all of them (u16 entries, 12 KB for 16 candidates)
 constexpr int kG3Touch = 512;
+// Super stage of the one-candidate-per-wave chain through a hyper level (24 boxes of 16 supers, tested in one round, then only the supers
+// of the hit hypers): same picks (tests/test_gpu_kernels.py with this switched on), ~2 rounds of box tests instead of 6 -- and SLOWER where it
+// matters: 4.50 vs 4.24 us per pick at k = 30 128, 4.2 vs 4.2 at k = 20 556, 3.10 vs 3.31 at k = 2 314 (round 4, MI355X, inside a frame).  The
+// extra dependent LDS round trips (hyper table -> scalar bit walk -> super table) cost more than the ~80 box-test instructions they save:
+// each search wave is a chain of dependent latencies, not an issue-bound stream.  Kept as a checked alternative, off.
+constexpr bool kG3UseHypers = false;
 constexpr int kG3Keep = 3;                              // evaluation instruction streams (16 items each) a wave keeps in registers
 
 struct G3Shared {
@@ -114,6 +121,7 @@ __global__ __launch_bounds__(kG3Threads) void mbk_init3_kernel(const uint32_t* _
   __shared__ G3Shared sh;
   __shared__ uint4 blk[kG3MaxLeaves];                    // per leaf: box (3 pairs), max closest
   __shared__ uint4 sup[kG3MaxSup];                       // per super: box, max of the leaves' max (may lag high)
+  __shared__ uint4 hyp[kG3MaxHyp];                       // per hyper (16 supers): box, max (may lag high) -- round 4: see the super stage
   __shared__ uint32_t dsum[kG3MaxDsum];                  // per 64 consecutive draws: sum of closest
   __shared__ uint32_t dtop[kG3MaxTop];                   // per 4 096 consecutive draws
   __shared__ uint32_t items[kG3MaxItems];
@@ -125,7 +133,7 @@ __global__ __launch_bounds__(kG3Threads) void mbk_init3_kernel(const uint32_t* _
   const int n = (int)P.init_n, k = (int)P.k, T = P.T;
   const int NW = (T + kCW - 1) / kCW;                             // search waves
   const int nd = (n + 63) >> 6, np = nd << 6;                     // 64-draw blocks; padded sample count
-  const int nb = np >> 4, nsb = (nb + 15) >> 4, ntop = (nd + 63) >> 6;
+  const int nb = np >> 4, nsb = (nb + 15) >> 4, ntop = (nd + 63) >> 6, nhyp = (nsb + 15) >> 4;
   uint2* samp = kLdsS ? reinterpret_cast<uint2*>(&blk[nb]) : reinterpret_cast<uint2*>(scratch + scratch_off[blockIdx.x]);
   uint2* dsamp = samp + np;
   int32_t* cho = chosen + P.koff;
@@ -178,6 +186,17 @@ __global__ __launch_bounds__(kG3Threads) void mbk_init3_kernel(const uint32_t* _
     psum += sum;
   }
   psum = block_sum<unsigned long long>(psum, sh.red64);
+  for (int h = tid; h < nhyp; h += kG3Threads) {          // (sup is visible: the sum above went through two barriers)
+    int r0 = 255, g0 = 255, b0 = 255, r1 = 0, g1 = 0, b1 = 0;
+    unsigned m = 0;
+    for (int sb = h * 16; sb < min(h * 16 + 16, nsb); ++sb) {
+      const uint4 se = sup[sb];
+      r0 = min(r0, pair_lo(se.x)); g0 = min(g0, pair_lo(se.y)); b0 = min(b0, pair_lo(se.z));
+      r1 = max(r1, pair_hi(se.x)); g1 = max(g1, pair_hi(se.y)); b1 = max(b1, pair_hi(se.z));
+      m = max(m, se.w);
+    }
+    hyp[h] = make_uint4(box_pair((unsigned)r0, (unsigned)r1), box_pair((unsigned)g0, (unsigned)g1), box_pair((unsigned)b0, (unsigned)b1), m);
+  }
   if (tid == 0) { cho[0] = P.first; sh.n_touch2[0] = 0; sh.n_touch2[1] = 0; sh.pot = psum; sh.n_items = 0; sh.overflow = 0; }
   if (tid < kTMaxI) sh.delta[tid] = 0;
   if (tid < T && k > 1) sh.R[tid] = (unsigned long long)ceil(rand[P.rand_off + tid] * (double)psum);
@@ -285,7 +304,31 @@ __global__ __launch_bounds__(kG3Threads) void mbk_init3_kernel(const uint32_t* _
       int n_sup[kCW];
 #pragma unroll
       for (int c2 = 0; c2 < kCW; ++c2) n_sup[c2] = 0;
-      {
+      if constexpr (kCW == 1 && kG3UseHypers) {
+        // round 4: the <= 24 hypers (16 supers each) in ONE round, then only the supers of the hypers that may improve, four hypers per
+        // round (a row of 16 lanes each).  A candidate meets 2-4 hypers of the 22 of a 90 000-sample problem: ~2 rounds of box tests
+        // instead of 6 (the chain is bound by the instructions its 12 search waves issue on 4 SIMDs), for one more dependent LDS
+        // round trip.  Hit supers land in the list in ascending order, as before.
+        const uint4 he = hyp[min(lane, nhyp - 1)];
+        const bool hh = (bool)((int)(box_dist2(cp[0], he.x, he.y, he.z) < he.w) & (int)(lane < nhyp) & (int)on[0]);
+        unsigned long long mh = __ballot(hh);
+        while (mh) {
+          int h4[4];
+#pragma unroll
+          for (int i = 0; i < 4; ++i) {
+            h4[i] = mh ? __ffsll((long long)mh) - 1 : -1;
+            mh &= mh - 1ull;                               // (0 stays 0)
+          }
+          const int my_h = sel4(rq, h4);
+          const int sbi = my_h * 16 + rj;
+          const bool valid = (bool)((int)(my_h >= 0) & (int)(sbi < nsb));
+          const uint4 se = sup[valid ? sbi : 0];
+          const bool h = (bool)((int)valid & (int)(box_dist2(cp[0], se.x, se.y, se.z) < se.w));
+          const unsigned long long m = __ballot(h);
+          if (h) wlist[tc[0] * kG3WList + n_sup[0] + g3_rank_in(m)] = (uint16_t)sbi;
+          n_sup[0] += __popcll(m);
+        }
+      } else {
         uint4 se[kG3MaxSup / 64];
         const int nr = nsb > 128 ? kG3MaxSup / 64 : 2;      // (wave-uniform; the unrolled rounds beyond it cost a scalar branch)
 #pragma unroll
@@ -408,6 +451,19 @@ __global__ __launch_bounds__(kG3Threads) void mbk_init3_kernel(const uint32_t* _
         unsigned m = b < nb ? blk[b].w : 0u;
         m = dpp_row_max(m);
         if ((i & 15) == 0) sup[sb].w = m;
+      }
+      // ... and the maxima of their hypers, straight from the leaves (256 per hyper, four per lane): independent of the super writes
+      // above, and like them allowed to lag high
+      for (int e = wave - NW; e < n_touched; e += kG3Waves - NW) {
+        const int h = touch_r[e] >> 4;
+        unsigned m = 0;
+#pragma unroll
+        for (int j = 0; j < 4; ++j) {
+          const int b = h * 256 + j * 64 + lane;
+          m = max(m, b < nb ? blk[b].w : 0u);
+        }
+        m = wave_max_u32(m);
+        if (lane == 0) hyp[h].w = m;
       }
     }
     WEND(0);
@@ -564,6 +620,12 @@ __global__ __launch_bounds__(kG3Threads) void mbk_init3_kernel(const uint32_t* _
         sup[sb].w = m;
       }
       if (tid == 0) sh.n_touch2[c & 1] = 0;
+      __syncthreads();
+      for (int h = tid; h < nhyp; h += kG3Threads) {
+        unsigned m = 0;
+        for (int sb = h * 16; sb < min(h * 16 + 16, nsb); ++sb) m = max(m, sup[sb].w);
+        hyp[h].w = m;
+      }
       __syncthreads();
     }
   }
