@@ -297,6 +297,9 @@ __global__ __launch_bounds__(kG3Threads) void mbk_init3_kernel(const uint32_t* _
           sh.ck[tc[c2]] = make_uint2(ck[c2], norm2_key(ck[c2]));
         }
       }
+      // (round 4, measured and dropped: requesting the super entries at the START of the pick, so that they arrive in the shadow of the search's
+      // three dependent round trips -- same picks, 4.75 vs 4.62 us per pick on one box, tools/chain_ab.py: read that early the maxima of the supers
+      // the previous winner touched have not been refreshed by the idle waves yet, and a stale larger maximum means more leaves to test.)
       // every super, 64 per round, against the wave's candidates; the rounds are independent of each other (one LDS round trip for
       // all: loads unconditional, indices clamped, all of them issued before the first test -- sched_barrier: left alone the
       // compiler waits for each entry before it asks for the next).  The maxima may be mid-refresh by the idle waves: a stale,

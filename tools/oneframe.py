@@ -9,5 +9,5 @@ rh = Rhccq(0)
 enc = FrameEncoder(rh)
 _, rgb, specs, roi, _ = bench.build_inputs(rh, 2160, 3840, 1234, (2, 1), 20, 20, 2.0)
 for _ in range(3):
-    enc.encode(rgb, specs)
+    enc.encode_native(rgb, specs)          # the host bench.py times (rhccq_encode_frame)
 torch.cuda.synchronize()
