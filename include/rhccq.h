@@ -483,6 +483,14 @@ int rhccq_label_reduce(rhccq_ctx* ctx, const int32_t* labels, const uint16_t* va
  * out4 (device u64[4]) = {components whose max exceeds high, their pixels, their sum of val8, their sum of val8^2}; lut (device u8[n + 1], may
  * be NULL) = 255 for those components (for rhccq_ccl_select) */
 int rhccq_edge_score(rhccq_ctx* ctx, const uint64_t* red, int32_t n_labels, int32_t high, uint64_t* out4, uint8_t* lut);
+/* The scores of SEVERAL threshold pairs with nothing crossing to the host in between (find_best_edges_by_quality tries 20 pairs,
+ * encoder/ROI/edges.py:40-71): per distinct `low` one mask + one labelling of {nm > low} (component count kept on the device) + one per-label
+ * reduction capped at `cap` labels; per pair one verdict.  lows / highs: HOST int32[n_pairs], pairs with equal `low` adjacent.  out: DEVICE
+ * uint64[n_pairs][5] = {edge components, edge pixels, sum gray, sum gray^2, components of {nm > low}}; a pair whose last number exceeds `cap`
+ * must be scored through rhccq_label_reduce / rhccq_edge_score instead.  work: rhccq_canny_scores_bytes(H, W, cap) bytes. */
+int64_t rhccq_canny_scores_bytes(int32_t H, int32_t W, int32_t cap);
+int rhccq_canny_scores(rhccq_ctx* ctx, const uint16_t* nm, const uint8_t* gray, int32_t H, int32_t W, const int32_t* lows_host,
+                       const int32_t* highs_host, int32_t n_pairs, int32_t cap, void* work, int64_t work_bytes, uint64_t* out);
 int rhccq_box_count(rhccq_ctx* ctx, const uint8_t* mask, int32_t H, int32_t W, int32_t kernel_size, uint16_t* out);
 /* the same window, summing the pixel VALUES (maps that are not 0 / one value: the notebook's 0 / 1 / 255 planes) */
 int rhccq_box_sum(rhccq_ctx* ctx, const uint8_t* plane, int32_t H, int32_t W, int32_t kernel_size, uint32_t* out);

@@ -157,6 +157,60 @@ __global__ __launch_bounds__(256) void label_reduce_kernel(const int32_t* __rest
   }
 }
 
+// the same with a capacity: labels beyond `cap` are left out (the caller sees n > cap in the scores record and takes the two-step path)
+__global__ __launch_bounds__(256) void label_reduce_capped_kernel(const int32_t* __restrict__ labels, const uint16_t* __restrict__ val16,
+                                                                  const uint8_t* __restrict__ val8, long long n, int cap, unsigned long long* red) {
+  const long long p = (long long)blockIdx.x * 256 + threadIdx.x;
+  const int lane = threadIdx.x & 63;
+  int l = p < n ? labels[p] : 0;
+  if (l > cap) l = 0;
+  const unsigned long long fg = __ballot(l != 0);
+  if (!fg) return;
+  unsigned long long v16 = l ? val16[p] : 0ull, v8 = l && val8 ? val8[p] : 0ull;
+  const int first = __builtin_ctzll(fg);
+  const int lead = __shfl(l, first);
+  if (__ballot(l != 0 && l != lead) == 0) {
+    unsigned long long mx = v16, s1 = v8, s2 = v8 * v8;
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) {
+      mx = max(mx, (unsigned long long)__shfl_down(mx, o, 64));
+      s1 += __shfl_down(s1, o, 64);
+      s2 += __shfl_down(s2, o, 64);
+    }
+    if (lane == 0) {
+      atomicMax(&red[4ll * lead], mx);
+      if (s1) { atomicAdd(&red[4ll * lead + 1], s1); atomicAdd(&red[4ll * lead + 2], s2); }
+      atomicAdd(&red[4ll * lead + 3], (unsigned long long)__popcll(fg));
+    }
+  } else if (l) {
+    atomicMax(&red[4ll * l], v16);
+    if (v8) { atomicAdd(&red[4ll * l + 1], v8); atomicAdd(&red[4ll * l + 2], v8 * v8); }
+    atomicAdd(&red[4ll * l + 3], 1ull);
+  }
+}
+
+// edge_score_kernel with the component count read on the device: out[0..3] as there, out[4] = the component count itself
+__global__ __launch_bounds__(256) void edge_score_dev_kernel(const unsigned long long* __restrict__ red, const int32_t* __restrict__ n_dev, int cap, int high,
+                                                             unsigned long long* out) {
+  __shared__ unsigned long long s_acc[4];
+  const int n_all = *n_dev, n = min(n_all, cap);
+  if (blockIdx.x * 256 > n) return;
+  if (threadIdx.x < 4) s_acc[threadIdx.x] = 0;
+  __syncthreads();
+  const int l = blockIdx.x * 256 + threadIdx.x;
+  unsigned long long v[4] = {0, 0, 0, 0};
+  if (l <= n && l > 0 && red[4ll * l] > (unsigned long long)high) { v[0] = 1; v[1] = red[4ll * l + 3]; v[2] = red[4ll * l + 1]; v[3] = red[4ll * l + 2]; }
+#pragma unroll
+  for (int k = 0; k < 4; ++k) {
+    unsigned long long t = v[k];
+    for (int o = 32; o > 0; o >>= 1) t += __shfl_down(t, o, 64);
+    if ((threadIdx.x & 63) == 0 && t) atomicAdd(&s_acc[k], t);
+  }
+  __syncthreads();
+  if (threadIdx.x < 4 && s_acc[threadIdx.x]) atomicAdd(&out[threadIdx.x], s_acc[threadIdx.x]);
+  if (blockIdx.x == 0 && threadIdx.x == 0) out[4] = (unsigned long long)n_all;
+}
+
 // hysteresis verdict per component and the four numbers the quality score needs, without a trip to the host: a component is an edge
 // when its largest magnitude exceeds `high`; out = {edge components, edge pixels, sum of gray, sum of gray^2 over the edge pixels};
 // lut (optional): 255 for edge components, 0 otherwise (label 0 = background: 0)
@@ -277,6 +331,48 @@ int rhccq_edge_score(rhccq_ctx* ctx, const uint64_t* red, int32_t n_labels, int3
   RHCCQ_HIP(ctx, hipMemsetAsync(out4, 0, 4 * sizeof(uint64_t), ctx->stream));
   hipLaunchKernelGGL(edge_score_kernel, dim3((unsigned)((n_labels + 1 + 255) / 256)), dim3(256), 0, ctx->stream, (const unsigned long long*)red, n_labels, high,
                      (unsigned long long*)out4, lut);
+  RHCCQ_LAUNCH_CHECK(ctx);
+  return 0;
+}
+
+// The scores of SEVERAL Canny threshold pairs without a trip to the host in between (get_edge_map tries 20 pairs, encoder/ROI/edges.py:40-71): per
+// distinct `low` one mask, one labelling of {nm > low} (unordered ids, the count stays on the device), one capped per-label reduction; per pair
+// one verdict kernel.  out (device uint64[n_pairs][5]): edge components, edge pixels, sum gray, sum gray^2, and the number of components of
+// {nm > low} -- when that exceeds `cap` the pair's four numbers are incomplete and the caller scores it through rhccq_label_reduce /
+// rhccq_edge_score.  Pairs must be grouped by `low` (equal lows adjacent).  work: rhccq_canny_scores_bytes(H, W, cap) bytes.
+int64_t rhccq_canny_scores_bytes(int32_t H, int32_t W, int32_t cap) {
+  if (H <= 0 || W <= 0 || cap < 0) return 0;
+  const size_t n = (size_t)H * W;
+  auto al = [](size_t v) { return (v + 255) & ~(size_t)255; };
+  return (int64_t)(al(n) + al(4 * n) + al(32 * ((size_t)cap + 1)) + 256 + al((size_t)rhccq_ccl_work_bytes(H, W, 0)));
+}
+
+int rhccq_canny_scores(rhccq_ctx* ctx, const uint16_t* nm, const uint8_t* gray, int32_t H, int32_t W, const int32_t* lows_host, const int32_t* highs_host,
+                       int32_t n_pairs, int32_t cap, void* work, int64_t work_bytes, uint64_t* out) {
+  if (!ctx || !nm || !lows_host || !highs_host || !work || !out || H <= 0 || W <= 0 || n_pairs <= 0 || cap < 1)
+    return rhccq_fail(ctx, RHCCQ_E_ARG, "canny_scores: bad argument");
+  if (work_bytes < rhccq_canny_scores_bytes(H, W, cap)) return rhccq_fail(ctx, RHCCQ_E_ARG, "canny_scores: work buffer too small");
+  const size_t n = (size_t)H * W;
+  auto al = [](size_t v) { return (v + 255) & ~(size_t)255; };
+  char* base = (char*)work;
+  uint8_t* mask = (uint8_t*)base; base += al(n);
+  int32_t* labels = (int32_t*)base; base += al(4 * n);
+  unsigned long long* red = (unsigned long long*)base; base += al(32 * ((size_t)cap + 1));
+  int32_t* count = (int32_t*)base; base += 256;
+  void* cwork = (void*)base;
+  const int64_t cbytes = rhccq_ccl_work_bytes(H, W, 0);
+  RHCCQ_HIP(ctx, hipMemsetAsync(out, 0, (size_t)n_pairs * 5 * sizeof(uint64_t), ctx->stream));
+  for (int i = 0; i < n_pairs; ++i) {
+    if (lows_host[i] < 0 || highs_host[i] < 0) return rhccq_fail(ctx, RHCCQ_E_ARG, "canny_scores: negative threshold");
+    if (i == 0 || lows_host[i] != lows_host[i - 1]) {
+      if (int e = rhccq_edges_above(ctx, nm, (int64_t)n, lows_host[i], mask)) return e;
+      if (int e = rhccq_ccl(ctx, mask, H, W, 8, 2, cwork, cbytes, 0, labels, nullptr, count)) return e;
+      RHCCQ_HIP(ctx, hipMemsetAsync(red, 0, 32 * ((size_t)cap + 1), ctx->stream));
+      hipLaunchKernelGGL(label_reduce_capped_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, ctx->stream, labels, nm, gray, (long long)n, (int)cap, red);
+    }
+    hipLaunchKernelGGL(edge_score_dev_kernel, dim3((unsigned)(((size_t)cap + 1 + 255) / 256)), dim3(256), 0, ctx->stream, (const unsigned long long*)red,
+                       (const int32_t*)count, (int)cap, (int)highs_host[i], (unsigned long long*)out + 5 * (size_t)i);
+  }
   RHCCQ_LAUNCH_CHECK(ctx);
   return 0;
 }

@@ -1044,6 +1044,30 @@ class Rhccq:
         self._check(self.lib.rhccq_edge_score(self.ctx, self._p(red), n, int(high), self._p(out4), self._p(lut)), "edge_score")
         return lut, tuple(int(v) for v in out4.cpu().numpy())
 
+    CANNY_SCORES_CAP = 1 << 20      # labels the fused scoring reduces per labelling (32 MB of per-label sums); beyond: the two-step path
+
+    def canny_scores(self, nm, gray, pairs):
+        """[(edge components, edge pixels, sum gray, sum gray^2)] of several (low, high) pairs (normalised, low <= high) in ONE call and ONE
+        read-back (rhccq_canny_scores): pairs that share `low` share the labelling of {nm > low}"""
+        H, W = int(nm.shape[0]), int(nm.shape[1])
+        order = sorted(range(len(pairs)), key=lambda i: pairs[i])
+        lows = (C.c_int32 * len(pairs))(*[int(pairs[i][0]) for i in order])
+        highs = (C.c_int32 * len(pairs))(*[int(pairs[i][1]) for i in order])
+        cap = self.CANNY_SCORES_CAP
+        wb = int(self.lib.rhccq_canny_scores_bytes(H, W, cap))
+        work = self.empty((wb,), torch.uint8)
+        out = self.empty((len(pairs), 5), torch.int64)
+        self._check(self.lib.rhccq_canny_scores(self.ctx, self._p(nm), self._p(gray), H, W, lows, highs, len(pairs), cap, self._p(work), wb, self._p(out)),
+                    "canny_scores")
+        res = out.cpu().numpy()
+        fours = [None] * len(pairs)
+        for j, i in enumerate(order):
+            if int(res[j, 4]) > cap:                              # more components than the fused reduction holds: score this pair the long way
+                fours[i] = self.canny_components(nm, int(pairs[i][0]), int(pairs[i][1]), gray)[2]
+            else:
+                fours[i] = tuple(int(v) for v in res[j, :4])
+        return fours
+
     def canny_components(self, nm, low, high, gray=None, want_lut=False):
         """both halves -> (labels, lut or None, the four numbers)"""
         n, labels, red = self.canny_label(nm, low, gray)
