@@ -50,8 +50,10 @@ const char* rhccq_last_error(const rhccq_ctx* ctx);
  *                              samples, box pruning) up to 98 304 init samples, second generation (blocks of 64) up to 262 144,
  *                              first generation beyond; 1: the first-generation chain always; 2: the second generation whenever
  *                              its tables fit; 3: same as 0; 4: brute force with the samples in registers (kpp_flat.h, at most
- *                              8 192 init samples; the chain KMeans uses).  Same picks everywhere; the other chains serve other
- *                              sizes and as cross-checks;
+ *                              8 192 init samples; the chain KMeans uses); 5: the third generation with every candidate's improvement
+ *                              summed by the wave that found it (no shared work list, two barriers per pick instead of three: measured
+ *                              5 % SLOWER).  Same picks everywhere; the other chains serve other sizes and as
+ *                              cross-checks;
  *   RHCCQ_OPT_INIT_CANDS_PER_WAVE  third-generation chain: how many of a pick's candidates ONE search wave finds and descends for,
  *                              as interleaved dependency chains of one instruction stream (1, 2 or 3; same picks);
  *   RHCCQ_OPT_REASSIGN_LDS     mini-batch steps that reassign low-count centres: 1 (default) = the five sweeps over the weights read

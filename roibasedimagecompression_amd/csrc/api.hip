@@ -53,7 +53,7 @@ int rhccq_ctx_set_int(rhccq_ctx* ctx, int32_t option, int64_t value) {
       ctx->opt_init_max_items = (int)value;
       return 0;
     case RHCCQ_OPT_INIT_KERNEL:
-      if (value < 0 || value > 4) return rhccq_fail(ctx, RHCCQ_E_ARG, "RHCCQ_OPT_INIT_KERNEL: 0 .. 4");
+      if (value < 0 || value > 5) return rhccq_fail(ctx, RHCCQ_E_ARG, "RHCCQ_OPT_INIT_KERNEL: 0 .. 5");
       ctx->opt_init_kernel = (int)value;
       return 0;
     case RHCCQ_OPT_INIT_CANDS_PER_WAVE:

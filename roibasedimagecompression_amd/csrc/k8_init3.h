@@ -50,6 +50,7 @@ struct G3Shared {
   int cand[kTMaxI];
   uint2 ck[kTMaxI];                                     // candidate colour, its squared norm
   int n_items, overflow, n_touch2[2];
+  int n_it[kTMaxI];                                     // in-wave variant: items of every candidate's own list
 };
 
 // number of set bits of a ballot below this lane: v_mbcnt_lo / _hi (2 instructions; popcount of the masked halves takes 4)
@@ -112,7 +113,13 @@ __device__ __forceinline__ void g3_commit_quad(bool on, int b, uint32_t ck, int 
 // then makes no L2 round trip at all: 3.5 us alone on the chip either way, but INSIDE a frame, beside another problem's step
 // kernels, the global-memory version of a level-2 chain ran at 6.9 us per pick (its two dependent L2 reads waited behind their traffic).
 constexpr int kG3LdsSamples = 5760;   // 17 / 16 x padded samples <= kG3MaxLeaves table entries
-template <int kCW, bool kLdsS = false>          // candidates per search wave: 1 (one wave each), 2 or 3
+// kIW (round 4, kCW == 1 only): EVALUATION INSIDE THE CANDIDATE'S OWN WAVE.  The wave that found candidate t and its leaves keeps them in a list of
+// its own (no shared list, no atomic on a shared counter), loads their samples and sums its candidate's improvement itself -- no barrier between
+// search and evaluation, no atomics on the improvement sums: two barriers per pick instead of three.  The winner's wave commits from its registers.
+// Same picks (tests) and SLOWER: 4.82 vs 4.60 us per pick at k = 30 128 on one box (tools/chain_ab.py opt:3 opt:5): the pick now waits for the
+// candidate with the most leaves to search AND evaluate them alone, where the shared list spreads every candidate's leaves over all 16 waves; the
+// barrier it saves is cheaper than that imbalance.  Opt-in (RHCCQ_OPT_INIT_KERNEL = 5), kept as a checked alternative.
+template <int kCW, bool kLdsS = false, bool kIW = false>          // candidates per search wave: 1 (one wave each), 2 or 3
 __global__ __launch_bounds__(kG3Threads) void mbk_init3_kernel(const uint32_t* __restrict__ keys, const MbkP* __restrict__ probs,
                                                                const int32_t* __restrict__ init_idx, const int32_t* __restrict__ perm,
                                                                const double* __restrict__ rand, double* __restrict__ centres,
@@ -139,6 +146,8 @@ __global__ __launch_bounds__(kG3Threads) void mbk_init3_kernel(const uint32_t* _
   int32_t* cho = chosen + P.koff;
   const int rq = lane >> 4, rj = lane & 15;
   const int quad = lane >> 2, qj = lane & 3;
+  static_assert(!kIW || kCW == 1, "in-wave evaluation: one candidate per search wave");
+  const int cap_c = kIW ? min(kG3MaxItems / kTMaxI, max_items / kTMaxI) : 0;      // in-wave variant: room of one candidate's own list
   // ---- gather the sample (both orders), first centre, tables ---------------------------------------------
   const uint32_t kf = keys[P.off + init_idx[P.init_off + P.first]];
   {
@@ -215,9 +224,13 @@ __global__ __launch_bounds__(kG3Threads) void mbk_init3_kernel(const uint32_t* _
     double u_next = 0.0;
     if (tid < T && c + 1 < k) u_next = rand[P.rand_off + (size_t)c * T + tid];
     const unsigned long long pot = sh.pot;
-    if (tid < T) sh.delta[tid] = 0;                      // (read for the arg-max before the previous pick's closing barrier)
+    if (!kIW && tid < T) sh.delta[tid] = 0;              // (read for the arg-max before the previous pick's closing barrier; the in-wave variant
+                                                         //  stores every candidate's sum instead of adding to it)
     const int* touch_r = s_touch + (((c - 1) & 1) ? kG3Touch : 0);
     const int n_touched = min(sh.n_touch2[(c - 1) & 1], kG3Touch);
+    uint4 ka[kG3Keep], kb[kG3Keep];
+    uint32_t kw[kG3Keep];
+    int n_it = 0;                                        // (in-wave variant: items in this wave's own list)
     // ================= phase 1: waves t < T -- candidate t, the supers and the leaves it may improve ================
     if (wave < NW) {
       // Search wave w finds candidates w, w + NW, ... (kCW of them, the last wave possibly fewer): kCW independent dependency chains
@@ -391,6 +404,19 @@ __global__ __launch_bounds__(kG3Threads) void mbk_init3_kernel(const uint32_t* _
           }
         if (total) {
           int base = 0;
+          if constexpr (kIW) {
+            // the wave's own list: no shared counter
+            if (n_it + total > cap_c) { if (lane == 0) sh.overflow = 1; n_it = cap_c + 1; }
+            else {
+              base = tc[0] * cap_c + n_it;
+#pragma unroll
+              for (int q = 0; q < 4; ++q) {
+                if (hb[0][q]) items[base + g3_rank_in(mb[0][q])] = ((uint32_t)tc[0] << 24) | (uint32_t)bq[0][q];
+                base += __popcll(mb[0][q]);
+              }
+              n_it += total;
+            }
+          } else {
           if (lane == 0) base = atomicAdd(&sh.n_items, total);
           base = __builtin_amdgcn_readfirstlane(base);
           if (base + total > max_items) { if (lane == 0) sh.overflow = 1; }
@@ -402,6 +428,7 @@ __global__ __launch_bounds__(kG3Threads) void mbk_init3_kernel(const uint32_t* _
                 if (hb[c2][q]) items[base + g3_rank_in(mb[c2][q])] = ((uint32_t)tc[c2] << 24) | (uint32_t)bq[c2][q];
                 base += __popcll(mb[c2][q]);
               }
+          }
           }
         }
       }
@@ -434,6 +461,18 @@ __global__ __launch_bounds__(kG3Threads) void mbk_init3_kernel(const uint32_t* _
           }
           if (total) {
             int base = 0;
+            if constexpr (kIW) {
+              if (n_it + total > cap_c) { if (lane == 0) sh.overflow = 1; n_it = cap_c + 1; }
+              else {
+                base = tc[c2] * cap_c + n_it;
+#pragma unroll
+                for (int q = 0; q < 4; ++q) {
+                  if (hb[q]) items[base + g3_rank_in(mb[q])] = ((uint32_t)tc[c2] << 24) | (uint32_t)bq[q];
+                  base += __popcll(mb[q]);
+                }
+                n_it += total;
+              }
+            } else {
             if (lane == 0) base = atomicAdd(&sh.n_items, total);
             base = __builtin_amdgcn_readfirstlane(base);
             if (base + total > max_items) { if (lane == 0) sh.overflow = 1; }
@@ -444,8 +483,47 @@ __global__ __launch_bounds__(kG3Threads) void mbk_init3_kernel(const uint32_t* _
                 base += __popcll(mb[q]);
               }
             }
+            }
           }
         }
+      }
+      if constexpr (kIW) {
+        // ================= the candidate's improvement, summed by its own wave: 16 leaves per instruction stream (a quad of lanes holds a leaf),
+        // the first kG3Keep streams stay in registers for the commit.  The list was written by this wave: LDS keeps a wave's accesses in order.
+        const bool ok = n_it <= cap_c;
+        unsigned long long acc = 0;
+        if (ok && on[0]) {
+          const uint32_t* mine = items + tc[0] * cap_c;
+#pragma unroll
+          for (int s2 = 0; s2 < kG3Keep; ++s2) {
+            kw[s2] = 0xffffffffu;
+            ka[s2] = make_uint4(0, 0, 0, 0);
+            kb[s2] = ka[s2];
+            if (16 * s2 < n_it) {
+              const int ii = 16 * s2 + quad;
+              const uint32_t w = mine[min(ii, n_it - 1)];
+              const uint4* p4 = reinterpret_cast<const uint4*>(samp + ((w & 0xffffffu) << 4) + 4 * qj);
+              ka[s2] = p4[0];
+              kb[s2] = p4[1];
+              kw[s2] = ii < n_it ? w : (w | 0xf0000000u);  // the high nibble marks a padding quad
+            }
+          }
+          const uint32_t ckx = ck[0];
+          const int na = (int)norm2_key(ckx);
+#pragma unroll
+          for (int s2 = 0; s2 < kG3Keep; ++s2)
+            if (16 * s2 < n_it) acc += (kw[s2] >> 28) ? 0u : j_eval4(ckx, na, ka[s2], kb[s2]);
+          for (int o = kG3Keep; 16 * o < n_it; ++o) {        // more leaves than the registers hold
+            const int ii = 16 * o + quad;
+            if (ii < n_it) {
+              const uint32_t w = mine[ii];
+              const uint4* p4 = reinterpret_cast<const uint4*>(samp + ((w & 0xffffffu) << 4) + 4 * qj);
+              acc += j_eval4(ckx, na, p4[0], p4[1]);
+            }
+          }
+        }
+        acc = wave_sum(acc);
+        if (lane == 0 && on[0]) { sh.delta[tc[0]] = acc; sh.n_it[tc[0]] = ok ? n_it : 0; }
       }
     } else {
       // the other waves refresh the super maxima the previous winner touched
@@ -481,9 +559,16 @@ __global__ __launch_bounds__(kG3Threads) void mbk_init3_kernel(const uint32_t* _
     const bool kept = n_ops <= kG3Waves * kG3Keep;         // every item's samples stay in the registers of its wave
     int* touch_w = s_touch + ((c & 1) ? kG3Touch : 0);
     int* n_touch_w = &sh.n_touch2[c & 1];
-    uint4 ka[kG3Keep], kb[kG3Keep];
-    uint32_t kw[kG3Keep];
-    if (use_list) {
+    if constexpr (kIW) {
+      if (!use_list) {
+        // a candidate's list overflowed (the first picks): the in-wave sums of the others are void -- start over, brute force (below)
+        if (tid < T) sh.delta[tid] = 0;
+        __syncthreads();
+      }
+    }
+    if (kIW && use_list) {
+      // (evaluated in phase 1 by the candidates' own waves)
+    } else if (use_list) {
       // (wave-uniform guards; a quad beyond the list re-reads the last item and contributes nothing)
 #pragma unroll
       for (int s = 0; s < kG3Keep; ++s) {
@@ -552,7 +637,7 @@ __global__ __launch_bounds__(kG3Threads) void mbk_init3_kernel(const uint32_t* _
     _acc[11] += use_list ? (kept ? 0 : 1) : 0;
     _acc[12] += use_list ? 0 : 1;
 #endif
-    __syncthreads();
+    if (!(kIW && use_list)) __syncthreads();              // (in-wave variant: the sums were complete behind the first barrier)
     STAMP(5);
     WBEGIN();
     // ================= phase 4: greedy choice + commit =======================================================
@@ -565,7 +650,30 @@ __global__ __launch_bounds__(kG3Threads) void mbk_init3_kernel(const uint32_t* _
     const int best = __ffsll((long long)__ballot(lane < T && dv == bd)) - 1;
     const uint32_t kbest = (uint32_t)__builtin_amdgcn_readlane((int)(lane < T ? sh.ck[lane].x : 0u), best);
     const int nabest = (int)norm2_key(kbest);
-    if (use_list && kept) {
+    if (kIW && use_list) {
+      // the winner's wave commits the leaves it still holds; leaves beyond those are shared out over all waves (their samples re-read)
+      const int n_best = sh.n_it[best];
+      if (wave == best) {
+#pragma unroll
+        for (int s = 0; s < kG3Keep; ++s)
+          if (16 * s < n_best) {
+            const bool mine = (kw[s] >> 28) == 0u;
+            g3_commit_quad(mine, (int)(kw[s] & 0xffffffu), kbest, nabest, ka[s], kb[s], samp, dsamp, blk, dsum, dtop, touch_w, n_touch_w);
+          }
+      }
+      for (int o = kG3Keep + wave; 16 * o < n_best; o += kG3Waves) {
+        const int ii = 16 * o + quad;
+        const bool mine = ii < n_best;
+        const uint32_t w = items[best * cap_c + min(ii, n_best - 1)];
+        uint4 a = make_uint4(0, 0, 0, 0), bb = a;
+        if (mine) {
+          const uint4* p4 = reinterpret_cast<const uint4*>(samp + ((w & 0xffffffu) << 4) + 4 * qj);
+          a = p4[0];
+          bb = p4[1];
+        }
+        g3_commit_quad(mine, (int)(w & 0xffffffu), kbest, nabest, a, bb, samp, dsamp, blk, dsum, dtop, touch_w, n_touch_w);
+      }
+    } else if (use_list && kept) {
 #pragma unroll
       for (int s = 0; s < kG3Keep; ++s) {
         if (16 * (wave + s * kG3Waves) < n_items) {

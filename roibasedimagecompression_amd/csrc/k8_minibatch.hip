@@ -2881,7 +2881,7 @@ int rhccq_mbk_init(rhccq_ctx* ctx, const uint32_t* keys, const rhccq_mbk_problem
   for (int i = 0; i < n_prob && lean; ++i) lean = (probs[i].init_n + 63) / 64 <= lds_blocks;
   // third generation (leaves of 16 samples, k8_init3.h) whenever every problem's leaf table fits LDS: init samples <= 98 304,
   // the regime of 4K frames; RHCCQ_OPT_INIT_KERNEL = 2 keeps the second generation (A/B runs, parity tests)
-  bool gen3 = lean && (ctx->opt_init_kernel == 0 || ctx->opt_init_kernel == 3) && ctx->opt_init_shards <= 1 && lds_blocks >= kInitLdsBlocks;
+  bool gen3 = lean && (ctx->opt_init_kernel == 0 || ctx->opt_init_kernel == 3 || ctx->opt_init_kernel == 5) && ctx->opt_init_shards <= 1 && lds_blocks >= kInitLdsBlocks;
   for (int i = 0; i < n_prob && gen3; ++i) gen3 = probs[i].init_n <= kG3MaxSamples;
   // brute force with the samples in registers (kpp_flat.h): RHCCQ_OPT_INIT_KERNEL = 4 only.  MEASURED per pick: alone on the
   // chip 3.2 us at 3 000 init samples (every problem with k <= 3 000) against the third generation's 3.5-3.7, 3.8-4.0 at
@@ -2953,8 +2953,13 @@ int rhccq_mbk_init(rhccq_ctx* ctx, const uint32_t* keys, const rhccq_mbk_problem
     if (t16) cw = 1;
     bool lds_s = cw == 1;
     for (int i = 0; i < n_prob && lds_s; ++i) lds_s = probs[i].init_n <= kG3LdsSamples;
-    if (lds_s)
+    const bool in_wave = cw == 1 && ctx->opt_init_kernel == 5;      // RHCCQ_OPT_INIT_KERNEL = 5: evaluation inside the candidate's own wave (measured slower)
+    if (lds_s && in_wave)
+      hipLaunchKernelGGL((mbk_init3_kernel<1, true, true>), dim3(n_prob), dim3(kG3Threads), 0, ctx->stream, keys, dp, init_idx, perm, rand, centres, chosen, dscr, dof, mi);
+    else if (lds_s)
       hipLaunchKernelGGL((mbk_init3_kernel<1, true>), dim3(n_prob), dim3(kG3Threads), 0, ctx->stream, keys, dp, init_idx, perm, rand, centres, chosen, dscr, dof, mi);
+    else if (in_wave)
+      hipLaunchKernelGGL((mbk_init3_kernel<1, false, true>), dim3(n_prob), dim3(kG3Threads), 0, ctx->stream, keys, dp, init_idx, perm, rand, centres, chosen, dscr, dof, mi);
     else if (cw == 3)
       hipLaunchKernelGGL(mbk_init3_kernel<3>, dim3(n_prob), dim3(kG3Threads), 0, ctx->stream, keys, dp, init_idx, perm, rand, centres, chosen, dscr, dof, mi);
     else if (cw == 2)

@@ -332,7 +332,7 @@ def test_dct_quant_extension(rh, O, block):
 
 @pytest.mark.parametrize("path", ["default", "register_chain", "third_generation", "tiny_work_list", "small_work_list", "one_candidate_per_wave", "two_candidates_per_wave", "three_candidates_per_wave",
                                   "three_candidates_per_wave_small_work_list", "second_generation", "second_generation_tiny_work_list",
-                                  "first_generation", "first_generation_tiny_work_list", "global_tables"])
+                                  "first_generation", "first_generation_tiny_work_list", "global_tables", "in_wave", "in_wave_small_work_list"])
 def test_minibatch_init_chain_many_cases(rh, O, path):
     """The k-means++ chains (mbk_init3_kernel: leaves of 16 samples under three box levels, 64-ary candidate search, quad
     evaluation with the samples kept in registers for the commit, brute force when the work list overflows -- the default up
@@ -357,6 +357,8 @@ def test_minibatch_init_chain_many_cases(rh, O, path):
         rh.set_option(rh.OPT_INIT_KERNEL, 2)
     if path == "third_generation":                         # (option 3: the same choice as the default)
         rh.set_option(rh.OPT_INIT_KERNEL, 3)
+    if path.startswith("in_wave"):                         # round 4: every candidate evaluated by the wave that found it (opt-in: measured slower)
+        rh.set_option(rh.OPT_INIT_KERNEL, 5)
     if path == "register_chain":                           # kpp_flat.h (the chain KMeans uses): opt-in for the MiniBatch init
         rh.set_option(rh.OPT_INIT_KERNEL, 4)
     try:

@@ -1,5 +1,6 @@
 """diagnostic: the k-means++ chain of the bench frame's longest problem (k = 30 128) under two builds of the library on ONE box, alternating
-child processes (box-to-box clocks differ by ~10 %, so only a same-box A/B says anything):  python tools/chain_ab.py libA.so libB.so [reps]"""
+child processes (box-to-box clocks differ by ~10 %, so only a same-box A/B says anything):  python tools/chain_ab.py libA.so libB.so [reps]
+(`opt:N` instead of a path: the library in the tree with RHCCQ_OPT_INIT_KERNEL = N)"""
 import os, subprocess, sys
 HERE = os.path.dirname(os.path.abspath(__file__))
 if len(sys.argv) > 1 and sys.argv[1] == "--child":
@@ -7,10 +8,16 @@ if len(sys.argv) > 1 and sys.argv[1] == "--child":
     import math
     import numpy as np
     from roibasedimagecompression_amd import _lib
-    _lib.LIB_PATH = os.path.abspath(sys.argv[2])
+    opt = None
+    if sys.argv[2].startswith("opt:"):                   # the library in the tree with RHCCQ_OPT_INIT_KERNEL set (3 = round 3's shared work list, 0 = default)
+        opt = int(sys.argv[2][4:])
+    else:
+        _lib.LIB_PATH = os.path.abspath(sys.argv[2])
     from roibasedimagecompression_amd.ops import Rhccq
     from roibasedimagecompression_amd import synth
     rh = Rhccq(0)
+    if opt is not None:
+        rh.set_option(rh.OPT_INIT_KERNEL, opt)
     img = synth.photo(2160, 3840, 1234)
     keys = (img[..., 0].astype(np.uint32) << 16) | (img[..., 1].astype(np.uint32) << 8) | img[..., 2]
     pal = np.unique(keys[:, 1920:])
