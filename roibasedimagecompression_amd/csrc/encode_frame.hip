@@ -555,6 +555,7 @@ void cluster_jobs(Lane& L, std::vector<Job>& jobs) {
     }
   }
   // ---- DBSCAN(eps / 255, min_samples = 1) labels of all small palettes in one launch (clustering.py:233-235)
+  const double t_db = now_ms();
   if (!db.empty()) {
     std::vector<int32_t> desc(db.size() * 4);
     std::vector<double> r2(db.size());
@@ -587,6 +588,7 @@ void cluster_jobs(Lane& L, std::vector<Job>& jobs) {
       jb.have_labels = true;
     }
   }
+  if (trace_on() && !db.empty()) fprintf(stderr, "[rhccq] dbscan: %zu palettes, %.2f ms\n", db.size(), now_ms() - t_db);
   // ---- MiniBatchKMeans problems side by side
   run_mbk_tasks(L, mbk);
   for (Job* pj : mbk) {
@@ -713,9 +715,11 @@ void cluster_jobs(Lane& L, std::vector<Job>& jobs) {
     double* work = L.dalloc<double>((size_t)(8 * ktot + 8));
     int32_t* d_lab = L.dalloc<int32_t>(cat.size());
     int32_t* d_info = L.dzeros<int32_t>(run.size() * 4);
+    const double t_km = now_ms();
     EF_RC(c, rhccq_kmeans(c, d_keys, d_desc, d_koff, d_rand, (int32_t)run.size(), max_n, work, d_lab, d_info));
     std::vector<int32_t> lab(cat.size());
     L.download(lab.data(), d_lab, lab.size());
+    if (trace_on()) fprintf(stderr, "[rhccq] kmeans split round: %zu nodes, %zu points, largest %d, %lld clusters, %.2f ms\n", run.size(), cat.size(), max_n, (long long)ktot, now_ms() - t_km);
     for (size_t i = 0; i < run.size(); ++i) {
       const int ndi = run[i].first;
       const int64_t k = run[i].second;

@@ -28,7 +28,7 @@ for it in range(n_prob):
     k = int(rng.integers(8, max(9, min(len(P) // 3, 9000 if it % 2 else 2700))))     # (every other problem small enough for the register chain)
     keys = pack_rgb(P)
     got = {}
-    gens = (0, 2, 1) + ((4,) if (3000 if k <= 3000 else 3 * k) <= 8192 and it % 5 != 4 else ())   # (the register chain has no work list to shrink)
+    gens = (0, 5, 2, 1) + ((4,) if (3000 if k <= 3000 else 3 * k) <= 8192 and it % 5 != 4 else ())   # (the register chain has no work list to shrink)
     for gen in gens:
         rh.set_option(rh.OPT_INIT_KERNEL, gen)
         if it % 5 == 4:
