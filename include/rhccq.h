@@ -328,7 +328,9 @@ int rhccq_mbk_assign(rhccq_ctx* ctx, const uint32_t* keys, const rhccq_mbk_probl
  *   palette_out: HOST uint8[pal_cap][3]; indices_out: DEVICE buffer of H * W * 4 bytes, written as uint8 / uint16 / uint32 [H][W]
  *     (res->index_bytes) on the context's stream, complete when the call returns; n_unique_out (HOST int64[n_jobs], may be NULL):
  *     unique colours per segment.  At most 2048 segments per frame (beyond: the sort-based path of the Python FrameEncoder).
- * Returns 0, RHCCQ_E_ARG, RHCCQ_E_HIP or RHCCQ_E_LIMIT (too many segments, or pal_cap too small: res->n_colours says how many). */
+ * Returns 0, RHCCQ_E_ARG, RHCCQ_E_HIP or RHCCQ_E_LIMIT (too many segments, or pal_cap too small: res->n_colours says how many).
+ * One call at a time per context (the context keeps the lanes' streams and device arenas between frames; use one context per host
+ * thread that encodes); the call returns with every lane idle. */
 typedef struct rhccq_class_desc {
   const int32_t* labels;
   int32_t n_seg;

@@ -17,17 +17,19 @@ Parity pins (see DESIGN.md "Oracle"):
     (oversize-cluster split): restated with the "KM64" arithmetic below; against scikit-learn itself it reproduces the
     same partition on most golden cases (Tier A when it does, Tier B = same palette size / equivalent PSNR otherwise).
     MiniBatchKMeans (every segment of >= 10 000 colours): restated operation for operation -- RandomState(42) consumed as
-    sklearn consumes it, k-means++ in draw order, batch-ordered centre updates, sequential inertia -- and pinned bit for
-    bit against scikit-learn's own fit with its ONE unportable step (an unstable np.argsort over tied counts) forced
-    stable (tests/golden/make_golden_mbk.py, G11); wherever that step does not trigger (k < 500) the untouched fit, i.e.
-    the reference's own result, is reproduced.
+    sklearn consumes it, k-means++ in draw order, batch-ordered centre updates, sequential inertia, and its ONE
+    host-dependent step (an unstable np.argsort over tied counts in _mini_batch_step) as numpy's scalar sort kernel runs
+    it (npy_argsort.c) -- and pinned bit for bit against scikit-learn's UNTOUCHED fit_predict under that stated host
+    setting (tests/golden/make_golden_npysort.py, G11-scalar / G15); the stable tie order of rounds 1-3 stays selectable
+    and pinned to sklearn with that call forced stable (make_golden_mbk.py, G11); wherever the step does not trigger
+    (k < 500) every host gives the same fit and it is reproduced.
 
   * PARITY UNPINNED (say so wherever these are cited): the stages UPSTREAM of the hot path lean on libraries that are absent
     from the build container -- scikit-image (split score, masked SLIC, SSIM: sk_* / slic_* / structural_similarity_win7) and
     OpenCV (the whole ROI stage: cv_* , get_edge_map, the clean-up chain, connected components and their numbering).  They
     are restated from the libraries' published algorithms; what pins them is (a) scipy, wherever the reference itself or
     scikit-image calls it (extract_roi_nonroi's dilations, resize's gaussian_filter / zoom), (b) known answers that need no
-    library (tests/test_roi_cpu.py), and (c) Tier B end to end: the whole script flow lands within 0.15 dB / 3.2 % of four
+    library (tests/test_roi_cpu.py), and (c) Tier B end to end (all 25 + 8 artefact pairs, tests/test_gpu_notebook.py; the r02 figure follows): the whole script flow lands within 0.15 dB / 3.2 % of four
     artefacts the reference ships and within 0.6 dB / 6.3 % of two more (tests/test_gpu_notebook.py).
 
 Canonical k-means arithmetic "KM64" (shared with csrc/):
