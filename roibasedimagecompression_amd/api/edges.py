@@ -67,6 +67,8 @@ class _Gradient:
         self.counts = counts
         self.n = n_pixels
         self._mean = None
+        self._std = None
+        self._pct = {}            # the threshold search asks for the same percentiles / moments at five sensitivities: computed once
 
     def mean(self):
         if self._mean is None:
@@ -74,14 +76,16 @@ class _Gradient:
         return self._mean
 
     def std(self):
-        d = self.mag - self.mean()
-        return math.sqrt(float(np.dot(d * d, self.counts)) / self.n)
+        if self._std is None:
+            d = self.mag - self.mean()
+            self._std = math.sqrt(float(np.dot(d * d, self.counts)) / self.n)
+        return self._std
 
     def percentile_nonzero(self, q):
-        nz = self.mag > 0
-        if not nz.any():
-            return None
-        return _percentile(self.mag[nz], self.counts[nz], q)
+        if q not in self._pct:
+            nz = self.mag > 0
+            self._pct[q] = _percentile(self.mag[nz], self.counts[nz], q) if nz.any() else None
+        return self._pct[q]
 
 
 class EdgeAnalysis:
@@ -103,12 +107,18 @@ class EdgeAnalysis:
         self.H, self.W = image.shape[:2]
         self._grad = None
         self._nm = {}
+        self._otsu_val = None
 
     def gradient(self):
         if self._grad is None:
             m2, c = self.rh.edges_grad_hist(self.gray)
             self._grad = _Gradient(m2, c, self.H * self.W)
         return self._grad
+
+    def otsu(self):
+        if self._otsu_val is None:
+            self._otsu_val = _otsu(self.hist)
+        return self._otsu_val
 
     def nm(self, colour=False):
         if colour not in self._nm:
@@ -118,7 +128,7 @@ class EdgeAnalysis:
     def thresholds(self, method="otsu", sensitivity=1.0):
         """edges.py:88-169"""
         if method == "otsu":
-            o = _otsu(self.hist)
+            o = self.otsu()
             lo, hi = max(10, int(o * 0.5 * sensitivity)), min(255, int(o * 1.5 * sensitivity))
         elif method == "percentile":
             g = self.gradient()
@@ -133,7 +143,7 @@ class EdgeAnalysis:
             mean, std = g.mean(), g.std()
             lo, hi = max(10, int((mean - 0.5 * std) * sensitivity)), min(255, int((mean + 0.5 * std) * sensitivity))
         elif method == "hybrid":
-            o = _otsu(self.hist)
+            o = self.otsu()
             mean = self.gradient().mean()
             lo = max(10, int((o * 0.5 + mean * 0.5) * sensitivity))
             hi = min(255, int((o * 1.5 + mean * 1.0) * sensitivity))
