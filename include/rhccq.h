@@ -263,9 +263,10 @@ int rhccq_mbk_init(rhccq_ctx* ctx, const uint32_t* keys, const rhccq_mbk_problem
 /* np.argsort(w)[:cap] AS A SET under numpy's scalar sort kernel (numpy/_core/src/npysort/quicksort.cpp aquicksort_<double>,
  * heapsort.cpp behind its depth limit) -- the selection inside a capped reassignment of rhccq_mbk_steps, exposed for tests.
  * w: double[k] on the device, non-negative integers < 2^32; 0 < cap < k; depth0 < 0 = numpy's depth limit 2 floor(log2 k)
- * (tests lower it to drive the heapsort branch); scratch: 16 k bytes; mask_out: uint32[(k + 31) / 32], bit j set <=> j is
- * among the first cap entries. */
-int rhccq_npysort_head(rhccq_ctx* ctx, const double* w, int32_t k, int32_t cap, int32_t depth0, void* scratch, uint32_t* mask_out);
+ * (tests lower it to drive the heapsort branch); use_lds != 0: the part that still matters moves to LDS once it has shrunk to 7 680
+ * elements (what rhccq_mbk_steps does), 0: global memory throughout; scratch: 16 k bytes; mask_out: uint32[(k + 31) / 32], bit j set
+ * <=> j is among the first cap entries. */
+int rhccq_npysort_head(rhccq_ctx* ctx, const double* w, int32_t k, int32_t cap, int32_t depth0, int32_t use_lds, void* scratch, uint32_t* mask_out);
 /* run mini-batch steps step0 .. step0 + n_steps - 1 for every problem that has not stopped (call with step0 = 0 first -- that
  * call writes the problem tables at the head of `work`, later calls only queue kernels -- then with the number of steps launched so far; all problems of a call sequence share the step index).  state:
  * double[n_prob][16] = {[0] ewa, [1] ewa_min, [2] no_improvement, [3] samples since the last reassignment, [4] why the

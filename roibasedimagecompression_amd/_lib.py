@@ -75,7 +75,7 @@ PROTOTYPES = {
     "rhccq_mbk_init": (c_int32, [c_void_p, c_void_p, C.POINTER(MbkProblem), c_int32, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p]),
     "rhccq_encode_frame": (c_int32, [c_void_p, c_void_p, c_int32, c_int32, C.POINTER(ClassDesc), c_int32, c_void_p, c_int32, c_void_p, c_void_p,
                                      C.POINTER(FrameResult)]),
-    "rhccq_npysort_head": (c_int32, [c_void_p, c_void_p, c_int32, c_int32, c_int32, c_void_p, c_void_p]),
+    "rhccq_npysort_head": (c_int32, [c_void_p, c_void_p, c_int32, c_int32, c_int32, c_int32, c_void_p, c_void_p]),
     "rhccq_mbk_steps": (c_int32, [c_void_p, c_void_p, C.POINTER(MbkProblem), c_int32, c_int64, c_int32, c_void_p, c_int64, c_void_p,
                                   c_void_p, c_void_p, c_void_p, c_int64, c_int32, c_int32]),
     "rhccq_mbk_steps_overlapped": (c_int32, [c_void_p, c_void_p, C.POINTER(MbkProblem), c_int32, c_int64, c_int32, c_void_p, c_int64, c_void_p,

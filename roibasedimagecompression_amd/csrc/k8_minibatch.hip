@@ -1979,7 +1979,9 @@ __device__ __forceinline__ void reassign_select(UpdShared& sh, const double* __r
   double sel_w = thr;
   int take = 0;
   if (use_mask) {
-    npysort_head(sh, W, k, cap, *qs, -1);
+    // (the sort takes over the LDS the weight copy sits in -- the update's member tables, 16 bytes per element: sweep 2 below then reads the
+    // weights from global memory, one sweep)
+    npysort_head(sh, W, k, cap, *qs, -1, wl, kWLds / 4);
   } else if (capped) {
     if (use_hist) {
       if (tid == 0) {                                 // smallest weight v with #(W <= v) >= cap
@@ -2025,7 +2027,13 @@ __device__ __forceinline__ void reassign_select(UpdShared& sh, const double* __r
   // sweep 2: selected count per wave, min weight of the centres that stay
   int nsel = 0, eq_run = eq_base;
   double wmin = INFINITY;
-  RHCCQ_WSWEEP({
+#define RHCCQ_WSWEEP2(...)                                                                                                    \
+  for (int i = 0; i < n_it; ++i) {                                                                                            \
+    const int j = j0 + lane + 64 * i;                                                                                         \
+    const double w = j < j1 ? ((kLds && !use_mask) ? (double)wl[j] : W[j]) : INFINITY;                                        \
+    __VA_ARGS__                                                                                                               \
+  }
+  RHCCQ_WSWEEP2({
     const bool is_eq = capped && (w < thr) && (w == sel_w);
     const unsigned long long meq = __ballot(is_eq);
     const int rank = eq_run + __popcll(meq & ((1ull << lane) - 1ull));
@@ -2046,6 +2054,7 @@ __device__ __forceinline__ void reassign_select(UpdShared& sh, const double* __r
     rs->tag_sel = (int)(step + 1);
   }
 #undef RHCCQ_WSWEEP
+#undef RHCCQ_WSWEEP2
 }
 
 // Where the draws of a launch go (the batches live in a ring of four buffers, batch b in ring[b & 3]):
@@ -2331,9 +2340,10 @@ __global__ __launch_bounds__(kUpdThreads) void mbk_reassign_apply_kernel(const u
 #include "k8_overlap.h"
 
 __global__ __launch_bounds__(kUpdThreads) void npysort_head_kernel(const double* __restrict__ w, int k, int cap, int depth0, unsigned long long* e,
-                                                                   int* lpos, int* rpos, unsigned* mask) {
+                                                                   int* lpos, int* rpos, unsigned* mask, int use_lds) {
   __shared__ UpdShared sh;
-  npysort_head(sh, w, k, cap, QsScratch{e, lpos, rpos, mask}, depth0);
+  void* lds = use_lds ? reinterpret_cast<void*>(reinterpret_cast<char*>(&sh) + kWLdsOff) : nullptr;      // the region reassign_select lends it
+  npysort_head(sh, w, k, cap, QsScratch{e, lpos, rpos, mask}, depth0, lds, kWLds / 4);
 }
 
 // ------------------------------------------------------------------------------------------------
@@ -2980,11 +2990,11 @@ int rhccq_mbk_init(rhccq_ctx* ctx, const uint32_t* keys, const rhccq_mbk_problem
   return 0;
 }
 
-int rhccq_npysort_head(rhccq_ctx* ctx, const double* w, int32_t k, int32_t cap, int32_t depth0, void* scratch, uint32_t* mask_out) {
+int rhccq_npysort_head(rhccq_ctx* ctx, const double* w, int32_t k, int32_t cap, int32_t depth0, int32_t use_lds, void* scratch, uint32_t* mask_out) {
   if (!ctx || !w || !scratch || !mask_out || k < 2 || cap < 1 || cap >= k) return rhccq_fail(ctx, RHCCQ_E_ARG, "npysort_head: bad argument");
   unsigned long long* e = (unsigned long long*)scratch;
   int* lpos = (int*)(e + k);
-  hipLaunchKernelGGL(npysort_head_kernel, dim3(1), dim3(kUpdThreads), 0, ctx->stream, w, (int)k, (int)cap, (int)depth0, e, lpos, lpos + k, mask_out);
+  hipLaunchKernelGGL(npysort_head_kernel, dim3(1), dim3(kUpdThreads), 0, ctx->stream, w, (int)k, (int)cap, (int)depth0, e, lpos, lpos + k, mask_out, (int)use_lds);
   RHCCQ_LAUNCH_CHECK(ctx);
   return 0;
 }

@@ -23,8 +23,9 @@
 //   * parts of at most 16 elements are insertion-sorted and parts behind the depth limit (2 floor(log2 k), counted as numpy
 //     counts it: only a part that was PUSHED on its stack is checked) heap-sorted by one lane, operation for operation.
 //
-// Everything lives in global memory (L2-resident: 16 B per centre), any k; ~20 levels of a few microseconds each, on
-// ~15 steps of a problem.  Checked against oracle/npy_argsort.c on its own (rhccq_npysort_head, with the depth limit lowered
+// The arrays start in global memory (L2-resident: 16 B per centre, any k); once the part that straddles slot `cap` has shrunk to what the
+// caller's spare LDS holds (the update's member tables: 7 680 elements) it moves there -- every level is a handful of dependent round
+// trips and barriers, ~1 us each through the L2, a tenth of that in LDS: ~114 us per call at k = 30 128 in global memory alone.  Checked against oracle/npy_argsort.c on its own (rhccq_npysort_head, with the depth limit lowered
 // to drive the heapsort branch) and through whole fits against scikit-learn's untouched fit_predict (G11 scalar records).
 
 struct QsScratch {
@@ -76,10 +77,15 @@ __device__ inline void qs_heapsort(unsigned long long* e0, int n) {
 
 // All kUpdThreads threads of the workgroup.  W[0 .. k): the weights; cap < k.  depth0 < 0: numpy's limit 2 floor(log2 k).
 // On return q.mask names the centres np.argsort(W)[:cap] holds (as a set).  Uses sh.weq / sh.wsel / sh.ired.
-__device__ __forceinline__ void npysort_head(UpdShared& sh, const double* __restrict__ W, const int k, const int cap, const QsScratch& q,
-                                             const int depth0) {
+// lds / lds_elems: spare LDS of 16 * lds_elems bytes (nullptr: none).
+__device__ __forceinline__ void npysort_head(UpdShared& sh, const double* __restrict__ W, const int k, const int cap, const QsScratch& q0,
+                                             const int depth0, void* lds = nullptr, const int lds_elems = 0) {
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
   const unsigned long long below = (1ull << lane) - 1ull;
+  QsScratch q = q0;                                      // (the arrays move to LDS on the way down)
+  int off = 0;                                           // position x of the part lives at index x - off of the current arrays (an explicit
+                                                         //  offset: a pointer re-based BELOW the start of an LDS array leaves the LDS aperture)
+  int moved_at = 0x7fffffff;                             // positions >= moved_at live in LDS
   for (int j = tid; j < k; j += kUpdThreads) q.e[j] = ((unsigned long long)(unsigned)W[j] << 32) | (unsigned)j;
   for (int j = tid; j < (k + 31) / 32; j += kUpdThreads) q.mask[j] = 0u;
   __syncthreads();
@@ -87,25 +93,37 @@ __device__ __forceinline__ void npysort_head(UpdShared& sh, const double* __rest
   int cdepth = depth0 >= 0 ? depth0 : 2 * (31 - __clz(k));
   bool pushed = true;                                    // (numpy tests the depth on entry and whenever it pops a part)
   while (pr >= cap && pl < cap) {
+    if (lds != nullptr && moved_at == 0x7fffffff && pr - pl + 1 <= lds_elems) {
+      // the part fits the spare LDS: copy it once; from here on position x lives at index x - off
+      unsigned long long* le = reinterpret_cast<unsigned long long*>(lds);
+      int* ll = reinterpret_cast<int*>(le + lds_elems);
+      for (int x = pl + tid; x <= pr; x += kUpdThreads) le[x - pl] = q.e[x];
+      q.e = le;
+      q.lpos = ll;
+      q.rpos = ll + lds_elems;
+      off = pl;
+      moved_at = pl;
+      __syncthreads();
+    }
     if (pushed && cdepth < 0) {
-      if (tid == 0) qs_heapsort(q.e + pl, pr - pl + 1);
+      if (tid == 0) qs_heapsort(q.e + (pl - off), pr - pl + 1);
       break;
     }
     if (pr - pl <= 15) {
-      if (tid == 0) qs_insertion(q.e, pl, pr);
+      if (tid == 0) qs_insertion(q.e, pl - off, pr - off);
       break;
     }
     // ---- median of three, pivot to pr - 1 (every thread evaluates it, thread 0 stores)
     const int pm = pl + ((pr - pl) >> 1);
-    unsigned long long a = q.e[pl], b = q.e[pm], c = q.e[pr];
-    const unsigned long long d = q.e[pr - 1];
+    unsigned long long a = q.e[(pl) - off], b = q.e[(pm) - off], c = q.e[(pr) - off];
+    const unsigned long long d = q.e[(pr - 1) - off];
     unsigned long long t;
     if (qs_w(b) < qs_w(a)) { t = a; a = b; b = t; }
     if (qs_w(c) < qs_w(b)) { t = c; c = b; b = t; }
     if (qs_w(b) < qs_w(a)) { t = a; a = b; b = t; }
     const unsigned vp = qs_w(b);
     __syncthreads();
-    if (tid == 0) { q.e[pl] = a; q.e[pr] = c; q.e[pm] = d; q.e[pr - 1] = b; }
+    if (tid == 0) { q.e[(pl) - off] = a; q.e[(pr) - off] = c; q.e[(pm) - off] = d; q.e[(pr - 1) - off] = b; }
     __syncthreads();
     // ---- stop lists: wave w owns positions [x0, x1)
     const int m = pr - pl + 1;
@@ -115,7 +133,7 @@ __device__ __forceinline__ void npysort_head(UpdShared& sh, const double* __rest
     for (int xb = x0; xb < x1; xb += 64) {
       const int x = xb + lane;
       const bool valid = x < x1;
-      const unsigned w = valid ? qs_w(q.e[x]) : 0u;
+      const unsigned w = valid ? qs_w(q.e[(x) - off]) : 0u;
       cL += __popcll(__ballot(valid && x > pl && x < pr && w >= vp));
       cR += __popcll(__ballot(valid && x < pr - 1 && w <= vp));
     }
@@ -130,11 +148,11 @@ __device__ __forceinline__ void npysort_head(UpdShared& sh, const double* __rest
     for (int xb = x0; xb < x1; xb += 64) {
       const int x = xb + lane;
       const bool valid = x < x1;
-      const unsigned w = valid ? qs_w(q.e[x]) : 0u;
+      const unsigned w = valid ? qs_w(q.e[(x) - off]) : 0u;
       const bool fl = valid && x > pl && x < pr && w >= vp, fr = valid && x < pr - 1 && w <= vp;
       const unsigned long long bL = __ballot(fl), bR = __ballot(fr);
-      if (fl) q.lpos[pl + runL + __popcll(bL & below)] = x;
-      if (fr) q.rpos[pl + nR - 1 - (runR + __popcll(bR & below))] = x;
+      if (fl) q.lpos[(pl + runL + __popcll(bL & below)) - off] = x;
+      if (fr) q.rpos[(pl + nR - 1 - (runR + __popcll(bR & below))) - off] = x;
       runL += __popcll(bL);
       runR += __popcll(bR);
     }
@@ -143,21 +161,21 @@ __device__ __forceinline__ void npysort_head(UpdShared& sh, const double* __rest
     const int np = min(nL, nR);
     int cnt = 0;
     for (int mm = tid; mm < np; mm += kUpdThreads) {
-      const int l = q.lpos[pl + mm], r = q.rpos[pl + mm];
+      const int l = q.lpos[(pl + mm) - off], r = q.rpos[(pl + mm) - off];
       if (l < r) {
-        const unsigned long long el = q.e[l], er = q.e[r];
-        q.e[l] = er;
-        q.e[r] = el;
+        const unsigned long long el = q.e[(l) - off], er = q.e[(r) - off];
+        q.e[(l) - off] = er;
+        q.e[(r) - off] = el;
         ++cnt;
       }
     }
     const int M = block_sum<int>(cnt, sh.ired);
-    const int pi = M >= 1 ? min(q.lpos[pl + M], q.rpos[pl + M - 1]) : q.lpos[pl];
+    const int pi = M >= 1 ? min(q.lpos[(pl + M) - off], q.rpos[(pl + M - 1) - off]) : q.lpos[(pl) - off];
     __syncthreads();
     if (tid == 0) {
-      const unsigned long long ei = q.e[pi];
-      q.e[pi] = q.e[pr - 1];
-      q.e[pr - 1] = ei;
+      const unsigned long long ei = q.e[(pi) - off];
+      q.e[(pi) - off] = q.e[(pr - 1) - off];
+      q.e[(pr - 1) - off] = ei;
     }
     __syncthreads();
     --cdepth;
@@ -167,7 +185,7 @@ __device__ __forceinline__ void npysort_head(UpdShared& sh, const double* __rest
   }
   __syncthreads();
   for (int mm = tid; mm < cap; mm += kUpdThreads) {
-    const unsigned j = (unsigned)q.e[mm];
+    const unsigned j = (unsigned)(mm >= moved_at ? q.e[(mm) - off] : q0.e[mm]);      // (slots below the move were final when it happened)
     atomicOr(&q.mask[j >> 5], 1u << (j & 31));
   }
   __syncthreads();

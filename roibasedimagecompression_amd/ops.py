@@ -688,14 +688,15 @@ class Rhccq:
             st = pending[-1][0].numpy().copy()
         return step, st, n_ov
 
-    def npysort_head(self, w, cap, depth0=-1):
+    def npysort_head(self, w, cap, depth0=-1, use_lds=True):
         """the SET np.argsort(w)[:cap] under numpy's scalar sort kernel (rhccq_npysort_head; w: non-negative integer counts as a
         float64 device tensor or numpy array): bool[k] numpy mask.  The selection inside a capped mini-batch reassignment."""
         w = w if torch.is_tensor(w) else self.dev(np.ascontiguousarray(w, dtype=np.float64))
         k = int(w.numel())
         scratch = self.empty((16 * k,), torch.uint8)
         mask = self.empty(((k + 31) // 32,), torch.int32)
-        self._check(self.lib.rhccq_npysort_head(self.ctx, self._p(w), k, int(cap), int(depth0), self._p(scratch), self._p(mask)), "npysort_head")
+        self._check(self.lib.rhccq_npysort_head(self.ctx, self._p(w), k, int(cap), int(depth0), int(bool(use_lds)), self._p(scratch), self._p(mask)),
+                    "npysort_head")
         bits = np.unpackbits(mask.cpu().numpy().view(np.uint8), bitorder="little")[:k]
         return bits.astype(bool)
 

@@ -161,6 +161,8 @@ def test_npysort_head_equals_numpy_scalar_argsort(rh, O):
             want = np.zeros(k, bool)
             want[order[:cap]] = True
             assert np.array_equal(rh.npysort_head(w, cap), want), (i, k, cap)
+            if k > 64:
+                assert np.array_equal(rh.npysort_head(w, cap, use_lds=False), want), (i, k, cap, "global memory throughout")
             n_checked += 1
     assert n_checked >= 300, n_checked
     rng = np.random.default_rng(15)
@@ -173,6 +175,7 @@ def test_npysort_head_equals_numpy_scalar_argsort(rh, O):
             want = np.zeros(k, bool)
             want[order[:cap]] = True
             assert np.array_equal(rh.npysort_head(w, cap, depth0), want), (k, draws, depth0, cap)
+            assert np.array_equal(rh.npysort_head(w, cap, depth0, use_lds=False), want), (k, draws, depth0, cap, "global memory throughout")
 
 
 @pytest.mark.parametrize("order", ["npysort", "stable"])
