@@ -31,8 +31,8 @@ if len(sys.argv) > 1 and sys.argv[1] == "--child":
     import hashlib
     print(f"{best * 1e3 / k:.4f} {hashlib.sha256(info['chosen'].tobytes()).hexdigest()[:12]} {int(info['state'][0][5])}")
     sys.exit(0)
-libs = sys.argv[1:3]
-reps = int(sys.argv[3]) if len(sys.argv) > 3 else 3
+libs = [a for a in sys.argv[1:] if not a.isdigit()]          # two or more builds
+reps = next((int(a) for a in sys.argv[1:] if a.isdigit()), 3)
 res = {l: [] for l in libs}
 for r in range(reps):
     for l in libs:
