@@ -218,6 +218,36 @@ def test_config0_lenna512_reference_chain():
     assert np.array_equal(np.unique(p, axis=0), np.unique(gp, axis=0))
 
 
+def test_config0_lenna512_through_the_native_entry():
+    """The same configs[0] frame through ONE call of rhccq_encode_frame (the native host: csrc/encode_frame.hip) against the REFERENCE's own final
+    output (g12_lenna512.*): every pixel's colour identical, the same set of palette colours (A': the reference appends the k-means children of
+    oversize clusters in thread-completion order) -- no oracle and no Python host logic in between."""
+    import json
+    import torch
+    from PIL import Image
+    from roibasedimagecompression_amd.frame import ClassSpec, FrameEncoder
+    from roibasedimagecompression_amd.ops import default_context
+    rh = default_context()
+    g = np.load(os.path.join(G, "g12_lenna512.npz"))
+    meta = json.load(open(os.path.join(G, "g12_lenna512.json")))
+    img = np.asarray(Image.open(os.path.join(G, "Lenna.png")).convert("RGB"), dtype=np.uint8)
+    qs = [int(v) for v in g["q"]]
+    specs = []
+    for key, q in (("lab_roi", qs[0]), ("lab_non", qs[1])):
+        lab = g[key].astype(np.int32) + 1
+        rows, cols = np.where(lab > 0)
+        bbox = (int(rows.min()), int(cols.min()), int(rows.max()) + 1, int(cols.max()) + 1)
+        specs.append(ClassSpec(torch.from_numpy(np.ascontiguousarray(lab)).to(rh.device), np.zeros(int(lab.max()), np.int64), [bbox], q))
+    out = FrameEncoder(rh).encode_native(torch.from_numpy(np.ascontiguousarray(img)).to(rh.device), specs)
+    p = out["palette"]
+    i = out["indices"].cpu().numpy()
+    i = (i.view(np.uint16) if out["indices_dtype"] == "uint16" else i).astype(np.int64).reshape(-1)
+    gp, gi = g["fin_pal"], g["fin_idx"].astype(np.int64).reshape(-1)
+    assert len(p) == len(gp) == meta["levels"]["fin"]["colours"]
+    assert np.array_equal(p[i], gp[gi])                      # the decoded frame is the reference's
+    assert np.array_equal(np.unique(p, axis=0), np.unique(gp, axis=0))
+
+
 def test_split_score_vs_oracle():
     """encoder/subregions/split_score.py:15-142 on the device vs the numpy restatement (scikit-image's rgb2lab / rgb2gray /
     sobel / uniform LBP(8,1) from their published definitions -- PARITY UNPINNED, scikit-image is not in the build container).
