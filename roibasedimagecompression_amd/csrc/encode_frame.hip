@@ -719,7 +719,14 @@ void cluster_jobs(Lane& L, std::vector<Job>& jobs) {
     EF_RC(c, rhccq_kmeans(c, d_keys, d_desc, d_koff, d_rand, (int32_t)run.size(), max_n, work, d_lab, d_info));
     std::vector<int32_t> lab(cat.size());
     L.download(lab.data(), d_lab, lab.size());
-    if (trace_on()) fprintf(stderr, "[rhccq] kmeans split round: %zu nodes, %zu points, largest %d, %lld clusters, %.2f ms\n", run.size(), cat.size(), max_n, (long long)ktot, now_ms() - t_km);
+    if (trace_on()) {
+      std::vector<int32_t> inf(run.size() * 4);
+      L.download(inf.data(), d_info, inf.size());
+      int it_max = 0;
+      for (size_t i = 0; i < run.size(); ++i) it_max = std::max(it_max, inf[4 * i]);
+      fprintf(stderr, "[rhccq] kmeans split round: %zu nodes, %zu points, largest %d, %lld clusters, %.2f ms, most Lloyd iterations %d (node 0: %d)\n", run.size(),
+              cat.size(), max_n, (long long)ktot, now_ms() - t_km, it_max, inf[0]);
+    }
     for (size_t i = 0; i < run.size(); ++i) {
       const int ndi = run[i].first;
       const int64_t k = run[i].second;
