@@ -3,9 +3,11 @@
 // random_state=42, n_init='auto')).  These kernels follow sklearn's fit operation for operation -- the
 // RandomState(42) stream (randint batches, choice() reassignment rows, k-means++ uniforms) is replayed on the
 // device from its raw MT19937 words, k-means++ runs over the init sample in DRAW order, centre updates add the
-// batch members in batch order -- so that the result equals sklearn's bit for bit, except for ONE canonical
-// choice: np.argsort's unstable tie order in the low-count reassignment is replaced by the stable order
-// (oracle/rhccq_oracle.py::minibatch_kmeans_labels; pinned against sklearn itself in tests/golden/).
+// batch members in batch order, and np.argsort's UNSTABLE tie order in the low-count reassignment is the one
+// numpy's scalar sort kernel produces (k8_npysort.h) -- so that the result equals scikit-learn's untouched
+// fit_predict bit for bit under numpy's scalar sort kernels, the host setting of record (RHCCQ_OPT_REASSIGN_ORDER
+// = 0: the stable order of rounds 1-3; oracle/rhccq_oracle.py::minibatch_kmeans_labels; both pinned against
+// sklearn itself in tests/golden/).
 //
 // MI355X design
 //   init   greedy k-means++ over the init sample in EXACT integers.  The chain of k picks is sequential, so one
