@@ -493,6 +493,13 @@ int rhccq_edge_score(rhccq_ctx* ctx, const uint64_t* red, int32_t n_labels, int3
  * reduction capped at `cap` labels; per pair one verdict.  lows / highs: HOST int32[n_pairs], pairs with equal `low` adjacent.  out: DEVICE
  * uint64[n_pairs][5] = {edge components, edge pixels, sum gray, sum gray^2, components of {nm > low}}; a pair whose last number exceeds `cap`
  * must be scored through rhccq_label_reduce / rhccq_edge_score instead.  work: rhccq_canny_scores_bytes(H, W, cap) bytes. */
+/* rhccq_canny_scores_nested: the same scores from ONE union-find grown over the thresholds in descending `low` (the sets {nm > low} nest):
+ * every pixel is linked once over the whole search, a pair's verdict marks the roots of the pixels above `high` with a generation number and
+ * sums the pixels under marked roots -- no component numbering, no per-label tables, no capacity.  Pairs in any order; out[i][4] = 0.
+ * work: rhccq_canny_scores_nested_bytes(H, W) bytes. */
+int64_t rhccq_canny_scores_nested_bytes(int32_t H, int32_t W);
+int rhccq_canny_scores_nested(rhccq_ctx* ctx, const uint16_t* nm, const uint8_t* gray, int32_t H, int32_t W, const int32_t* lows_host,
+                              const int32_t* highs_host, int32_t n_pairs, void* work, int64_t work_bytes, uint64_t* out);
 int64_t rhccq_canny_scores_bytes(int32_t H, int32_t W, int32_t cap);
 int rhccq_canny_scores(rhccq_ctx* ctx, const uint16_t* nm, const uint8_t* gray, int32_t H, int32_t W, const int32_t* lows_host,
                        const int32_t* highs_host, int32_t n_pairs, int32_t cap, void* work, int64_t work_bytes, uint64_t* out);

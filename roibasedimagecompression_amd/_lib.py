@@ -124,6 +124,8 @@ PROTOTYPES = {
     "rhccq_zoom_linear_f64": (c_int32, [c_void_p, c_void_p, c_int32, c_int32, c_int32, c_void_p, c_void_p, c_void_p, c_void_p, c_int32, c_int32,
                                         c_double, c_double, c_void_p]),
     "rhccq_zoom_nearest": (c_int32, [c_void_p, c_void_p, c_int32, c_int32, c_int32, c_int32, c_void_p, c_void_p, c_int32, c_int32, c_void_p]),
+    "rhccq_canny_scores_nested_bytes": (c_int64, [c_int32, c_int32]),
+    "rhccq_canny_scores_nested": (c_int32, [c_void_p, c_void_p, c_void_p, c_int32, c_int32, c_void_p, c_void_p, c_int32, c_void_p, c_int64, c_void_p]),
     "rhccq_canny_scores_bytes": (c_int64, [c_int32, c_int32, c_int32]),
     "rhccq_canny_scores": (c_int32, [c_void_p, c_void_p, c_void_p, c_int32, c_int32, c_void_p, c_void_p, c_int32, c_int32, c_void_p, c_int64, c_void_p]),
     "rhccq_edge_score": (c_int32, [c_void_p, c_void_p, c_int32, c_int32, c_void_p, c_void_p]),

@@ -1011,7 +1011,7 @@ class Rhccq:
         H, W = int(gray.shape[0]), int(gray.shape[1])
         hist = self.empty((int(self.lib.rhccq_edges_m2_bins()),), torch.int32)
         self._check(self.lib.rhccq_edges_grad_hist(self.ctx, self._p(gray), H, W, self._p(hist)), "edges_grad_hist")
-        h = hist.cpu().numpy()
+        h = self.to_host(hist)                               # (8 MB of bins: through a page-locked buffer)
         v = np.flatnonzero(h)
         return v.astype(np.int64), h[v].astype(np.int64)
 
@@ -1046,11 +1046,22 @@ class Rhccq:
         return lut, tuple(int(v) for v in out4.cpu().numpy())
 
     CANNY_SCORES_CAP = 1 << 20      # labels the fused scoring reduces per labelling (32 MB of per-label sums); beyond: the two-step path
+    CANNY_SCORES_NESTED = True      # one union-find grown over the descending thresholds (rhccq_canny_scores_nested) instead of a labelling per `low`
 
-    def canny_scores(self, nm, gray, pairs):
+    def canny_scores(self, nm, gray, pairs, nested=None):
         """[(edge components, edge pixels, sum gray, sum gray^2)] of several (low, high) pairs (normalised, low <= high) in ONE call and ONE
-        read-back (rhccq_canny_scores): pairs that share `low` share the labelling of {nm > low}"""
+        read-back: rhccq_canny_scores_nested (every pixel linked once over the whole search), or with nested=False rhccq_canny_scores (pairs
+        that share `low` share a labelling of {nm > low} from scratch) -- the same numbers"""
         H, W = int(nm.shape[0]), int(nm.shape[1])
+        if self.CANNY_SCORES_NESTED if nested is None else nested:
+            lows = (C.c_int32 * len(pairs))(*[int(p[0]) for p in pairs])
+            highs = (C.c_int32 * len(pairs))(*[int(p[1]) for p in pairs])
+            wb = int(self.lib.rhccq_canny_scores_nested_bytes(H, W))
+            work = self.empty((wb,), torch.uint8)
+            out = self.empty((len(pairs), 5), torch.int64)
+            self._check(self.lib.rhccq_canny_scores_nested(self.ctx, self._p(nm), self._p(gray), H, W, lows, highs, len(pairs), self._p(work), wb, self._p(out)),
+                        "canny_scores_nested")
+            return [tuple(int(v) for v in row[:4]) for row in out.cpu().numpy()]
         order = sorted(range(len(pairs)), key=lambda i: pairs[i])
         lows = (C.c_int32 * len(pairs))(*[int(pairs[i][0]) for i in order])
         highs = (C.c_int32 * len(pairs))(*[int(pairs[i][1]) for i in order])

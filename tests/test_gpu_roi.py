@@ -368,3 +368,26 @@ def test_notebook_cell6_inline_chain_vs_oracle():
             assert np.array_equal(E.compute_local_density(mixed, k), O.local_density(mixed, k))
         if len(np.unique(mixed)) == 3:
             assert np.array_equal(E.compute_local_density(mixed, 3), O.local_density(mixed, 3))
+
+
+def test_threshold_pair_scores_three_ways():
+    """The four numbers behind evaluate_edge_quality (edge components, edge pixels, sum and sum of squares of gray) for a set of (low, high) pairs:
+    the union-find grown over the descending thresholds (rhccq_canny_scores_nested: what get_edge_map uses), a labelling from scratch per `low`
+    with the counts kept on the device (rhccq_canny_scores) and the two-step path of round 3 (rhccq_label_reduce + rhccq_edge_score) must agree
+    exactly -- on a noisy photo (hundreds of thousands of components), a poster and tiny / degenerate frames, pairs in scrambled order with repeated
+    and equal thresholds."""
+    import torch
+    from roibasedimagecompression_amd import synth
+    from roibasedimagecompression_amd.api.edges import EdgeAnalysis
+    rng = np.random.default_rng(31)
+    for H, W, kind in ((540, 960, "photo"), (300, 420, "poster"), (7, 9, "photo"), (1, 70, "photo"), (64, 1, "photo")):
+        img = synth.photo(H, W, 77, sigma=3.0) if kind == "photo" else synth.poster(H, W, 78)
+        a = EdgeAnalysis(img)
+        pairs = [(10, 30), (10, 10), (200, 255), (37, 90), (36, 90), (37, 37), (0, 0), (0, 600), (120, 121), (64, 200), (65, 66), (10, 255)]
+        pairs = [pairs[i] for i in rng.permutation(len(pairs))]
+        nested = a.rh.canny_scores(a.nm(False), a.gray, pairs, nested=True)
+        scratch = a.rh.canny_scores(a.nm(False), a.gray, pairs, nested=False)
+        two_step = [a.rh.canny_components(a.nm(False), lo, hi, a.gray)[2] for lo, hi in pairs]
+        assert nested == scratch == two_step, (H, W, kind)
+        if H * W > 10000:
+            assert max(t[0] for t in two_step) > 50                     # real work: many components
