@@ -60,8 +60,8 @@ def parse():
     ap.add_argument("--host", choices=["native", "python"], default="native",
                     help="frame mode: host side of the encoder -- rhccq_encode_frame (C++, csrc/encode_frame.hip) or the Python FrameEncoder")
     ap.add_argument("--frames-per-step", type=int, default=None,
-                    help="frames encoded together per step and GPU (frame mode: 1 = configs[1]; stream mode: 24)")
-    ap.add_argument("--lanes", type=int, default=None, help="stream mode: batches in flight on this many host threads (5)")
+                    help="frames encoded together per step and GPU (frame mode: 1 = configs[1]; stream mode: 12)")
+    ap.add_argument("--lanes", type=int, default=None, help="stream mode: batches in flight on this many host threads (10)")
     return ap.parse_args()
 
 
@@ -457,17 +457,18 @@ def main():
     Rhccq.scan_events = []          # class-wide: the lanes of the stream regime own their own contexts
     rh = Rhccq(local)
     mode = args.mode
-    batch_mode = mode == "batch"                          # configs[2]: the frame path with 64 1080p frames per step, tiers (20, 10)
-    if batch_mode:
-        mode = "frame"
+    batch_mode = mode == "batch"                          # configs[2]: 64 1080p frames per step, tiers (20, 10): two sub-batches of 32 in flight
+    if batch_mode:                                        # (383 Mpx/s against 338-352 for one encode_batch call over all 64: same box, round 4)
+        mode = "stream"
     H = args.height or (4320 if mode == "tiled" else (1080 if batch_mode else 2160))
     W = args.width or (7680 if mode == "tiled" else (1920 if batch_mode else 3840))
-    block = args.block or (16 if mode == "stream" else 8)
+    block = args.block or (16 if (mode == "stream" and not batch_mode) else 8)
     q_roi = args.quality
     q_bg = args.quality_bg if args.quality_bg is not None else (args.quality if (mode == "frame" and not batch_mode) else 10)
-    # stream regime: measured 458 Mpx/s at 3 lanes x 16 frames, 570 at 5 x 24, 574 at 6 x 32, 605 at 8 x 32 (3.5 s per step)
-    B = args.frames_per_step or (24 if mode == "stream" else (64 if batch_mode else 1))
-    L = args.lanes or (5 if mode == "stream" else 1)
+    # stream regime, round 4 (no straggling problems any more: smaller batches, more of them in flight): 910 Mpx/s at 5 lanes x 24 frames,
+    # 754 at 4 x 32, 806 at 8 x 16, 883 at 4 x 48, 1 011 at 12 x 8, 1 015 at 8 x 12, 1 031 at 10 x 10, 1 014-1 113 at 10 x 12 (same box pairs)
+    B = args.frames_per_step or (32 if batch_mode else (12 if mode == "stream" else 1))
+    L = args.lanes or (2 if batch_mode else (10 if mode == "stream" else 1))
 
     def barrier():
         if world > 1:
@@ -504,16 +505,18 @@ def main():
         # configs[4]: a stream of 4K frames per GPU, batches of B frames, L batches in flight
         from roibasedimagecompression_amd.stream import StreamEncoder
         frames, masks = [], []
-        for i in range(B):
-            img, r_i, sp_i, m_i, (lr, ln, br, bn) = build_inputs(rh, H, W, 1234 + rank * B + i, (2, 1), q_roi, q_bg, args.sigma)
+        D = B * L if batch_mode else B                      # distinct frames: configs[2] = ONE batch of B * L different frames per step
+        for i in range(D):
+            img, r_i, sp_i, m_i, (lr, ln, br, bn) = build_inputs(rh, H, W, 1234 + rank * D + i, (2, 1), q_roi, q_bg, args.sigma)
             frames.append((r_i, sp_i))
             masks.append(m_i)
         rgb, specs = frames[0]
         se = StreamEncoder(local, batch=B, lanes=L)
+        reps = B * L // D                                   # passes over the distinct frames per step
 
         def run(n_steps):
-            outs = se.run(frames * (L * n_steps))
-            for _ in range(L * n_steps):
+            outs = se.run(frames * (reps * n_steps))
+            for _ in range(reps * n_steps):
                 for (r, _), m in zip(frames, masks):
                     dct_ext(rh, r, m, block)
             return outs
@@ -524,8 +527,9 @@ def main():
         barrier()
         dt = time.perf_counter() - t0
         px = H * W * args.steps * world * B * L
-        workload = (f"configs[4]: stream of {B * L * args.steps} {W}x{H} RGB synthetic 'photo' frames per GPU ({B} distinct frames, seeds 1234+rank*{B}+i, "
-                    f"sigma={args.sigma}) through StreamEncoder: batches of {B}, {L} in flight; quality tiers ({q_roi},{q_bg}), three-level palette "
+        workload = ((f"configs[2]: batch of {B * L} {W}x{H} RGB synthetic 'photo' frames per GPU per step ({D} distinct frames, seeds 1234+rank*{D}+i, " if batch_mode else
+                     f"configs[4]: stream of {B * L * args.steps} {W}x{H} RGB synthetic 'photo' frames per GPU ({B} distinct frames, seeds 1234+rank*{B}+i, ")
+                    + f"sigma={args.sigma}) through StreamEncoder: batches of {B}, {L} in flight; quality tiers ({q_roi},{q_bg}), three-level palette "
                     f"hierarchy, {block}x{block} DCT extension")
         scaling, par = "weak", f"frame-parallel x{world}, {L} lanes x batch {B}"
     else:
