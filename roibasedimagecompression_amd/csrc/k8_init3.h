@@ -31,6 +31,7 @@ constexpr int kG3MaxSup = kG3MaxLeaves / 16;            // 384
 constexpr int kG3MaxHyp = kG3MaxSup / 16;               // 24 hypers of 16 supers = 4 096 samples
 constexpr int kG3MaxDsum = kG3MaxSamples / 64;          // 64-draw sums: 1 536
 constexpr int kG3MaxTop = kG3MaxDsum / 64;              // 4 096-draw sums: 24
+static_assert(kG3MaxTop <= 32, "the 32-bit top-level scan covers half a wave");
 constexpr int kG3MaxItems = 4096;                       // (candidate, leaf) items per pick
 constexpr int kG3WList = kG3MaxSup;                     // hit supers one candidate keeps: room for all of them (u16 entries, 12 KB for 16 candidates)
 constexpr int kG3Touch = 512;
@@ -40,12 +41,23 @@ constexpr int kG3Touch = 512;
 // extra dependent LDS round trips (hyper table -> scalar bit walk -> super table) cost more than the ~80 box-test instructions they save:
 // each search wave is a chain of dependent latencies, not an issue-bound stream.  Kept as a checked alternative, off.
 constexpr bool kG3UseHypers = false;
-constexpr int kG3Keep = 3;                              // evaluation instruction streams (16 items each) a wave keeps in registers
+// round 4: a super's BOX never changes after the tables are built (only its maximum does), so every lane keeps the boxes of "its" supers
+// (lane + 64 r, r < 6) in 18 registers for the whole chain: the super stage then fetches only the six maxima (4 B instead of 16 B per
+// super and wave: 55 KB less LDS traffic per pick) and computes the six box distances WHILE those are in flight, instead of waiting for
+// six 16-byte entries first.  (The earlier attempt to hide this round trip -- the whole entries requested at the start of the pick -- lost
+// because maxima read that early are stale; the boxes cannot be.)  One candidate per search wave only.
+#ifndef RHCCQ_G3_REGBOX
+#define RHCCQ_G3_REGBOX 1
+#endif
+constexpr bool kG3RegBox = RHCCQ_G3_REGBOX != 0;
+#ifndef RHCCQ_G3_KEEP
+#define RHCCQ_G3_KEEP 1
+#endif
+constexpr int kG3Keep = RHCCQ_G3_KEEP;                              // evaluation instruction streams (16 items each) a wave keeps in registers
 
 struct G3Shared {
   unsigned long long delta[kTMaxI];
   unsigned long long R[kTMaxI];                         // integer search targets: ceil(u * pot)
-  unsigned long long pot;
   unsigned long long red64[kG3Waves];
   int cand[kTMaxI];
   uint2 ck[kTMaxI];                                     // candidate colour, its squared norm
@@ -58,6 +70,15 @@ __device__ __forceinline__ int g3_rank_in(unsigned long long m) {
   return (int)__builtin_amdgcn_mbcnt_hi((unsigned)(m >> 32), __builtin_amdgcn_mbcnt_lo((unsigned)m, 0u));
 }
 
+// inclusive scan over lanes 0 .. 31 only (what lanes 32 .. 63 end up with is not a scan): the wave total of those lanes must fit 32 bits
+__device__ __forceinline__ unsigned half_incscan_u32(unsigned v) {
+  v += (unsigned)__builtin_amdgcn_update_dpp(0, (int)v, 0x111, 0xF, 0xF, true);   // row_shr:1
+  v += (unsigned)__builtin_amdgcn_update_dpp(0, (int)v, 0x112, 0xF, 0xF, true);   // row_shr:2
+  v += (unsigned)__builtin_amdgcn_update_dpp(0, (int)v, 0x114, 0xF, 0xF, true);   // row_shr:4
+  v += (unsigned)__builtin_amdgcn_update_dpp(0, (int)v, 0x118, 0xF, 0xF, true);   // row_shr:8  -> scan inside each row of 16
+  v += (unsigned)__builtin_amdgcn_update_dpp(0, (int)v, 0x142, 0xA, 0xF, false);  // row_bcast:15 into rows 1 and 3
+  return v;
+}
 __device__ __forceinline__ unsigned dpp_quad_sum(unsigned v) {
   v += (unsigned)__builtin_amdgcn_update_dpp(0, (int)v, 0xB1, 0xF, 0xF, true);    // quad_perm [1,0,3,2]
   v += (unsigned)__builtin_amdgcn_update_dpp(0, (int)v, 0x4E, 0xF, 0xF, true);    // quad_perm [2,3,0,1]
@@ -206,10 +227,22 @@ __global__ __launch_bounds__(kG3Threads) void mbk_init3_kernel(const uint32_t* _
     }
     hyp[h] = make_uint4(box_pair((unsigned)r0, (unsigned)r1), box_pair((unsigned)g0, (unsigned)g1), box_pair((unsigned)b0, (unsigned)b1), m);
   }
-  if (tid == 0) { cho[0] = P.first; sh.n_touch2[0] = 0; sh.n_touch2[1] = 0; sh.pot = psum; sh.n_items = 0; sh.overflow = 0; }
+  if (tid == 0) { cho[0] = P.first; sh.n_touch2[0] = 0; sh.n_touch2[1] = 0; sh.n_items = 0; sh.overflow = 0; }
   if (tid < kTMaxI) sh.delta[tid] = 0;
-  if (tid < T && k > 1) sh.R[tid] = (unsigned long long)ceil(rand[P.rand_off + tid] * (double)psum);
+  // Every thread tracks the potential in a register (the block sums hand all of them the same totals).  The LAST wave -- never a search
+  // wave: T <= 12 for init samples <= 98 304 -- fetches the uniforms of the coming pick (a cold line in HBM: a wave's memory operations
+  // return in order, so a search wave that asked for it would wait for it before its own sample read) and turns them into the integer
+  // targets at the end of the pick; it also records the winner.
+  unsigned long long pot = psum;
+  const bool r_wave = wave == kG3Waves - 1;
+  if (r_wave && lane < T && k > 1) sh.R[lane] = (unsigned long long)ceil(rand[P.rand_off + lane] * (double)psum);
   __syncthreads();
+  uint32_t sbx[kG3MaxSup / 64], sby[kG3MaxSup / 64], sbz[kG3MaxSup / 64];      // (kG3RegBox) the static boxes of supers lane + 64 r
+#pragma unroll
+  for (int r = 0; r < kG3MaxSup / 64; ++r) {
+    const uint4 e = sup[min(r * 64 + lane, nsb - 1)];
+    sbx[r] = e.x; sby[r] = e.y; sbz[r] = e.z;
+  }
 #ifdef RHCCQ_STAMPS
   unsigned long long _acc[16] = {0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0};
   unsigned long long _last = clock64();
@@ -222,8 +255,7 @@ __global__ __launch_bounds__(kG3Threads) void mbk_init3_kernel(const uint32_t* _
     WBEGIN();
     // the next pick's uniforms are a cold line in HBM: fetch them now, use them at the end of the pick
     double u_next = 0.0;
-    if (tid < T && c + 1 < k) u_next = rand[P.rand_off + (size_t)c * T + tid];
-    const unsigned long long pot = sh.pot;
+    if (r_wave && lane < T && c + 1 < k) u_next = rand[P.rand_off + (size_t)c * T + lane];
     if (!kIW && tid < T) sh.delta[tid] = 0;              // (read for the arg-max before the previous pick's closing barrier; the in-wave variant
                                                          //  stores every candidate's sum instead of adding to it)
     const int* touch_r = s_touch + (((c - 1) & 1) ? kG3Touch : 0);
@@ -240,21 +272,39 @@ __global__ __launch_bounds__(kG3Threads) void mbk_init3_kernel(const uint32_t* _
       // np.searchsorted(cumsum(closest), r, 'left') in DRAW order; cum and the target R = ceil(r) are exact integers
       int tc[kCW];
       bool on[kCW];
-      unsigned long long R[kCW];
+      unsigned long long R[kCW], rv[kCW];
+      const unsigned v_top = dtop[min(lane, ntop - 1)];       // (the targets and the top level of the sums in ONE round trip)
 #pragma unroll
       for (int c2 = 0; c2 < kCW; ++c2) {
         tc[c2] = wave + c2 * NW;
         on[c2] = tc[c2] < T;
-        const unsigned long long rv = sh.R[min(tc[c2], T - 1)];
-        R[c2] = ((unsigned long long)(unsigned)__builtin_amdgcn_readfirstlane((int)(rv >> 32)) << 32) |
-                (unsigned)__builtin_amdgcn_readfirstlane((int)(unsigned)rv);
+        rv[c2] = sh.R[min(tc[c2], T - 1)];
       }
+      __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+      for (int c2 = 0; c2 < kCW; ++c2)
+        R[c2] = ((unsigned long long)(unsigned)__builtin_amdgcn_readfirstlane((int)(rv[c2] >> 32)) << 32) |
+                (unsigned)__builtin_amdgcn_readfirstlane((int)(unsigned)rv[c2]);
       int cand[kCW], l1[kCW], bh[kCW];
       uint32_t ck[kCW];
       bool found[kCW];
       unsigned rr[kCW], rr3[kCW];
-      {
-        const unsigned v = lane < ntop ? dtop[lane] : 0u;
+      if (__builtin_amdgcn_readfirstlane((int)(pot >> 32)) == 0) {
+        // the whole potential fits 32 bits (every pick of a photo's chain: 90 000 samples x ~10^4): ONE scan of the <= 24 top-level
+        // sums over half a wave (5 shifted adds) instead of two 16-bit-limb scans over the whole wave and 64-bit compares
+        const unsigned v = lane < ntop ? v_top : 0u;
+        const unsigned inc = half_incscan_u32(v);
+        const unsigned exc = inc - v;
+#pragma unroll
+        for (int c2 = 0; c2 < kCW; ++c2) {
+          const unsigned r32 = (unsigned)R[c2];
+          const unsigned long long m1 = __ballot(v > 0 && exc < r32 && r32 <= inc);
+          found[c2] = m1 != 0ull;
+          l1[c2] = found[c2] ? __ffsll((long long)m1) - 1 : 0;
+          rr[c2] = r32 - (unsigned)__builtin_amdgcn_readlane((int)exc, l1[c2]);             // <= the 4 096-draw sum
+        }
+      } else {
+        const unsigned v = lane < ntop ? v_top : 0u;
         const unsigned long long inc = wave_incscan_limbs(v);
         const unsigned long long exc = inc - v;
 #pragma unroll
@@ -344,6 +394,29 @@ __global__ __launch_bounds__(kG3Threads) void mbk_init3_kernel(const uint32_t* _
           if (h) wlist[tc[0] * kG3WList + n_sup[0] + g3_rank_in(m)] = (uint16_t)sbi;
           n_sup[0] += __popcll(m);
         }
+      } else if constexpr (kCW == 1 && kG3RegBox) {
+        // two straight-line versions (all six rounds / the two a small problem has) behind ONE wave-uniform branch: a branch per round
+        // between the loads serialises them
+        auto rounds = [&](auto nr_c) {
+          constexpr int kNr = decltype(nr_c)::value;
+          uint32_t sw[kNr];
+          unsigned d2[kNr];
+#pragma unroll
+          for (int r = 0; r < kNr; ++r) sw[r] = sup[min(r * 64 + lane, nsb - 1)].w;
+          __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+          for (int r = 0; r < kNr; ++r) d2[r] = box_dist2(cp[0], sbx[r], sby[r], sbz[r]);      // in the shadow of the loads
+          __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+          for (int r = 0; r < kNr; ++r) {
+            const bool h = (bool)((int)(d2[r] < sw[r]) & (int)(r * 64 + lane < nsb) & (int)on[0]);      // (no short circuit)
+            const unsigned long long m = __ballot(h);
+            if (h) wlist[tc[0] * kG3WList + n_sup[0] + g3_rank_in(m)] = (uint16_t)(r * 64 + lane);
+            n_sup[0] += __popcll(m);
+          }
+        };
+        if (nsb > 128) rounds(std::integral_constant<int, kG3MaxSup / 64>{});
+        else rounds(std::integral_constant<int, 2>{});
       } else {
         uint4 se[kG3MaxSup / 64];
         const int nr = nsb > 128 ? kG3MaxSup / 64 : 2;      // (wave-uniform; the unrolled rounds beyond it cost a scalar branch)
@@ -372,21 +445,24 @@ __global__ __launch_bounds__(kG3Threads) void mbk_init3_kernel(const uint32_t* _
       // the leaves of the hit supers: four supers per round (one row of lanes each), four independent rounds per batch; the FIRST
       // batch of every candidate of the wave in one straight line (one atomic for all of them), further batches (one candidate in
       // six has more than 16 hit supers) candidate by candidate
-      {
-        int bq[kCW][4];
-        bool hb[kCW][4];
-        unsigned long long mb[kCW][4];
-        uint32_t sq[kCW][4];
-        uint4 be[kCW][4];
+      // (straight-line versions for 1 .. 4 rounds behind ONE wave-uniform branch -- most candidates have 5 .. 16 hit supers; a branch per
+      //  round between the loads serialises them: measured, 4.65 vs 4.39 us per pick)
+      auto first_batch = [&](auto nq_c) {
+        constexpr int kNq = decltype(nq_c)::value;
+        int bq[kCW][kNq];
+        bool hb[kCW][kNq];
+        unsigned long long mb[kCW][kNq];
+        uint32_t sq[kCW][kNq];
+        uint4 be[kCW][kNq];
 #pragma unroll
         for (int c2 = 0; c2 < kCW; ++c2)
 #pragma unroll
-          for (int q = 0; q < 4; ++q) sq[c2][q] = wlist[min(tc[c2], kTMaxI - 1) * kG3WList + 4 * q + rq];      // (entries beyond n_sup: stale, masked below)
+          for (int q = 0; q < kNq; ++q) sq[c2][q] = wlist[min(tc[c2], kTMaxI - 1) * kG3WList + 4 * q + rq];      // (entries beyond n_sup: stale, masked below)
         __builtin_amdgcn_sched_barrier(0);
 #pragma unroll
         for (int c2 = 0; c2 < kCW; ++c2)
 #pragma unroll
-          for (int q = 0; q < 4; ++q) {
+          for (int q = 0; q < kNq; ++q) {
             const int b = (int)sq[c2][q] * 16 + rj;
             bq[c2][q] = ((int)(4 * q + rq < n_sup[c2]) & (int)(b < nb)) ? b : -1;
             be[c2][q] = blk[max(bq[c2][q], 0)];
@@ -396,7 +472,7 @@ __global__ __launch_bounds__(kG3Threads) void mbk_init3_kernel(const uint32_t* _
 #pragma unroll
         for (int c2 = 0; c2 < kCW; ++c2)
 #pragma unroll
-          for (int q = 0; q < 4; ++q) {
+          for (int q = 0; q < kNq; ++q) {
             const unsigned d2 = box_dist2(cp[c2], be[c2][q].x, be[c2][q].y, be[c2][q].z);
             hb[c2][q] = (bool)((int)(d2 < be[c2][q].w) & (int)(bq[c2][q] >= 0));
             mb[c2][q] = __ballot(hb[c2][q]);
@@ -410,7 +486,7 @@ __global__ __launch_bounds__(kG3Threads) void mbk_init3_kernel(const uint32_t* _
             else {
               base = tc[0] * cap_c + n_it;
 #pragma unroll
-              for (int q = 0; q < 4; ++q) {
+              for (int q = 0; q < kNq; ++q) {
                 if (hb[0][q]) items[base + g3_rank_in(mb[0][q])] = ((uint32_t)tc[0] << 24) | (uint32_t)bq[0][q];
                 base += __popcll(mb[0][q]);
               }
@@ -424,13 +500,22 @@ __global__ __launch_bounds__(kG3Threads) void mbk_init3_kernel(const uint32_t* _
 #pragma unroll
             for (int c2 = 0; c2 < kCW; ++c2)
 #pragma unroll
-              for (int q = 0; q < 4; ++q) {
+              for (int q = 0; q < kNq; ++q) {
                 if (hb[c2][q]) items[base + g3_rank_in(mb[c2][q])] = ((uint32_t)tc[c2] << 24) | (uint32_t)bq[c2][q];
                 base += __popcll(mb[c2][q]);
               }
           }
           }
         }
+      };
+      {
+        int ns_max = n_sup[0];
+#pragma unroll
+        for (int c2 = 1; c2 < kCW; ++c2) ns_max = max(ns_max, n_sup[c2]);
+        if (ns_max > 12) first_batch(std::integral_constant<int, 4>{});
+        else if (ns_max > 8) first_batch(std::integral_constant<int, 3>{});
+        else if (ns_max > 4) first_batch(std::integral_constant<int, 2>{});
+        else if (ns_max > 0) first_batch(std::integral_constant<int, 1>{});
       }
 #pragma unroll
       for (int c2 = 0; c2 < kCW; ++c2) {
@@ -553,8 +638,15 @@ __global__ __launch_bounds__(kG3Threads) void mbk_init3_kernel(const uint32_t* _
     STAMP(1);
     WBEGIN();
     // ================= phase 3: potentials ===================================================================
-    const bool use_list = sh.overflow == 0;
-    const int n_items = use_list ? sh.n_items : 0;
+    // (this wave's slots of the work list are requested TOGETHER with the list's length -- one LDS round trip instead of two; what a slot
+    //  beyond the length holds is never used)
+    uint32_t wpre[kG3Keep];
+#pragma unroll
+    for (int s = 0; s < kG3Keep; ++s) wpre[s] = kIW ? 0u : items[16 * (wave + s * kG3Waves) + quad];
+    const int ovf_ = sh.overflow, nit_ = sh.n_items;
+    __builtin_amdgcn_sched_barrier(0);
+    const bool use_list = ovf_ == 0;
+    const int n_items = use_list ? nit_ : 0;
     const int n_ops = (n_items + 15) >> 4;                 // one evaluation instruction stream = 16 items, one per quad
     const bool kept = n_ops <= kG3Waves * kG3Keep;         // every item's samples stay in the registers of its wave
     int* touch_w = s_touch + ((c & 1) ? kG3Touch : 0);
@@ -577,11 +669,11 @@ __global__ __launch_bounds__(kG3Threads) void mbk_init3_kernel(const uint32_t* _
         kb[s] = ka[s];
         if (16 * (wave + s * kG3Waves) < n_items) {
           const int ii = 16 * (wave + s * kG3Waves) + quad;
-          const uint32_t w = items[min(ii, n_items - 1)];
+          const uint32_t w = ii < n_items ? wpre[s] : 0xf0000000u;      // candidate numbers are < 16: the high nibble marks a padding quad (it reads leaf 0)
           const uint4* p4 = reinterpret_cast<const uint4*>(samp + ((w & 0xffffffu) << 4) + 4 * qj);
           ka[s] = p4[0];
           kb[s] = p4[1];
-          kw[s] = ii < n_items ? w : (w | 0xf0000000u);    // candidate numbers are < 16: the high nibble marks a padding quad
+          kw[s] = w;
         }
       }
 #pragma unroll
@@ -642,13 +734,23 @@ __global__ __launch_bounds__(kG3Threads) void mbk_init3_kernel(const uint32_t* _
     WBEGIN();
     // ================= phase 4: greedy choice + commit =======================================================
     // largest reduction == smallest potential; the first candidate wins ties
-    const unsigned long long dv = lane < T ? sh.delta[lane] : 0ull;
-    const unsigned dhi = (unsigned)(dv >> 32), dlo = (unsigned)dv;
-    const unsigned mhi = wave_max_u32(dhi);
-    const unsigned mlo = wave_max_u32(dhi == mhi ? dlo : 0u);
-    const unsigned long long bd = ((unsigned long long)mhi << 32) | mlo;
+    const uint32_t ckl = sh.ck[lane & (kTMaxI - 1)].x;      // (requested with the sums: one round trip)
+    const unsigned long long dv = sh.delta[lane & (kTMaxI - 1)];
+    __builtin_amdgcn_sched_barrier(0);
+    // (the <= 16 sums sit in the first row of lanes: a row maximum and one readlane; and while the potential is below 2^32 -- it bounds
+    //  every sum -- their high words are zero)
+    static_assert(kTMaxI == 16, "the candidates' sums fill one row of lanes");
+    const unsigned dhi = lane < T ? (unsigned)(dv >> 32) : 0u, dlo = lane < T ? (unsigned)dv : 0u;
+    unsigned long long bd;
+    if (__builtin_amdgcn_readfirstlane((int)(pot >> 32)) == 0) {
+      bd = (unsigned)__builtin_amdgcn_readlane((int)dpp_row_max(dlo), 0);
+    } else {
+      const unsigned mhi = (unsigned)__builtin_amdgcn_readlane((int)dpp_row_max(dhi), 0);
+      const unsigned mlo = (unsigned)__builtin_amdgcn_readlane((int)dpp_row_max(dhi == mhi ? dlo : 0u), 0);
+      bd = ((unsigned long long)mhi << 32) | mlo;
+    }
     const int best = __ffsll((long long)__ballot(lane < T && dv == bd)) - 1;
-    const uint32_t kbest = (uint32_t)__builtin_amdgcn_readlane((int)(lane < T ? sh.ck[lane].x : 0u), best);
+    const uint32_t kbest = (uint32_t)__builtin_amdgcn_readlane((int)ckl, best);
     const int nabest = (int)norm2_key(kbest);
     if (kIW && use_list) {
       // the winner's wave commits the leaves it still holds; leaves beyond those are shared out over all waves (their samples re-read)
@@ -713,12 +815,16 @@ __global__ __launch_bounds__(kG3Threads) void mbk_init3_kernel(const uint32_t* _
       }
     }
     if (tid == 0) {
-      cho[c] = sh.cand[best];
-      sh.pot = pot - bd;
       sh.n_items = 0; sh.overflow = 0;
       sh.n_touch2[(c + 1) & 1] = 0;
     }
-    if (tid < T) sh.R[tid] = (unsigned long long)ceil(u_next * (double)(pot - bd));
+    pot -= bd;
+    if (r_wave) {
+      if (lane == 0) cho[c] = sh.cand[best];
+      // (a potential below 2^32 -- the usual case -- converts in one instruction each way; the generic 64-bit conversions are ~30)
+      if (lane < T)
+        sh.R[lane] = (pot >> 32) == 0 ? (unsigned long long)(unsigned)ceil(u_next * (double)(unsigned)pot) : (unsigned long long)ceil(u_next * (double)pot);
+    }
     WEND(3);
     STAMP(6);
     __syncthreads();
