@@ -50,6 +50,17 @@ constexpr bool kG3UseHypers = false;
 #define RHCCQ_G3_REGBOX 1
 #endif
 constexpr bool kG3RegBox = RHCCQ_G3_REGBOX != 0;
+// ... and a ROUND of 64 supers (= 4 hypers of 16) is skipped as a whole when none of its four hypers can improve: the <= 24 hyper entries are
+// requested with the pick's first reads (a maximum read that early may be stale, i.e. larger: conservative), tested by 24 lanes in one go
+// behind the search, and the six rounds' box tests run under wave-uniform guards.  Unlike the hyper LEVEL above this adds no dependent
+// round trip: the supers' maxima are still requested unconditionally, only VALU work is skipped (a candidate meets 2-4 hypers).
+#ifndef RHCCQ_G3_HYPSKIP
+#define RHCCQ_G3_HYPSKIP 1
+#endif
+constexpr bool kG3HypSkip = RHCCQ_G3_HYPSKIP != 0;
+#ifndef RHCCQ_G3_FIRSTQ
+#define RHCCQ_G3_FIRSTQ 6
+#endif
 #ifndef RHCCQ_G3_KEEP
 #define RHCCQ_G3_KEEP 1
 #endif
@@ -149,6 +160,7 @@ __global__ __launch_bounds__(kG3Threads) void mbk_init3_kernel(const uint32_t* _
   __shared__ G3Shared sh;
   __shared__ uint4 blk[kG3MaxLeaves];                    // per leaf: box (3 pairs), max closest
   __shared__ uint4 sup[kG3MaxSup];                       // per super: box, max of the leaves' max (may lag high)
+  __shared__ uint32_t supw[kG3MaxSup];                   // the maxima again, DENSE: 64 lanes reading sup[].w walk LDS at a 16-byte stride (bank conflicts)
   __shared__ uint4 hyp[kG3MaxHyp];                       // per hyper (16 supers): box, max (may lag high) -- round 4: see the super stage
   __shared__ uint32_t dsum[kG3MaxDsum];                  // per 64 consecutive draws: sum of closest
   __shared__ uint32_t dtop[kG3MaxTop];                   // per 4 096 consecutive draws
@@ -207,7 +219,9 @@ __global__ __launch_bounds__(kG3Threads) void mbk_init3_kernel(const uint32_t* _
       m = max(m, be.w);
     }
     sup[sb] = make_uint4(box_pair((unsigned)r0, (unsigned)r1), box_pair((unsigned)g0, (unsigned)g1), box_pair((unsigned)b0, (unsigned)b1), m);
+    supw[sb] = m;
   }
+  for (int sb = nsb + tid; sb < kG3MaxSup; sb += kG3Threads) supw[sb] = 0u;      // (no super there: no distance is below 0, the rounds need no lane mask)
   unsigned long long psum = 0;
   for (int tt = tid; tt < ntop; tt += kG3Threads) {
     unsigned sum = 0;                                     // 4 096 x 195 075 fits 32 bits
@@ -274,6 +288,8 @@ __global__ __launch_bounds__(kG3Threads) void mbk_init3_kernel(const uint32_t* _
       bool on[kCW];
       unsigned long long R[kCW], rv[kCW];
       const unsigned v_top = dtop[min(lane, ntop - 1)];       // (the targets and the top level of the sums in ONE round trip)
+      uint4 hyp_e = make_uint4(0, 0, 0, 0);
+      if constexpr (kCW == 1 && kG3RegBox && kG3HypSkip) hyp_e = hyp[min(lane, nhyp - 1)];
 #pragma unroll
       for (int c2 = 0; c2 < kCW; ++c2) {
         tc[c2] = wave + c2 * NW;
@@ -397,19 +413,23 @@ __global__ __launch_bounds__(kG3Threads) void mbk_init3_kernel(const uint32_t* _
       } else if constexpr (kCW == 1 && kG3RegBox) {
         // two straight-line versions (all six rounds / the two a small problem has) behind ONE wave-uniform branch: a branch per round
         // between the loads serialises them
+        unsigned hyp_m = 0xffffffffu;
+        if constexpr (kG3HypSkip)
+          hyp_m = (unsigned)__ballot((bool)((int)(box_dist2(cp[0], hyp_e.x, hyp_e.y, hyp_e.z) < hyp_e.w) & (int)(lane < nhyp)));
         auto rounds = [&](auto nr_c) {
           constexpr int kNr = decltype(nr_c)::value;
           uint32_t sw[kNr];
           unsigned d2[kNr];
 #pragma unroll
-          for (int r = 0; r < kNr; ++r) sw[r] = sup[min(r * 64 + lane, nsb - 1)].w;
+          for (int r = 0; r < kNr; ++r) sw[r] = supw[r * 64 + lane];
           __builtin_amdgcn_sched_barrier(0);
 #pragma unroll
           for (int r = 0; r < kNr; ++r) d2[r] = box_dist2(cp[0], sbx[r], sby[r], sbz[r]);      // in the shadow of the loads
           __builtin_amdgcn_sched_barrier(0);
 #pragma unroll
           for (int r = 0; r < kNr; ++r) {
-            const bool h = (bool)((int)(d2[r] < sw[r]) & (int)(r * 64 + lane < nsb) & (int)on[0]);      // (no short circuit)
+            if (kG3HypSkip && ((hyp_m >> (4 * r)) & 15u) == 0u) continue;      // (wave-uniform)
+            const bool h = d2[r] < sw[r];                   // (kCW == 1: the wave's candidate exists; lanes beyond the last super read a zero maximum)
             const unsigned long long m = __ballot(h);
             if (h) wlist[tc[0] * kG3WList + n_sup[0] + g3_rank_in(m)] = (uint16_t)(r * 64 + lane);
             n_sup[0] += __popcll(m);
@@ -447,6 +467,9 @@ __global__ __launch_bounds__(kG3Threads) void mbk_init3_kernel(const uint32_t* _
       // six has more than 16 hit supers) candidate by candidate
       // (straight-line versions for 1 .. 4 rounds behind ONE wave-uniform branch -- most candidates have 5 .. 16 hit supers; a branch per
       //  round between the loads serialises them: measured, 4.65 vs 4.39 us per pick)
+      // (a candidate with more than 16 hit supers -- one in six, i.e. most picks have one -- used to take a second, dependent batch: list read,
+      //  leaf read, tests, atomic; the pick waits for its slowest search wave, so the first straight line now reaches RHCCQ_G3_FIRSTQ rounds)
+      constexpr int kFirstQ = kCW == 1 ? RHCCQ_G3_FIRSTQ : 4;
       auto first_batch = [&](auto nq_c) {
         constexpr int kNq = decltype(nq_c)::value;
         int bq[kCW][kNq];
@@ -512,6 +535,14 @@ __global__ __launch_bounds__(kG3Threads) void mbk_init3_kernel(const uint32_t* _
         int ns_max = n_sup[0];
 #pragma unroll
         for (int c2 = 1; c2 < kCW; ++c2) ns_max = max(ns_max, n_sup[c2]);
+        if constexpr (kFirstQ >= 8) {
+          if (ns_max > 28) { first_batch(std::integral_constant<int, 8>{}); ns_max = 0; }
+          else if (ns_max > 24) { first_batch(std::integral_constant<int, 7>{}); ns_max = 0; }
+        }
+        if constexpr (kFirstQ >= 6) {
+          if (ns_max > 20) { first_batch(std::integral_constant<int, 6>{}); ns_max = 0; }
+          else if (ns_max > 16) { first_batch(std::integral_constant<int, 5>{}); ns_max = 0; }
+        }
         if (ns_max > 12) first_batch(std::integral_constant<int, 4>{});
         else if (ns_max > 8) first_batch(std::integral_constant<int, 3>{});
         else if (ns_max > 4) first_batch(std::integral_constant<int, 2>{});
@@ -520,7 +551,7 @@ __global__ __launch_bounds__(kG3Threads) void mbk_init3_kernel(const uint32_t* _
 #pragma unroll
       for (int c2 = 0; c2 < kCW; ++c2) {
         const uint16_t* wl = wlist + min(tc[c2], kTMaxI - 1) * kG3WList;
-        for (int h0 = 16; h0 < n_sup[c2]; h0 += 16) {
+        for (int h0 = 4 * kFirstQ; h0 < n_sup[c2]; h0 += 16) {
           int bq[4];
           bool hb[4];
           unsigned long long mb[4];
@@ -616,10 +647,23 @@ __global__ __launch_bounds__(kG3Threads) void mbk_init3_kernel(const uint32_t* _
         const int sb = touch_r[i >> 4], b = sb * 16 + (i & 15);
         unsigned m = b < nb ? blk[b].w : 0u;
         m = dpp_row_max(m);
-        if ((i & 15) == 0) sup[sb].w = m;
+        if ((i & 15) == 0) { sup[sb].w = m; supw[sb] = m; }
       }
       // ... and the maxima of their hypers, straight from the leaves (256 per hyper, four per lane): independent of the super writes
       // above, and like them allowed to lag high
+      if constexpr (kG3RegBox && kG3HypSkip && !kG3UseHypers) {
+        // the round guards only need the hyper maxima roughly: from the (dense) super maxima, a row of 16 lanes per touched super.  A super
+        // another lane is refreshing right now may still show its old, larger value: conservative, and put right the next time the hyper
+        // is touched.  (Re-reading the hyper's 256 leaves, as the hyper LEVEL wants it, cost the search waves 9 % of the pick: the
+        // phase is bound by the instructions the four waves of a SIMD issue together.)
+        for (int i = tid - NW * 64; i < n_touched * 16; i += kG3Threads - NW * 64) {
+          const int h = touch_r[i >> 4] >> 4;
+          unsigned m = supw[h * 16 + (i & 15)];
+          m = dpp_row_max(m);
+          if ((i & 15) == 0) hyp[h].w = m;
+        }
+      }
+      if constexpr (kG3UseHypers)                                   // (exact hyper maxima only while the hyper level reads them)
       for (int e = wave - NW; e < n_touched; e += kG3Waves - NW) {
         const int h = touch_r[e] >> 4;
         unsigned m = 0;
@@ -661,15 +705,20 @@ __global__ __launch_bounds__(kG3Threads) void mbk_init3_kernel(const uint32_t* _
     if (kIW && use_list) {
       // (evaluated in phase 1 by the candidates' own waves)
     } else if (use_list) {
-      // (wave-uniform guards; a quad beyond the list re-reads the last item and contributes nothing)
+      // (wave-uniform guards; a quad beyond the list reads leaf 0 and contributes nothing.  The candidate's colour is requested BEFORE the
+      //  samples: left to the compiler that LDS read waits behind the L2 round trip)
+      uint2 kc[kG3Keep];
 #pragma unroll
       for (int s = 0; s < kG3Keep; ++s) {
         kw[s] = 0xffffffffu;
         ka[s] = make_uint4(0, 0, 0, 0);
         kb[s] = ka[s];
+        kc[s] = make_uint2(0, 0);
         if (16 * (wave + s * kG3Waves) < n_items) {
           const int ii = 16 * (wave + s * kG3Waves) + quad;
           const uint32_t w = ii < n_items ? wpre[s] : 0xf0000000u;      // candidate numbers are < 16: the high nibble marks a padding quad (it reads leaf 0)
+          kc[s] = sh.ck[(w >> 24) & (kTMaxI - 1)];
+          __builtin_amdgcn_sched_barrier(0);
           const uint4* p4 = reinterpret_cast<const uint4*>(samp + ((w & 0xffffffu) << 4) + 4 * qj);
           ka[s] = p4[0];
           kb[s] = p4[1];
@@ -680,7 +729,7 @@ __global__ __launch_bounds__(kG3Threads) void mbk_init3_kernel(const uint32_t* _
       for (int s = 0; s < kG3Keep; ++s) {
         if (16 * (wave + s * kG3Waves) < n_items) {
           const int t = (int)(kw[s] >> 24) & (kTMaxI - 1);
-          const uint2 cc = sh.ck[t];
+          const uint2 cc = kc[s];
           unsigned imp = j_eval4(cc.x, (int)cc.y, ka[s], kb[s]);
           imp = dpp_quad_sum((kw[s] >> 28) ? 0u : imp);
           if (qj == 0 && imp) atomicAdd(&sh.delta[t], (unsigned long long)imp);
@@ -835,6 +884,7 @@ __global__ __launch_bounds__(kG3Threads) void mbk_init3_kernel(const uint32_t* _
         unsigned m = 0;
         for (int b = sb * 16; b < min(sb * 16 + 16, nb); ++b) m = max(m, blk[b].w);
         sup[sb].w = m;
+        supw[sb] = m;
       }
       if (tid == 0) sh.n_touch2[c & 1] = 0;
       __syncthreads();
