@@ -23,6 +23,15 @@
 //     whole-wave scans (the second generation: chunked u64 scans over 1 024-draw sums, a row scan, a wave scan);
 //   * a pick whose work list overflows (the first ~100 picks, when almost every leaf can still improve) is evaluated by
 //     brute force over all samples, all waves side by side (no per-candidate enumeration).
+// Round 4, second half (4.60 -> 3.5 us per pick on one box, tools/chain_ab.py, same picks): WHAT THE PICK IS BOUND BY.  Not the dependent
+// round trips the first half of the round chased (merging five of them moved the pick by 1 %): the search phase is bound by the INSTRUCTIONS
+// THE FOUR WAVES OF A SIMD ISSUE TOGETHER (three search waves + one idle wave) and by the bytes they pull through the LDS.  Evidence: the idle
+// waves re-reading 256 leaf maxima per touched hyper -- bookkeeping for a hyper level that was switched off -- cost the search waves 9 % of the
+// pick; a dozen fewer instructions per search wave are worth 1 %; letting the lanes without a leaf read a stale list entry's leaf instead
+// of all reading entry 0 (fewer instructions, more LDS bytes) cost 2 %.  Hence: the supers' static boxes in registers, dense zero-padded
+// maxima, one ds_read_b128 per leaf entry, the targets computed by the idle last wave, 32-bit scans and arg-max while the potential fits,
+// straight-line code chosen by ONE wave-uniform branch (a branch per round between loads serialises them), and no wave-uniform test the
+// idle waves have to pay for with more than a few instructions.
 constexpr int kG3Threads = 1024;
 constexpr int kG3Waves = kG3Threads / 64;
 constexpr int kG3MaxLeaves = 6144;                      // leaf table in LDS: 96 KB = 98 304 init samples
@@ -62,7 +71,7 @@ constexpr bool kG3HypSkip = RHCCQ_G3_HYPSKIP != 0;
 #define RHCCQ_G3_FIRSTQ 6
 #endif
 #ifndef RHCCQ_G3_KEEP
-#define RHCCQ_G3_KEEP 1
+#define RHCCQ_G3_KEEP 2
 #endif
 constexpr int kG3Keep = RHCCQ_G3_KEEP;                              // evaluation instruction streams (16 items each) a wave keeps in registers
 
@@ -89,6 +98,23 @@ __device__ __forceinline__ unsigned half_incscan_u32(unsigned v) {
   v += (unsigned)__builtin_amdgcn_update_dpp(0, (int)v, 0x118, 0xF, 0xF, true);   // row_shr:8  -> scan inside each row of 16
   v += (unsigned)__builtin_amdgcn_update_dpp(0, (int)v, 0x142, 0xA, 0xF, false);  // row_bcast:15 into rows 1 and 3
   return v;
+}
+// (measured and dropped: the items counter's fetch-and-add as a hand-written ds_add_rtn_u32 instead of atomicAdd() under `if (lane == 0)` with the
+// compiler's wave-aggregation around it -- 3.60 vs 3.57 us per pick: the inline wait and memory clobber cost more than the dozen instructions saved)
+// a whole 16-byte table entry in ONE ds_read_b128: left alone the compiler fetches box and maximum separately (b96 + b32), and 64 lanes reading
+// 4 bytes at a 16-byte stride keep the LDS as busy as the 12-byte part does
+#ifndef RHCCQ_G3_B128
+#define RHCCQ_G3_B128 1
+#endif
+__device__ __forceinline__ uint4 g3_lds_b128(const uint4* p) {
+  if (!RHCCQ_G3_B128) return *p;
+  typedef unsigned v4u __attribute__((ext_vector_type(4)));
+  const v4u v = *(const volatile __attribute__((address_space(3))) v4u*)p;      // (an LDS pointer: a generic volatile access would become a flat load)
+  return make_uint4(v.x, v.y, v.z, v.w);
+}
+// ... plus a base: v_mbcnt adds its last operand for free
+__device__ __forceinline__ int g3_rank_add(unsigned long long m, int base) {
+  return (int)__builtin_amdgcn_mbcnt_hi((unsigned)(m >> 32), __builtin_amdgcn_mbcnt_lo((unsigned)m, (unsigned)base));
 }
 __device__ __forceinline__ unsigned dpp_quad_sum(unsigned v) {
   v += (unsigned)__builtin_amdgcn_update_dpp(0, (int)v, 0xB1, 0xF, 0xF, true);    // quad_perm [1,0,3,2]
@@ -208,6 +234,8 @@ __global__ __launch_bounds__(kG3Threads) void mbk_init3_kernel(const uint32_t* _
     const unsigned ds = wave_sum_u32(dsamp[(d << 6) + lane].y);
     if (lane == 0) dsum[d] = ds;
   }
+  for (int d = nd + tid; d < kG3MaxDsum; d += kG3Threads) dsum[d] = 0u;        // (zero sums beyond the last block: the search reads whole rows of 64 unclamped)
+  for (int i = tid; i < kTMaxI * kG3WList / 2; i += kG3Threads) reinterpret_cast<uint32_t*>(wlist)[i] = 0u;   // (a stale list entry always names a super)
   __syncthreads();
   for (int sb = tid; sb < nsb; sb += kG3Threads) {
     int r0 = 255, g0 = 255, b0 = 255, r1 = 0, g1 = 0, b1 = 0;
@@ -289,7 +317,7 @@ __global__ __launch_bounds__(kG3Threads) void mbk_init3_kernel(const uint32_t* _
       unsigned long long R[kCW], rv[kCW];
       const unsigned v_top = dtop[min(lane, ntop - 1)];       // (the targets and the top level of the sums in ONE round trip)
       uint4 hyp_e = make_uint4(0, 0, 0, 0);
-      if constexpr (kCW == 1 && kG3RegBox && kG3HypSkip) hyp_e = hyp[min(lane, nhyp - 1)];
+      if constexpr (kCW == 1 && kG3RegBox && kG3HypSkip) hyp_e = g3_lds_b128(&hyp[min(lane, nhyp - 1)]);
 #pragma unroll
       for (int c2 = 0; c2 < kCW; ++c2) {
         tc[c2] = wave + c2 * NW;
@@ -334,11 +362,11 @@ __global__ __launch_bounds__(kG3Threads) void mbk_init3_kernel(const uint32_t* _
       {
         unsigned v2[kCW];
 #pragma unroll
-        for (int c2 = 0; c2 < kCW; ++c2) v2[c2] = dsum[min(l1[c2] * 64 + lane, nd - 1)];
+        for (int c2 = 0; c2 < kCW; ++c2) v2[c2] = dsum[l1[c2] * 64 + lane];      // (l1 < 24: inside the zero-padded table)
         __builtin_amdgcn_sched_barrier(0);
 #pragma unroll
         for (int c2 = 0; c2 < kCW; ++c2) {
-          const unsigned w2 = l1[c2] * 64 + lane < nd ? v2[c2] : 0u;
+          const unsigned w2 = v2[c2];
           const unsigned inc2 = wave_incscan_u32(w2);
           const unsigned long long m2 = __ballot(w2 > 0 && (inc2 - w2) < rr[c2] && rr[c2] <= inc2);
           found[c2] = found[c2] && m2 != 0ull;
@@ -350,13 +378,13 @@ __global__ __launch_bounds__(kG3Threads) void mbk_init3_kernel(const uint32_t* _
       {
         uint2 sv[kCW];
 #pragma unroll
-        for (int c2 = 0; c2 < kCW; ++c2) sv[c2] = dsamp[min((bh[c2] << 6) + lane, np - 1)];
+        for (int c2 = 0; c2 < kCW; ++c2) sv[c2] = dsamp[(bh[c2] << 6) + lane];      // (bh names a real block; the slots behind the last sample hold closest = 0)
         __builtin_amdgcn_sched_barrier(0);
 #pragma unroll
         for (int c2 = 0; c2 < kCW; ++c2) {
           const int i = (bh[c2] << 6) + lane;
-          const unsigned inc3 = wave_incscan_u32(i < n ? sv[c2].y : 0u);          // 64 x 195075 fits 32 bits
-          const unsigned long long m3 = __ballot(i < n && inc3 >= rr3[c2]);
+          const unsigned inc3 = wave_incscan_u32(sv[c2].y);                       // 64 x 195075 fits 32 bits
+          const unsigned long long m3 = __ballot(inc3 >= rr3[c2]);               // (a padding slot adds nothing: never the first lane to reach the target)
           const int l3 = m3 ? __ffsll((long long)m3) - 1 : min(63, n - 1 - (bh[c2] << 6));
           // R = 0: position 0; a target beyond the total (cannot happen): the last sample
           cand[c2] = found[c2] ? (bh[c2] << 6) + l3 : (R[c2] == 0 ? 0 : n - 1);
@@ -431,7 +459,7 @@ __global__ __launch_bounds__(kG3Threads) void mbk_init3_kernel(const uint32_t* _
             if (kG3HypSkip && ((hyp_m >> (4 * r)) & 15u) == 0u) continue;      // (wave-uniform)
             const bool h = d2[r] < sw[r];                   // (kCW == 1: the wave's candidate exists; lanes beyond the last super read a zero maximum)
             const unsigned long long m = __ballot(h);
-            if (h) wlist[tc[0] * kG3WList + n_sup[0] + g3_rank_in(m)] = (uint16_t)(r * 64 + lane);
+            if (h) wlist[g3_rank_add(m, tc[0] * kG3WList + n_sup[0])] = (uint16_t)(r * 64 + lane);
             n_sup[0] += __popcll(m);
           }
         };
@@ -487,8 +515,8 @@ __global__ __launch_bounds__(kG3Threads) void mbk_init3_kernel(const uint32_t* _
 #pragma unroll
           for (int q = 0; q < kNq; ++q) {
             const int b = (int)sq[c2][q] * 16 + rj;
-            bq[c2][q] = ((int)(4 * q + rq < n_sup[c2]) & (int)(b < nb)) ? b : -1;
-            be[c2][q] = blk[max(bq[c2][q], 0)];
+            bq[c2][q] = ((int)(4 * q + rq < n_sup[c2]) & (int)(b < nb)) ? b : -1;      // (the lanes without a leaf all read entry 0: one broadcast.
+            be[c2][q] = g3_lds_b128(&blk[max(bq[c2][q], 0)]);                          //  Measured: letting them read whatever a stale list entry names costs 2 %)
           }
         __builtin_amdgcn_sched_barrier(0);
         int total = 0;
@@ -524,7 +552,7 @@ __global__ __launch_bounds__(kG3Threads) void mbk_init3_kernel(const uint32_t* _
             for (int c2 = 0; c2 < kCW; ++c2)
 #pragma unroll
               for (int q = 0; q < kNq; ++q) {
-                if (hb[c2][q]) items[base + g3_rank_in(mb[c2][q])] = ((uint32_t)tc[c2] << 24) | (uint32_t)bq[c2][q];
+                if (hb[c2][q]) items[g3_rank_add(mb[c2][q], base)] = ((uint32_t)tc[c2] << 24) | (uint32_t)bq[c2][q];
                 base += __popcll(mb[c2][q]);
               }
           }
@@ -564,7 +592,7 @@ __global__ __launch_bounds__(kG3Threads) void mbk_init3_kernel(const uint32_t* _
           for (int q = 0; q < 4; ++q) {
             const int b = (int)sq[q] * 16 + rj;
             bq[q] = ((int)(h0 + 4 * q + rq < n_sup[c2]) & (int)(b < nb)) ? b : -1;
-            be[q] = blk[max(bq[q], 0)];
+            be[q] = g3_lds_b128(&blk[max(bq[q], 0)]);
           }
           __builtin_amdgcn_sched_barrier(0);
           int total = 0;
@@ -688,6 +716,7 @@ __global__ __launch_bounds__(kG3Threads) void mbk_init3_kernel(const uint32_t* _
 #pragma unroll
     for (int s = 0; s < kG3Keep; ++s) wpre[s] = kIW ? 0u : items[16 * (wave + s * kG3Waves) + quad];
     const int ovf_ = sh.overflow, nit_ = sh.n_items;
+    const int ntp_ = sh.n_touch2[(c - 1) & 1];             // (the PREVIOUS pick's touch count, stable until this pick's closing barrier: see the rebuild below)
     __builtin_amdgcn_sched_barrier(0);
     const bool use_list = ovf_ == 0;
     const int n_items = use_list ? nit_ : 0;
@@ -878,8 +907,10 @@ __global__ __launch_bounds__(kG3Threads) void mbk_init3_kernel(const uint32_t* _
     STAMP(6);
     __syncthreads();
     STAMP(7);
-    // more touched leaves than the list holds, or a brute-force pick: rebuild every super maximum
-    if (!use_list || sh.n_touch2[c & 1] > kG3Touch) {
+    // a brute-force pick, or more touched leaves than the list held in the PREVIOUS pick: rebuild every super maximum.  (The overflow is
+    // noticed one pick late, with a read that rides on phase 3's: asking for this pick's count here was a round trip of its own for every
+    // wave between two picks.  Until then the supers the list could not name keep their old, larger maxima: conservative.)
+    if (!use_list || ntp_ > kG3Touch) {
       for (int sb = tid; sb < nsb; sb += kG3Threads) {
         unsigned m = 0;
         for (int b = sb * 16; b < min(sb * 16 + 16, nb); ++b) m = max(m, blk[b].w);
