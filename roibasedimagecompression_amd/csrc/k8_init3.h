@@ -141,6 +141,10 @@ __device__ __forceinline__ void g3_store1(int imp, int newcp, unsigned nx, uint3
 
 // one quad = one leaf (lane j of the quad holds samples 4j .. 4j+3 in a, bb): lower closest[] against the new centre,
 // refresh the leaf's max, note its super as touched.  Straight-line code but for the stores.
+// (Measured and dropped: the quad refreshing the super's and the hyper's maximum itself, right here, instead of the touch list the idle
+// waves work off during the next search -- 3.79 vs 3.52 us per pick.  The leaves a winner improves are Morton neighbours, i.e. leaves
+// of the SAME super held by different waves: each refresh misses the others' new maxima, writes a value that is too large, and the
+// search pays for the stale maxima with leaf tests.)
 __device__ __forceinline__ void g3_commit_quad(bool on, int b, uint32_t ck, int na, const uint4& a, const uint4& bb, uint2* samp, uint2* dsamp,
                                                uint4* blk, uint32_t* dsum, uint32_t* dtop, int* touch, int* n_touch) {
   const int j = threadIdx.x & 3;
