@@ -383,6 +383,7 @@ __global__ __launch_bounds__(kG3Threads) void mbk_init3_kernel(const uint32_t* _
         uint2 sv[kCW];
 #pragma unroll
         for (int c2 = 0; c2 < kCW; ++c2) sv[c2] = dsamp[(bh[c2] << 6) + lane];      // (bh names a real block; the slots behind the last sample hold closest = 0)
+        // (measured, no gain: requesting the supers' maxima here, so that they arrive during this L2 round trip -- 3.53 vs 3.54 us per pick)
         __builtin_amdgcn_sched_barrier(0);
 #pragma unroll
         for (int c2 = 0; c2 < kCW; ++c2) {
