@@ -1,5 +1,5 @@
 """soak (GPU box): the generations of the k-means++ chain (and, where it fits, the register chain of kpp_flat.h) on random problems -- picks must be identical.  Not part of the
-test-suite; python tests/soak/chain_soak.py [n_problems] [seed]"""
+test-suite; python tests/soak/chain_soak.py [n_problems] [seed] [big]   (big: 4K-sized problems, 60 000 - 98 000 init samples, k up to 32 000)"""
 import os, sys, math
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__)))))
 import numpy as np
@@ -9,9 +9,10 @@ n_prob = int(sys.argv[1]) if len(sys.argv) > 1 else 40
 rng = np.random.default_rng(int(sys.argv[2]) if len(sys.argv) > 2 else 2026)
 rh = Rhccq(0)
 bad = 0
+big = len(sys.argv) > 3 and sys.argv[3] == "big"
 for it in range(n_prob):
     kind = it % 4
-    n = int(rng.integers(10000, 120000))
+    n = int(rng.integers(10000, 120000)) if not big else int(rng.integers(400000, 900000))
     if kind == 0:                                           # uniform cube of varying side
         P = rng.integers(0, int(rng.integers(24, 256)), (n, 3))
     elif kind == 1:                                         # a few blobs
@@ -26,6 +27,10 @@ for it in range(n_prob):
     if len(P) < 10000:
         continue
     k = int(rng.integers(8, max(9, min(len(P) // 3, 9000 if it % 2 else 2700))))     # (every other problem small enough for the register chain)
+    if big:
+        if len(P) < 100000:
+            continue
+        k = int(rng.integers(20000, min(len(P) // 3, 32700)))                       # 3 k init samples <= 98 304: the third generation's table
     keys = pack_rgb(P)
     got = {}
     gens = (0, 5, 2, 1) + ((4,) if (3000 if k <= 3000 else 3 * k) <= 8192 and it % 5 != 4 else ())   # (the register chain has no work list to shrink)
