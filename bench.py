@@ -564,7 +564,6 @@ def main():
                           "ms_per_step": (time.perf_counter() - t1) / args.steps * 1e3}
         px = H * W * args.steps * world * B
         workload = ((f"configs[1]: single {W}x{H} RGB synthetic 'photo' frame per GPU (seed 1234+rank, sigma={args.sigma}), " if B == 1 else
-                     ("configs[2]: " if batch_mode else "") +
                      f"batch of {B} {W}x{H} RGB synthetic 'photo' frames per GPU per step (seeds 1234+rank*{B}+i, sigma={args.sigma}), ")
                     + (f"one quality tier q={q_roi} (levels {q_roi}/{min(2 * q_roi, 100)}/{min(4 * q_roi, 100)}), " if q_roi == q_bg else f"quality tiers ({q_roi},{q_bg}), ")
                     + f"2 segments per class, ROI ellipse 35 % + 3 px overlap; {block}x{block} DCT + two-tier quantisation extension in the timed region")
