@@ -9,8 +9,9 @@ A "step" = one pass of the hot path over one batch of synthetic input resident i
           but the reference does not contain; the extension is inside the timed region so that no
           named work is skipped, its share is reported in `stages_ms`.  Frames are independent: every rank encodes its
           own frame, no data-path collective; value = pixels of all ranks / max-over-ranks time ("weak").
-  batch   (configs[2]) a batch of 64 1920x1080 frames per GPU through FrameEncoder.encode_batch (one batched clustering call per
-          level for all frames), two quality tiers (20, 10); value = pixels of all ranks / time ("weak").
+  batch   (configs[2]) a batch of 64 distinct 1920x1080 frames per GPU and step, as two sub-batches of 32 in flight through
+          stream.StreamEncoder (each one FrameEncoder.encode_batch: one batched clustering call per level for its frames),
+          two quality tiers (20, 10); value = pixels of all ranks / time ("weak").
   tiled   (configs[3]) ONE 7680x4320 frame cut into one tile per GPU (2x4 at 8 GPUs), pixels stay tile-local, palettes
           are exchanged: 1 all-gather (segment bitmaps + stats) + up to 3 small MIN all-reduces over RCCL
           (parallel.TiledFrameEncoder); value = frame pixels / max-over-ranks time ("strong").
