@@ -117,7 +117,10 @@ __global__ __launch_bounds__(kKmThreads) void kmeans_kernel(const uint32_t* __re
   // ---- k-means++ in exact integers ----------------------------------------------------------
   // (up to 10 points per thread: every point in a register, two barriers per pick -- kpp_flat.h; the loop below, a block scan, a
   // candidate search and a block reduction per pick, ~7 us each, serves larger inputs)
-  if (n <= kKmFlatS * kKmThreads) {
+  if (n <= 16 * 64 * 4) {
+    __syncthreads();      // (small inputs -- the one large split of a 4K frame's level 3 has 3 900 colours: four working waves, see kpp_flat.h)
+    kpp_flat<16, 4>([&](int i) { return P[i]; }, n, k, T, first, rand + rand_off, chosen, *reinterpret_cast<FlatShared*>(s_sum));
+  } else if (n <= kKmFlatS * kKmThreads) {
     __syncthreads();
     kpp_flat<kKmFlatS, kKmWaves>([&](int i) { return P[i]; }, n, k, T, first, rand + rand_off, chosen, *reinterpret_cast<FlatShared*>(s_sum));
   } else {

@@ -41,12 +41,17 @@ __device__ __forceinline__ unsigned flat_incscan_u32(unsigned v) {   // inclusiv
 
 // skey(i): colour of the sample at draw position i (0 <= i < n); n <= kS * blockDim.x; rand: (k - 1) * T uniforms in pick order;
 // chosen[0 .. k): the draw positions picked (chosen[0] = first).  All threads of the workgroup call; ends with a barrier.
-template <int kS, int kW, typename KeyFn>                      // kW = waves of the workgroup (blockDim.x == 64 kW)
+// kW: the waves that WORK (the first kW of the workgroup; the others only keep the barriers company).  A pick is bound by the instructions
+// the waves of a SIMD issue together, and every working wave pays the per-candidate bookkeeping (a DPP scan, a range test, the arg-min) once
+// per pick whatever its share of the samples: 3 900 samples over 4 waves x 16 samples per lane instead of 16 x 4 is the same arithmetic with
+// a quarter of the bookkeeping.
+template <int kS, int kW, typename KeyFn>
 __device__ __forceinline__ void kpp_flat(KeyFn skey, const int n, const int k, const int T, const int first, const double* __restrict__ rand,
                                          int* __restrict__ chosen, FlatShared& sh) {
   static_assert(kW % 4 == 0 && kW <= kFlatWaves, "wave totals are read four at a time");
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
   constexpr int nw = kW;
+  const bool act = wave < kW;                                       // (wave-uniform)
   const int S = (n + 64 * kW - 1) / (64 * kW);                      // samples per thread (<= kS)
   const int i0 = tid * S;
   // per sample: the colour, |x|^2 and c' = closest - |x|^2, so that min(closest, d(x, c)) = |x|^2 + min(c', |c|^2 - 2 <x, c>):
@@ -58,7 +63,7 @@ __device__ __forceinline__ void kpp_flat(KeyFn skey, const int n, const int k, c
 #pragma unroll
   for (int s = 0; s < kS; ++s) {
     const int i = i0 + s;
-    const bool in = s < S && i < n;
+    const bool in = act && s < S && i < n;
     key[s] = in ? skey(i) : kf;
     na[s] = (int)norm2_key(key[s]);
     const int cl = in ? dist2_keys(key[s], kf) : 0;                 // (samples beyond n: closest 0, never a candidate, never a gain)
@@ -70,7 +75,7 @@ __device__ __forceinline__ void kpp_flat(KeyFn skey, const int n, const int k, c
   unsigned long long pot, base;
   {
     const unsigned inc = flat_incscan_u32(loc);                       // <= 64 x 16 x 195 075 < 2^32
-    if (lane == 63) sh.red[wave] = inc;
+    if (lane == 63 && act) sh.red[wave] = inc;
     if (tid < T && k > 1) sh.u[1][tid] = rand[tid];
     __syncthreads();
     unsigned long long before = 0, tot = 0;
@@ -87,6 +92,11 @@ __device__ __forceinline__ void kpp_flat(KeyFn skey, const int n, const int k, c
 #endif
   for (int c = 1; c < k; ++c) {
     const int par = c & 1;
+    if (!act) {                                                        // (the idle waves: two barriers per pick, as everybody)
+      __syncthreads();
+      __syncthreads();
+      continue;
+    }
     const double un = (tid < T && c + 1 < k) ? rand[(size_t)c * T + tid] : 0.0;     // next pick's uniforms: in flight during this pick
     const double dpot = (double)pot;
     // ---- search: np.searchsorted(cumsum(closest), u * pot, 'left') clipped to n - 1, over the draw order.  The sums are integers
