@@ -25,7 +25,7 @@
 
 namespace rhccq {
 
-constexpr int kEpsThreads = 512;
+constexpr int kEpsThreads = 1024;   // (round 4: was 512 -- a lone level-3 palette of ~5 000 colours keeps one CU busy for 1.5 ms: four waves per SIMD instead of two)
 constexpr int kMaxCells = 4096;  // 16^3 (global-memory variant)
 
 struct EpsArrays {
@@ -256,7 +256,7 @@ __global__ __launch_bounds__(kEpsThreads) void eps_components_lds_kernel(const u
   __shared__ uint32_t s_parent[RHCCQ_EPS_LDS_MAX];
   __shared__ unsigned short s_perm[RHCCQ_EPS_LDS_MAX];
   __shared__ uint32_t s_cell[kFastWords];
-  __shared__ unsigned s_red[16];
+  __shared__ unsigned s_red[20];
   const int p = blockIdx.x, tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, n_waves = kEpsThreads / 64;
   const int off = desc[p * 4 + 0], n = desc[p * 4 + 1], thr = desc[p * 4 + 2], boundary = desc[p * 4 + 3];
   if (n <= 0) {
@@ -454,7 +454,7 @@ __global__ __launch_bounds__(kEpsThreads) void eps_components_kernel(const uint3
                                                                       int work_stride) {
   __shared__ unsigned s_cell_start[kMaxCells + 1];
   __shared__ unsigned s_cell_fill[kMaxCells];
-  __shared__ unsigned s_red[16];
+  __shared__ unsigned s_red[20];
   const int p = blockIdx.x;
   const int off = desc[p * 4 + 0], n = desc[p * 4 + 1], thr = desc[p * 4 + 2], boundary = desc[p * 4 + 3];
   if (n <= 0) {
