@@ -211,14 +211,15 @@ def chain_probe(rh, enc, rgb, specs, ms_per_step):
     ops = 8.0 * pairs
     sec = t["init_ms"] * 1e-3
     gen3 = max(max(3 * k, 3000) for k in ks) <= 98304
-    return {"bound": "valu-latency (neither hbm nor mfma: a sequential chain of dependent picks on one CU per problem)",
+    return {"bound": "valu-issue on one CU per problem (neither hbm nor mfma: a sequential chain of dependent picks)",
             "kernel": "mbk_init3_kernel" if gen3 else "mbk_init2_kernel", "achieved": ops / sec / 1e12, "peak": VALU_PEAK_TOPS,
             "unit": "Tops/s (brute-force equivalent)", "frac": ops / sec / 1e12 / VALU_PEAK_TOPS, "traffic": None,
             "launch_ms": t["init_ms"], "problems": len(ks), "picks_longest_chain": max(ks),
             "us_per_pick": t["init_ms"] * 1e3 / max(ks), "share_of_step": t["init_ms"] / ms_per_step,
             "brute_force_pair_evaluations": pairs, "cus_occupied": len(ks), "cus": N_CUS,
             "note": "one workgroup per problem; the chain cannot leave its CU: the per-pick time (candidate search + box descent -> evaluate -> "
-                    "commit, 3 barriers, 2 L2 round trips) sets the step, not throughput"}
+                    "commit, 3 barriers) sets the step; a pick is bound by the instructions the four waves of a SIMD issue together "
+                    "(~8 500 wave-instructions over 4 SIMDs x 4 cycles), DESIGN.md section 8"}
 
 
 def pixel_probe(rh, rgb, iters=10):
