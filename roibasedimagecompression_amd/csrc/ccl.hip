@@ -335,7 +335,8 @@ __global__ __launch_bounds__(256) void ccl_keys_kernel(const int32_t* __restrict
                                                        uint32_t* __restrict__ keys) {
   const long long p = (long long)blockIdx.x * 256 + threadIdx.x;
   if (p >= (long long)H * W) return;
-  const int y = (int)(p / W), x = (int)(p % W);
+  int y, x;
+  rhccq_row_col(p, W, y, x);
   const int l = labels[p];
   if (l <= 0 || (x > 0 && labels[p - 1] == l)) return;
   const long long gy = y0 + y, gx = x0 + x;

@@ -65,7 +65,9 @@ __global__ __launch_bounds__(256) void edges_gradhist_kernel(const uint8_t* __re
   const long long n = (long long)H * W;
   for (long long p = (long long)blockIdx.x * 256 + threadIdx.x; p < n; p += (long long)gridDim.x * 256) {
     int gx, gy;
-    sobel3<1, false>(gray, H, W, (int)(p / W), (int)(p % W), 0, gx, gy);
+    int y, x;
+    rhccq_row_col(p, W, y, x);
+    sobel3<1, false>(gray, H, W, y, x, 0, gx, gy);
     const int m2 = gx * gx + gy * gy;
     if (m2 < kM2Lds) atomicAdd(&s_h[m2], 1);
     else atomicAdd(&hist[m2], 1);
@@ -80,7 +82,8 @@ template <int kCn>
 __global__ __launch_bounds__(256) void canny_grad_kernel(const uint8_t* __restrict__ img, int H, int W, uint16_t* __restrict__ mag, int32_t* __restrict__ dxy) {
   const long long p = (long long)blockIdx.x * 256 + threadIdx.x;
   if (p >= (long long)H * W) return;
-  const int y = (int)(p / W), x = (int)(p % W);
+  int y, x;
+  rhccq_row_col(p, W, y, x);
   int bx = 0, by = 0, bm = -1;
 #pragma unroll
   for (int c = 0; c < kCn; ++c) {
@@ -98,7 +101,8 @@ __global__ __launch_bounds__(256) void canny_nms_kernel(const uint16_t* __restri
                                                         uint16_t* __restrict__ nm) {
   const long long p = (long long)blockIdx.x * 256 + threadIdx.x;
   if (p >= (long long)H * W) return;
-  const int y = (int)(p / W), x = (int)(p % W);
+  int y, x;
+  rhccq_row_col(p, W, y, x);
   const int m = mag[p];
   uint16_t out = 0;
   if (m > 0) {
@@ -203,7 +207,8 @@ __global__ __launch_bounds__(256) void hy_link_kernel(const uint16_t* __restrict
   if (p >= n) return;
   const int v = nm[p];
   if (!(v > lo && v <= hi_prev)) return;
-  const int y = (int)(p / W), x = (int)(p - (long long)y * W);
+  int y, x;
+  rhccq_row_col(p, W, y, x);
 #pragma unroll
   for (int dy = -1; dy <= 1; ++dy)
 #pragma unroll

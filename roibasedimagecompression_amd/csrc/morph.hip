@@ -66,7 +66,9 @@ __global__ __launch_bounds__(256) void morph_dilate_kernel(const uint8_t* __rest
 __global__ __launch_bounds__(256) void box_filter_seq_kernel(const uint8_t* __restrict__ plane, int H, int W, int k, int scale255, float* __restrict__ out) {
   const long long p = (long long)blockIdx.x * 256 + threadIdx.x;
   if (p >= (long long)H * W) return;
-  const int y = (int)(p / W), x = (int)(p % W), c = k / 2;
+  int y, x;
+  rhccq_row_col(p, W, y, x);
+  const int c = k / 2;
   const float term = 1.0f / (float)(k * k);
   float acc = 0.0f;
   for (int dy = 0; dy < k; ++dy) {
@@ -101,7 +103,8 @@ __global__ __launch_bounds__(256) void gap_bridge_kernel(const uint8_t* __restri
   if (in[p] != 0) { out[p] = 255; return; }
   uint8_t v = 0;
   if ((long long)counts[p] >= min_count) {
-    const int y = (int)(p / W), x = (int)(p % W);
+    int y, x;
+    rhccq_row_col(p, W, y, x);
     auto ray = [&](int dx, int dy) {
       for (int t = 1; t <= reach; ++t)
         if (in[(long long)m_reflect101(y + dy * t, H) * W + m_reflect101(x + dx * t, W)] != 0) return true;
@@ -163,7 +166,8 @@ __global__ __launch_bounds__(256) void dist_hz_kernel(const uint8_t* __restrict_
 __global__ __launch_bounds__(256) void dist_chamfer_kernel(const uint16_t* __restrict__ hz, int H, int W, int32_t* __restrict__ dist) {
   const long long p = (long long)blockIdx.x * 256 + threadIdx.x;
   if (p >= (long long)H * W) return;
-  const int y = (int)(p / W), x = (int)(p % W);
+  int y, x;
+  rhccq_row_col(p, W, y, x);
   const int h0 = hz[p];
   if (h0 == 0) { dist[p] = 0; return; }
   long long best = h0 == kHzNone ? (long long)kChamMax : (long long)h0 * kChamA;
@@ -191,7 +195,8 @@ __global__ __launch_bounds__(256) void binary_sobel_kernel(const uint8_t* __rest
   const long long p = (long long)blockIdx.x * 256 + threadIdx.x;
   int v = 0;
   if (p < (long long)H * W) {
-    const int y = (int)(p / W), x = (int)(p % W);
+    int y, x;
+    rhccq_row_col(p, W, y, x);
     const int ym = m_reflect101(y - 1, H), yp = m_reflect101(y + 1, H), xm = m_reflect101(x - 1, W), xp = m_reflect101(x + 1, W);
     auto at = [&](int yy, int xx) { return mask[(long long)yy * W + xx] != 0 ? 1 : 0; };
     const int a = at(ym, xm), b = at(ym, x), c = at(ym, xp), d = at(y, xm), f = at(y, xp), g = at(yp, xm), h = at(yp, x), i = at(yp, xp);

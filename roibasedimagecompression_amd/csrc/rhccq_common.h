@@ -93,6 +93,19 @@ __device__ __forceinline__ T wave_sum(T v) {
 }
 
 // block-wide sum; `red` must hold blockDim.x/64 elements; result returned to every thread
+// row and column of linear pixel index p in rows of W: ONE 32-bit division for every image of fewer than 2^32 pixels (all of them),
+// instead of a 64-bit division and a 64-bit remainder -- ~200 instructions that were most of what the light per-pixel kernels did
+__device__ __forceinline__ void rhccq_row_col(long long p, int W, int& y, int& x) {
+  if ((unsigned long long)p >> 32) {
+    y = (int)(p / W);
+    x = (int)(p - (long long)y * W);
+  } else {
+    const unsigned q = (unsigned)p / (unsigned)W;
+    y = (int)q;
+    x = (int)((unsigned)p - q * (unsigned)W);
+  }
+}
+
 template <typename T>
 __device__ __forceinline__ T block_sum(T v, T* red) {
   const int lane = threadIdx.x & 63, w = threadIdx.x >> 6, nw = (blockDim.x + 63) >> 6;

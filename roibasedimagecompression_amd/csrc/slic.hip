@@ -35,7 +35,8 @@ __global__ __launch_bounds__(256) void slic_assign_kernel(const double* __restri
   if (p >= (long long)H * W) return;
   int best = 0;
   if (mask[p]) {
-    const int y = (int)(p / W), x = (int)(p - (long long)y * W);
+    int y, x;
+    rhccq_row_col(p, W, y, x);
     const double inv = 1.0 / (step * step);
     const double i0 = img[p * 3], i1 = img[p * 3 + 1], i2 = img[p * 3 + 2];
     double bd = 1.7976931348623157e308;
