@@ -48,7 +48,9 @@ constexpr int kG3Touch = 512;
 // of the hit hypers): same picks (tests/test_gpu_kernels.py with this switched on), ~2 rounds of box tests instead of 6 -- and SLOWER where it
 // matters: 4.50 vs 4.24 us per pick at k = 30 128, 4.2 vs 4.2 at k = 20 556, 3.10 vs 3.31 at k = 2 314 (round 4, MI355X, inside a frame).  The
 // extra dependent LDS round trips (hyper table -> scalar bit walk -> super table) cost more than the ~80 box-test instructions they save:
-// each search wave is a chain of dependent latencies, not an issue-bound stream.  Kept as a checked alternative, off.
+// each search wave is a chain of dependent latencies, not an issue-bound stream.  Kept as a checked alternative, off.  (That explanation was
+// the belief of the time; what the hyper level really cost was the bookkeeping it needs -- the idle waves re-reading 256 leaf maxima per
+// touched hyper, 9 % of the pick, see above -- and its data-dependent loop.  kG3HypSkip below is what survived of the idea.)
 constexpr bool kG3UseHypers = false;
 // round 4: a super's BOX never changes after the tables are built (only its maximum does), so every lane keeps the boxes of "its" supers
 // (lane + 64 r, r < 6) in 18 registers for the whole chain: the super stage then fetches only the six maxima (4 B instead of 16 B per
@@ -68,7 +70,7 @@ constexpr bool kG3RegBox = RHCCQ_G3_REGBOX != 0;
 #endif
 constexpr bool kG3HypSkip = RHCCQ_G3_HYPSKIP != 0;
 #ifndef RHCCQ_G3_FIRSTQ
-#define RHCCQ_G3_FIRSTQ 6
+#define RHCCQ_G3_FIRSTQ 6                                             // rounds of 4 supers the first, straight-line leaf batch reaches (24 supers; 4 and 8 measured: section 8 of DESIGN.md)
 #endif
 #ifndef RHCCQ_G3_KEEP
 #define RHCCQ_G3_KEEP 2
